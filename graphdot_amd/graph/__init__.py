@@ -1,0 +1,175 @@
+"""Graph container feeding the marginalized graph kernel.
+
+Only the input surface the hot path needs is provided (scope):
+``Graph(nodes, edges, title)``, ``from_networkx``, ``unify_datatype``,
+``has_unified_types``, ``permute``, ``copy``, ``cookie``,
+``adjacency_matrix``/``laplacian`` and ``to_networkx``.  Semantics follow the
+reference's ``graphdot/graph/__init__.py:40-357``; the chemistry importers
+(ase / pymatgen / rdkit) are out of scope.
+"""
+import copy as cp
+import itertools as it
+import numpy as np
+from ..codegen.typetool import common_min_type, is_scalar_type
+from ..minipandas import DataFrame
+from ..util.cookie import VolatileCookie
+from ._from_networkx import _from_networkx, _to_networkx
+
+__all__ = ['Graph']
+
+
+def _as_frame(d):
+    return d if isinstance(d, DataFrame) else DataFrame(d)
+
+
+class Graph:
+    """An undirected graph as two tables.
+
+    Parameters
+    ----------
+    nodes: DataFrame or dict of columns
+        One row per node; must have the index column ``!i``.
+    edges: DataFrame or dict of columns
+        One row per undirected edge; must have ``!i`` and ``!j`` and may have
+        a weight column ``!w``.
+    title: str
+    """
+
+    def __init__(self, nodes, edges, title=''):
+        self.title = str(title)
+        self.nodes = _as_frame(nodes)
+        self.edges = _as_frame(edges)
+        assert '!i' in self.nodes
+        assert '!i' in self.edges and '!j' in self.edges
+
+    def __repr__(self):
+        return (f'{type(self).__name__}(nodes={self.nodes!r}, '
+                f'edges={self.edges!r}, title={self.title!r})')
+
+    @property
+    def cookie(self):
+        """Backend-private cache, dropped on pickle/deepcopy/permute."""
+        try:
+            return self.__cookie
+        except AttributeError:
+            self.__cookie = VolatileCookie()
+            return self.__cookie
+
+    def copy(self, deep=False):
+        g = type(self)(nodes=self.nodes.copy(deep=deep),
+                       edges=self.edges.copy(deep=deep),
+                       title=self.title)
+        for key, val in self.__dict__.items():
+            if key in ('nodes', 'edges', 'title') or key.endswith('__cookie'):
+                continue
+            g.__dict__[key] = cp.deepcopy(val) if deep else val
+        return g
+
+    def permute(self, perm, inplace=False):
+        """Relabel node `perm[k]` as node `k`."""
+        if inplace:
+            g = self
+            self.cookie.clear()
+        else:
+            g = self.copy(deep=True)
+        iperm = np.argsort(perm)
+        g.nodes['!i'][:] = iperm[g.nodes['!i']]
+        g.edges['!i'][:] = iperm[g.edges['!i']]
+        g.edges['!j'][:] = iperm[g.edges['!j']]
+        return g
+
+    @property
+    def adjacency_matrix(self):
+        import scipy.sparse
+        n = len(self.nodes)
+        i = np.asarray(self.edges['!i'])
+        j = np.asarray(self.edges['!j'])
+        w = (np.asarray(self.edges['!w']) if '!w' in self.edges
+             else np.ones_like(i))
+        a = scipy.sparse.coo_matrix((w, (i, j)), shape=(n, n))
+        return a + a.T
+
+    @property
+    def laplacian(self):
+        import scipy.sparse
+        a = self.adjacency_matrix
+        d = np.asarray(a.sum(axis=0)).ravel()
+        return scipy.sparse.diags(d, 0) - a
+
+    @staticmethod
+    def has_unified_types(graphs):
+        """True, or ``(component, first, offender)`` on the first mismatch of
+        node/edge row types."""
+        first = next(iter(graphs))
+        node_t = first.nodes.rowtype()
+        edge_t = first.edges.rowtype()
+        for other in graphs:
+            if other.nodes.rowtype() != node_t:
+                return ('nodes', first, other)
+            if other.edges.rowtype() != edge_t:
+                return ('edges', first, other)
+        return True
+
+    @classmethod
+    def unify_datatype(cls, graphs, inplace=False):
+        """Give every attribute one dtype across all `graphs` (the smallest
+        type that holds all values; list-like attributes are converted to
+        ndarrays of a common element type)."""
+        for g in graphs:
+            g.cookie.clear()
+        if inplace is not True:
+            graphs = [g.copy(deep=False) for g in graphs]
+
+        for component in ('nodes', 'edges'):
+            frames = [getattr(g, component) for g in graphs]
+            names = set(frames[0].columns)
+            for g, f in zip(graphs, frames):
+                if set(f.columns) != names:
+                    raise TypeError(
+                        f'Graph {g} with {component} features '
+                        f'{set(f.columns)} does not match with the other '
+                        'graphs.')
+            for key in names:
+                types = [f[key].concrete_type for f in frames]
+                t = common_min_type.of_types(types)
+                if t == object or t == np.dtype(object):
+                    t = common_min_type.of_types(types, coerce=False)
+                if t is None:
+                    raise TypeError(
+                        f'Cannot unify attribute {key} containing mixed '
+                        'object types')
+                if is_scalar_type(t):
+                    for f in frames:
+                        f[key] = f[key].astype(t)
+                elif t in (list, tuple, np.ndarray):
+                    t_sub = common_min_type.of_values(
+                        it.chain.from_iterable(
+                            it.chain.from_iterable(f[key] for f in frames)))
+                    if t_sub is None:
+                        raise TypeError(
+                            f'Cannot find a common type for elements in '
+                            f'{key}.')
+                    for f in frames:
+                        f[key] = [np.array(seq, dtype=t_sub)
+                                  for seq in f[key]]
+        if inplace is not True:
+            return graphs
+
+    @classmethod
+    def from_networkx(cls, graph, weight=None):
+        """Convert an undirected NetworkX graph whose nodes (and edges) all
+        carry the same attribute names; `weight` names the edge attribute to
+        use as ``!w``."""
+        return _from_networkx(cls, graph, weight)
+
+    def to_networkx(self):
+        return _to_networkx(self)
+
+    # chemistry importers of the reference: out of scope
+    @classmethod
+    def from_ase(cls, *args, **kwargs):
+        raise NotImplementedError(
+            'from_ase is outside the MI355X hot-path scope; build a NetworkX '
+            'graph and use Graph.from_networkx instead.')
+
+    from_pymatgen = from_rdkit = from_smiles = from_ase
