@@ -1,0 +1,45 @@
+// wave64 primitives for gfx950: lane id, wave-wide sums (DPP within 16-lane
+// rows + v_readlane across rows), workgroup sums for multi-wave jobs.
+// (Role of the reference's graphdot/cpp/util_cuda.h:8-70, written for
+// 64-wide wavefronts.)
+#ifndef GRAPHDOT_HIP_WAVE_H_
+#define GRAPHDOT_HIP_WAVE_H_
+#include <hip/hip_runtime.h>
+
+namespace graphdot {
+namespace wave {
+
+constexpr int size = 64;
+
+__device__ __forceinline__ int laneid() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+template<int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+    return v + __int_as_float(t);
+}
+
+// Sum over the 64 lanes; every lane gets the same (bitwise identical) total.
+__device__ __forceinline__ float sum(float v) {
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror : 8-lane sums
+    v = dpp_add<0x140>(v);  // row_mirror      : 16-lane sums
+    float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    float s3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (s0 + s1) + (s2 + s3);
+}
+
+__device__ __forceinline__ double sum(double v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    // make the result exactly uniform (xor butterflies are, but be explicit)
+    return __shfl(v, 0, 64);
+}
+
+}  // namespace wave
+}  // namespace graphdot
+#endif

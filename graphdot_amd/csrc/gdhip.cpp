@@ -1,0 +1,215 @@
+// libgdhip.so -- thin C ABI over the HIP runtime for the marginalized graph
+// kernel path (declarations and the reference call sites each function
+// replaces: include/gdhip.h).  Host-only translation unit: the solver kernels
+// are JIT-generated HIP C++ compiled to gfx950 code objects and loaded here
+// through hipModuleLoadData.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "gdhip.h"
+
+namespace {
+thread_local std::string g_err;
+
+int fail(hipError_t e, const char *what) {
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+    g_err = buf;
+    return (int)e ? (int)e : -1;
+}
+int fail(const char *what) {
+    g_err = what;
+    return -1;
+}
+#define GD_TRY(expr)                                  \
+    do {                                              \
+        hipError_t e_ = (expr);                       \
+        if (e_ != hipSuccess) return fail(e_, #expr); \
+    } while (0)
+
+inline hipStream_t S(gd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline hipEvent_t E(gd_event_t e) { return reinterpret_cast<hipEvent_t>(e); }
+}  // namespace
+
+extern "C" {
+
+const char *gd_last_error(void) { return g_err.c_str(); }
+const char *gd_version(void) { return "gdhip 0.1 (gfx950)"; }
+
+int gd_device_count(int *count) {
+    if (!count) return fail("gd_device_count: null argument");
+    GD_TRY(hipGetDeviceCount(count));
+    return 0;
+}
+
+int gd_init(int device) {
+    GD_TRY(hipSetDevice(device));
+    GD_TRY(hipFree(nullptr));  // force context creation
+    return 0;
+}
+
+int gd_device_props(int device, gd_device_props_t *out) {
+    if (!out) return fail("gd_device_props: null argument");
+    hipDeviceProp_t p;
+    GD_TRY(hipGetDeviceProperties(&p, device));
+    std::memset(out, 0, sizeof *out);
+    std::strncpy(out->name, p.name, sizeof out->name - 1);
+    std::strncpy(out->arch, p.gcnArchName, sizeof out->arch - 1);
+    out->compute_units = p.multiProcessorCount;
+    out->wavefront_size = p.warpSize;
+    out->max_threads_per_block = p.maxThreadsPerBlock;
+    out->clock_khz = p.clockRate;
+    out->lds_per_block = (int64_t)p.sharedMemPerBlock;
+    out->total_mem = (int64_t)p.totalGlobalMem;
+    return 0;
+}
+
+int gd_device_sync(void) {
+    GD_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+int gd_malloc(void **dptr, size_t bytes) {
+    if (!dptr) return fail("gd_malloc: null argument");
+    *dptr = nullptr;
+    if (bytes == 0) return 0;
+    GD_TRY(hipMalloc(dptr, bytes));
+    return 0;
+}
+int gd_free(void *dptr) {
+    if (dptr) GD_TRY(hipFree(dptr));
+    return 0;
+}
+int gd_host_alloc(void **hptr, size_t bytes) {
+    if (!hptr) return fail("gd_host_alloc: null argument");
+    *hptr = nullptr;
+    if (bytes == 0) return 0;
+    GD_TRY(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return 0;
+}
+int gd_host_free(void *hptr) {
+    if (hptr) GD_TRY(hipHostFree(hptr));
+    return 0;
+}
+int gd_memcpy_h2d(void *dst, const void *src, size_t bytes, gd_stream_t s) {
+    if (bytes) GD_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, S(s)));
+    return 0;
+}
+int gd_memcpy_d2h(void *dst, const void *src, size_t bytes, gd_stream_t s) {
+    if (bytes) GD_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, S(s)));
+    return 0;
+}
+int gd_memcpy_d2d(void *dst, const void *src, size_t bytes, gd_stream_t s) {
+    if (bytes) GD_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, S(s)));
+    return 0;
+}
+int gd_memset(void *dst, int value, size_t bytes, gd_stream_t s) {
+    if (bytes) GD_TRY(hipMemsetAsync(dst, value, bytes, S(s)));
+    return 0;
+}
+
+int gd_module_load(const void *image, size_t bytes, gd_module_t *out) {
+    if (!image || !bytes || !out) return fail("gd_module_load: bad argument");
+    hipModule_t m;
+    GD_TRY(hipModuleLoadData(&m, image));
+    *out = reinterpret_cast<gd_module_t>(m);
+    return 0;
+}
+int gd_module_unload(gd_module_t m) {
+    if (m) GD_TRY(hipModuleUnload(reinterpret_cast<hipModule_t>(m)));
+    return 0;
+}
+int gd_module_get_function(gd_module_t m, const char *name, gd_function_t *out) {
+    if (!m || !name || !out) return fail("gd_module_get_function: bad argument");
+    hipFunction_t f;
+    GD_TRY(hipModuleGetFunction(&f, reinterpret_cast<hipModule_t>(m), name));
+    *out = reinterpret_cast<gd_function_t>(f);
+    return 0;
+}
+int gd_module_get_global(gd_module_t m, const char *name, void **dptr, size_t *bytes) {
+    if (!m || !name || !dptr) return fail("gd_module_get_global: bad argument");
+    hipDeviceptr_t p;
+    size_t n = 0;
+    GD_TRY(hipModuleGetGlobal(&p, &n, reinterpret_cast<hipModule_t>(m), name));
+    *dptr = (void *)p;
+    if (bytes) *bytes = n;
+    return 0;
+}
+int gd_function_attributes(gd_function_t f, int *static_lds_bytes,
+                           int *max_threads_per_block, int *num_regs) {
+    if (!f) return fail("gd_function_attributes: null function");
+    hipFunction_t fn = reinterpret_cast<hipFunction_t>(f);
+    int v = 0;
+    if (static_lds_bytes) {
+        GD_TRY(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, fn));
+        *static_lds_bytes = v;
+    }
+    if (max_threads_per_block) {
+        GD_TRY(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, fn));
+        *max_threads_per_block = v;
+    }
+    if (num_regs) {
+        GD_TRY(hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn));
+        *num_regs = v;
+    }
+    return 0;
+}
+
+int gd_launch(gd_function_t f, uint32_t grid_x, uint32_t block_x,
+              uint32_t dynamic_lds_bytes, gd_stream_t s, const void *args,
+              size_t args_bytes) {
+    if (!f) return fail("gd_launch: null function");
+    if (grid_x == 0 || block_x == 0) return 0;
+    size_t size = args_bytes;
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void *>(args),
+                      HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    GD_TRY(hipModuleLaunchKernel(reinterpret_cast<hipFunction_t>(f), grid_x, 1, 1,
+                                 block_x, 1, 1, dynamic_lds_bytes, S(s), nullptr,
+                                 config));
+    return 0;
+}
+
+int gd_stream_create(gd_stream_t *out) {
+    if (!out) return fail("gd_stream_create: null argument");
+    hipStream_t s;
+    GD_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = reinterpret_cast<gd_stream_t>(s);
+    return 0;
+}
+int gd_stream_destroy(gd_stream_t s) {
+    if (s) GD_TRY(hipStreamDestroy(S(s)));
+    return 0;
+}
+int gd_stream_sync(gd_stream_t s) {
+    GD_TRY(hipStreamSynchronize(S(s)));
+    return 0;
+}
+int gd_event_create(gd_event_t *out) {
+    if (!out) return fail("gd_event_create: null argument");
+    hipEvent_t e;
+    GD_TRY(hipEventCreate(&e));
+    *out = reinterpret_cast<gd_event_t>(e);
+    return 0;
+}
+int gd_event_destroy(gd_event_t e) {
+    if (e) GD_TRY(hipEventDestroy(E(e)));
+    return 0;
+}
+int gd_event_record(gd_event_t e, gd_stream_t s) {
+    GD_TRY(hipEventRecord(E(e), S(s)));
+    return 0;
+}
+int gd_event_sync(gd_event_t e) {
+    GD_TRY(hipEventSynchronize(E(e)));
+    return 0;
+}
+int gd_event_elapsed_ms(gd_event_t start, gd_event_t stop, float *ms) {
+    if (!ms) return fail("gd_event_elapsed_ms: null argument");
+    GD_TRY(hipEventElapsedTime(ms, E(start), E(stop)));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+"""ctypes binding of libgdhip.so (declared in include/gdhip.h).
+
+There is no CPU fallback: if the shared library is missing it is built with
+hipcc, and if no gfx950 device is present every device call raises HIPError.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_here = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(_here), 'csrc')
+INCLUDE = os.path.join(os.path.dirname(os.path.dirname(_here)), 'include')
+LIB_PATH = os.path.join(CSRC, 'libgdhip.so')
+
+_lock = threading.Lock()
+_lib = None
+_device = None
+
+
+class HIPError(RuntimeError):
+    pass
+
+
+class DeviceProps(ctypes.Structure):
+    _fields_ = [('name', ctypes.c_char * 256), ('arch', ctypes.c_char * 64),
+                ('compute_units', ctypes.c_int32),
+                ('wavefront_size', ctypes.c_int32),
+                ('max_threads_per_block', ctypes.c_int32),
+                ('clock_khz', ctypes.c_int32),
+                ('lds_per_block', ctypes.c_int64),
+                ('total_mem', ctypes.c_int64)]
+
+
+# every exported symbol of include/gdhip.h with its argument types
+_vp, _sz, _u32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32
+_P = ctypes.POINTER
+SIGNATURES = {
+    'gd_device_count': [_P(ctypes.c_int)],
+    'gd_init': [ctypes.c_int],
+    'gd_device_props': [ctypes.c_int, _P(DeviceProps)],
+    'gd_device_sync': [],
+    'gd_malloc': [_P(_vp), _sz],
+    'gd_free': [_vp],
+    'gd_host_alloc': [_P(_vp), _sz],
+    'gd_host_free': [_vp],
+    'gd_memcpy_h2d': [_vp, _vp, _sz, _vp],
+    'gd_memcpy_d2h': [_vp, _vp, _sz, _vp],
+    'gd_memcpy_d2d': [_vp, _vp, _sz, _vp],
+    'gd_memset': [_vp, ctypes.c_int, _sz, _vp],
+    'gd_module_load': [_vp, _sz, _P(_vp)],
+    'gd_module_unload': [_vp],
+    'gd_module_get_function': [_vp, ctypes.c_char_p, _P(_vp)],
+    'gd_module_get_global': [_vp, ctypes.c_char_p, _P(_vp), _P(_sz)],
+    'gd_function_attributes': [_vp, _P(ctypes.c_int), _P(ctypes.c_int),
+                               _P(ctypes.c_int)],
+    'gd_launch': [_vp, _u32, _u32, _u32, _vp, _vp, _sz],
+    'gd_stream_create': [_P(_vp)],
+    'gd_stream_destroy': [_vp],
+    'gd_stream_sync': [_vp],
+    'gd_event_create': [_P(_vp)],
+    'gd_event_destroy': [_vp],
+    'gd_event_record': [_vp, _vp],
+    'gd_event_sync': [_vp],
+    'gd_event_elapsed_ms': [_vp, _vp, _P(ctypes.c_float)],
+}
+
+
+def build_library(force=False):
+    """hipcc-build csrc/gdhip.cpp -> csrc/libgdhip.so (host code only)."""
+    src = os.path.join(CSRC, 'gdhip.cpp')
+    hdr = os.path.join(INCLUDE, 'gdhip.h')
+    if (not force and os.path.exists(LIB_PATH)
+            and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(src),
+                                                  os.path.getmtime(hdr))):
+        return LIB_PATH
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '-O2', '-fPIC', '-shared', '-std=c++17', f'-I{INCLUDE}',
+           src, '-o', LIB_PATH]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise HIPError(f'building libgdhip.so failed:\n{r.stderr}')
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library with argtypes set (builds it on first use)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            L = ctypes.CDLL(build_library())
+            for name, argtypes in SIGNATURES.items():
+                fn = getattr(L, name)
+                fn.argtypes = argtypes
+                fn.restype = ctypes.c_int
+            L.gd_last_error.restype = ctypes.c_char_p
+            L.gd_last_error.argtypes = []
+            L.gd_version.restype = ctypes.c_char_p
+            L.gd_version.argtypes = []
+            _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HIPError(lib().gd_last_error().decode(errors='replace'))
+
+
+def ensure_device(device=None):
+    """Select (once) the HIP device of this process.  Honours LOCAL_RANK for
+    one-process-per-GPU launches."""
+    global _device
+    if _device is None or (device is not None and device != _device):
+        if device is None:
+            device = int(os.environ.get('GD_DEVICE',
+                                        os.environ.get('LOCAL_RANK', 0)))
+        n = ctypes.c_int(0)
+        check(lib().gd_device_count(ctypes.byref(n)))
+        if n.value <= 0:
+            raise HIPError('no HIP device')
+        check(lib().gd_init(device % n.value))
+        _device = device % n.value
+    return _device
+
+
+def device_props(device=None):
+    dev = ensure_device(device)
+    p = DeviceProps()
+    check(lib().gd_device_props(dev, ctypes.byref(p)))
+    return p
+
+
+class DeviceBuffer:
+    """Owning handle of one hipMalloc allocation."""
+
+    def __init__(self, nbytes):
+        ensure_device()
+        self.nbytes = int(nbytes)
+        p = ctypes.c_void_p()
+        check(lib().gd_malloc(ctypes.byref(p), max(self.nbytes, 1)))
+        self.ptr = p.value or 0
+
+    def upload(self, array, offset=0, stream=None):
+        import numpy as np
+        a = np.ascontiguousarray(array)
+        assert offset + a.nbytes <= self.nbytes
+        check(lib().gd_memcpy_h2d(self.ptr + offset, a.ctypes.data, a.nbytes,
+                                  stream))
+        if stream is None or True:
+            # pageable source: the copy is synchronous w.r.t. the host buffer
+            pass
+        return self
+
+    def download(self, array, offset=0, stream=None):
+        assert array.flags['C_CONTIGUOUS']
+        assert offset + array.nbytes <= self.nbytes
+        check(lib().gd_memcpy_d2h(array.ctypes.data, self.ptr + offset,
+                                  array.nbytes, stream))
+        check(lib().gd_stream_sync(stream))
+        return array
+
+    def zero(self, stream=None):
+        check(lib().gd_memset(self.ptr, 0, self.nbytes, stream))
+
+    def free(self):
+        if getattr(self, 'ptr', 0) and _lib is not None:
+            try:
+                _lib.gd_free(self.ptr)
+            except Exception:
+                pass
+            self.ptr = 0
+
+    def __del__(self):
+        self.free()
+
+
+class Event:
+    def __init__(self):
+        p = ctypes.c_void_p()
+        check(lib().gd_event_create(ctypes.byref(p)))
+        self.h = p.value
+
+    def record(self, stream=None):
+        check(lib().gd_event_record(self.h, stream))
+
+    def sync(self):
+        check(lib().gd_event_sync(self.h))
+
+    def elapsed_ms(self, stop):
+        ms = ctypes.c_float(0)
+        check(lib().gd_event_elapsed_ms(self.h, stop.h, ctypes.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, 'h', None) and _lib is not None:
+            try:
+                _lib.gd_event_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+
+class Module:
+    """A loaded gfx950 code object and its kernels."""
+
+    def __init__(self, image: bytes):
+        ensure_device()
+        self._image = ctypes.create_string_buffer(image, len(image))
+        m = ctypes.c_void_p()
+        check(lib().gd_module_load(self._image, len(image), ctypes.byref(m)))
+        self.h = m.value
+        self._functions = {}
+
+    def function(self, name):
+        if name not in self._functions:
+            f = ctypes.c_void_p()
+            check(lib().gd_module_get_function(self.h, name.encode(),
+                                               ctypes.byref(f)))
+            self._functions[name] = f.value
+        return self._functions[name]
+
+    def attributes(self, name):
+        lds, thr, regs = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib().gd_function_attributes(self.function(name),
+                                           ctypes.byref(lds),
+                                           ctypes.byref(thr),
+                                           ctypes.byref(regs)))
+        return dict(static_lds=lds.value, max_threads=thr.value,
+                    num_regs=regs.value)
+
+
+def launch(function, grid, block, args: bytes, stream=None, dynamic_lds=0):
+    buf = ctypes.create_string_buffer(args, len(args))
+    check(lib().gd_launch(function, grid, block, dynamic_lds, stream, buf,
+                          len(args)))
+
+
+def synchronize(stream=None):
+    if stream is None:
+        check(lib().gd_device_sync())
+    else:
+        check(lib().gd_stream_sync(stream))

@@ -1,0 +1,620 @@
+"""HIP backend of the marginalized graph kernel for MI355X (gfx950).
+
+Serves the reference's backend seam (``Backend.__call__``,
+``graphdot/kernel/marginalized/_backend_cuda.py:247-368``): graph images are
+packed and cached per graph, node/edge microkernels are printed as HIP C++
+functors and JIT-compiled with hipcc, hyperparameters are handed to the
+kernel as by-value arguments, and the job list is partitioned over a small
+menu of register-resident solver variants (see ``csrc/device/mgk_solver.h``).
+
+There is no CPU path: a missing ``libgdhip.so`` / hipcc / device raises.
+"""
+import copy
+import os
+import uuid
+import warnings
+from collections import OrderedDict, namedtuple
+import numpy as np
+from ...codegen import Template
+from ...codegen.sympy_printer import to_real_expr
+from ...codegen.typetool import _dtype_util
+from ...hip import jit, runtime
+from ...microkernel import TensorProduct, Product
+from ...util.iterable import flatten, fold_like
+from ._backend import Backend
+from ._devicegraph import DeviceGraph, GraphArena
+
+_TEMPLATE = os.path.join(os.path.dirname(__file__), 'template.hip')
+
+# solver flags, mirror graphdot::mgk::F_* (mgk_solver.h)
+F_NODAL, F_DIAGONAL, F_SYMMETRIC, F_LMIN1, F_BLOCK, F_PACKED = \
+    1, 2, 4, 8, 16, 32
+
+Variant = namedtuple('Variant', 'W S R')
+
+#: register-resident solver menu, cheapest first.  A pair fits a variant if
+#: its best 64-lane tiling needs <= S*W tiles and N = n1*n2 <= 64*W*R.
+VARIANTS = [
+    Variant(1, 8, 2), Variant(1, 16, 4), Variant(1, 24, 6),
+    Variant(1, 32, 9), Variant(1, 48, 9), Variant(1, 64, 16),
+    Variant(4, 16, 4), Variant(4, 32, 8), Variant(4, 64, 16),
+    Variant(16, 16, 2), Variant(16, 32, 4), Variant(16, 64, 8),
+    Variant(16, 128, 16),
+]
+LDS_LIMIT = 160 * 1024
+
+
+def _real_name(real):
+    return {np.dtype(np.float32): 'float', np.dtype(np.float64): 'double'}[
+        np.dtype(real)]
+
+
+# --------------------------------------------------------------------------
+# struct printing and packing
+# --------------------------------------------------------------------------
+def declstruct(dtype, name):
+    """C++ definition ``struct name {...};`` of an aligned numpy struct dtype.
+    Unlike ``decltype`` every nested struct is *named* (``name_field``) so
+    that zero-size members can be declared ``constexpr static`` (not allowed
+    inside unnamed structs in standard C++)."""
+    dtype = np.dtype(dtype)
+    members = []
+    for key in dtype.names or ():
+        ft = dtype.fields[key][0]
+        if key.startswith('$'):
+            n, tpl, *args = key[1:].split('::')
+            targs = ','.join(np.dtype(a).name for a in args)
+            members.append(f'{tpl}<{targs}> {n};')
+        elif _dtype_util.is_object(ft):
+            if ft.itemsize == 0:
+                members.append(f'constexpr static _empty {key} {{}};')
+            else:
+                sub = f'{name}_{key}'
+                members.append(declstruct(ft, sub)[:-1] + f' {key};')
+        elif _dtype_util.is_array(ft):
+            dims = ''.join(f'[{d}]' for d in ft.shape)
+            members.append(f'{ft.base.name} {key}{dims};')
+        else:
+            members.append(f'{ft.name} {key};')
+    return f'struct {name} {{' + ' '.join(members) + '};'
+
+
+def widen_theta(dtype, real):
+    """theta structs hold float32 hyperparameters in the reference; an fp64
+    build stores them as float64."""
+    dtype = np.dtype(dtype)
+    if np.dtype(real) == np.float32:
+        return dtype
+    if dtype.names is not None:
+        return np.dtype([(k, widen_theta(dtype.fields[k][0], real))
+                         for k in dtype.names], align=True)
+    if dtype.subdtype is not None:
+        return np.dtype((widen_theta(dtype.base, real), dtype.shape))
+    return np.dtype(real) if dtype == np.float32 else dtype
+
+
+def raw_state(obj):
+    """Like ``obj.state`` but without the float32 rounding of cpptype, so an
+    fp64 build sees the hyperparameters at full precision."""
+    values = getattr(obj, '_theta_values', None)
+    if values is not None:
+        return tuple(values.values())
+    out = []
+    dt = obj.dtype
+    for key in dt.names or ():
+        ft = dt.fields[key][0]
+        v = getattr(obj, key)
+        out.append(raw_state(v) if _dtype_util.is_object(ft) else v)
+    return tuple(out)
+
+
+def fill_struct(view, dtype, state):
+    """Write nested tuple `state` into the 0-d structured array `view`."""
+    for key, value in zip(dtype.names or (), state):
+        ft = dtype.fields[key][0]
+        if _dtype_util.is_object(ft):
+            if ft.itemsize:
+                fill_struct(view[key], ft, value)
+        else:
+            view[key] = value
+
+
+def pack_theta(obj, real):
+    dt = widen_theta(obj.dtype, real)
+    buf = np.zeros((), dtype=dt) if dt.itemsize else None
+    if buf is not None:
+        fill_struct(buf, dt, raw_state(obj) if np.dtype(real) != np.float32
+                    else obj.state)
+    return dt, buf
+
+
+# --------------------------------------------------------------------------
+# backend
+# --------------------------------------------------------------------------
+class Plan:
+    """Everything resident on the device for one kernel evaluation."""
+    pass
+
+
+class HIPBackend(Backend):
+    """MI355X backend.
+
+    Parameters
+    ----------
+    device: int or None
+        HIP device ordinal (default: ``$LOCAL_RANK`` or 0).
+    real: numpy float32 (reference arithmetic, default) or float64
+    blocks_per_cu: int
+        Persistent workgroups launched per compute unit.
+    hipcc_extra: list of str
+        Extra compiler flags.
+    """
+
+    @staticmethod
+    def array(ndarray):
+        return np.array(ndarray, copy=True)
+
+    @staticmethod
+    def zeros(size, dtype=np.float32):
+        return np.zeros(size, dtype)
+
+    @staticmethod
+    def empty(size, dtype=np.float32):
+        return np.empty(size, dtype)
+
+    def __init__(self, **kwargs):
+        self.uuid = uuid.uuid4()
+        self.device = kwargs.pop('device', None)
+        self.real = np.dtype(kwargs.pop('real', np.float32)).type
+        self.blocks_per_cu = kwargs.pop('blocks_per_cu', 8)
+        self.hipcc_extra = list(kwargs.pop('hipcc_extra', []))
+        self.variants = list(kwargs.pop('variants', VARIANTS))
+        self.record_iterations = kwargs.pop('record_iterations', False)
+        if kwargs:
+            raise TypeError(f'unknown HIPBackend options {sorted(kwargs)}')
+        runtime.lib()                      # fail loudly if the library is absent
+        self._modules = {}                 # (tu key) -> runtime.Module
+        self._arenas = OrderedDict()       # tuple(id(DeviceGraph)) -> (arena, buf)
+        self._pool = {}                    # name -> DeviceBuffer (grow-only)
+        self._props = None
+        self.last_plan = None
+
+    def __deepcopy__(self, memo):
+        # clones of a kernel (clone_with_theta) share device state, like the
+        # reference backend (_backend_cuda.py:63-64)
+        return copy.copy(self)
+
+    # -- device helpers -------------------------------------------------------
+    @property
+    def props(self):
+        if self._props is None:
+            self._props = runtime.device_props(self.device)
+        return self._props
+
+    def _buffer(self, name, nbytes):
+        buf = self._pool.get(name)
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None:
+                runtime.synchronize()
+                buf.free()
+            buf = self._pool[name] = runtime.DeviceBuffer(
+                max(int(nbytes * 1.25), 256))
+        return buf
+
+    # -- graphs ---------------------------------------------------------------
+    def _register_graph(self, graph):
+        key = (self.uuid, np.dtype(self.real).str)
+        if key not in graph.cookie:
+            graph.cookie[key] = DeviceGraph(graph, real=self.real)
+        return graph.cookie[key]
+
+    @staticmethod
+    def _assert_homogeneous(x, y):
+        if (x.weighted != y.weighted or x.node_t != y.node_t
+                or x.edge_t != y.edge_t):
+            raise TypeError(
+                'All nodes/edges must be of the same type: '
+                f'{x.node_t} / {x.edge_t} vs {y.node_t} / {y.edge_t}. '
+                'If the graph attributes match in name but differ in type, '
+                'try to normalize automatically with '
+                '`Graph.unify_datatype`.')
+
+    def _arena(self, dgraphs):
+        key = tuple(id(g) for g in dgraphs)
+        hit = self._arenas.get(key)
+        if hit is not None:
+            self._arenas.move_to_end(key)
+            return hit
+        arena = GraphArena(dgraphs)
+        buf = runtime.DeviceBuffer(arena.nbytes)
+        buf.upload(arena.relocated(buf.ptr))
+        runtime.synchronize()
+        self._arenas[key] = (arena, buf, list(dgraphs))
+        while len(self._arenas) > 4:
+            _, (_, old, _) = self._arenas.popitem(last=False)
+            old.free()
+        return self._arenas[key]
+
+    # -- code generation --------------------------------------------------------
+    @staticmethod
+    def gencode_kernel(kernel, name, real=np.float32):
+        """HIP C++ for a microkernel: ``struct <name>_theta_t`` (the packed
+        hyperparameters) and functor ``<name>_t`` with ``operator()`` and
+        ``_j_a_c_o_b_i_a_n_`` (reference: _backend_cuda.py:157-193)."""
+        fun, jac = kernel.gen_expr('x1', 'x2')
+        rn = _real_name(real)
+        fun = to_real_expr(fun, np.dtype(real).name)
+        jac = [to_real_expr(j, np.dtype(real).name) for j in jac]
+        return Template(r'''
+${theta_t}
+struct ${name}_t : ${name}_theta_t {
+    constexpr static int jac_dims = ${jac_dims};
+    template<class X> __device__ __forceinline__
+    auto operator() (X const &x1, X const &x2) const {
+        return ${expr};
+    }
+    template<class X> __device__ __forceinline__
+    auto _j_a_c_o_b_i_a_n_(X const &x1, X const &x2) const {
+        graphdot::array<real_t, jac_dims> j;
+        ${jac;}
+        return j;
+    }
+};
+''').render(
+            name=name, jac_dims=len(jac), expr=fun,
+            theta_t=declstruct(widen_theta(kernel.dtype, real),
+                               f'{name}_theta_t'),
+            jac=[f'j[{i}] = {e};' for i, e in enumerate(jac)] + [''],
+        ).replace('real_t', 'real_t') + f'// real = {rn}\n'
+
+    @staticmethod
+    def gencode_probability(pfunc, name, real=np.float32):
+        """Functor for the starting probability on a node ``n``
+        (reference: _backend_cuda.py:195-228)."""
+        fun, jac = pfunc.gen_expr()
+        fun = to_real_expr(fun, np.dtype(real).name)
+        jac = [to_real_expr(j, np.dtype(real).name) for j in jac]
+        return Template(r'''
+${theta_t}
+struct ${name}_t : ${name}_theta_t {
+    constexpr static int jac_dims = ${jac_dims};
+    template<class N> __device__ __forceinline__
+    auto operator() (N const &n) const {
+        return ${expr};
+    }
+    template<class N> __device__ __forceinline__
+    auto _j_a_c_o_b_i_a_n_(N const &n) const {
+        graphdot::array<real_t, jac_dims> j;
+        ${jac;}
+        return j;
+    }
+};
+''').render(
+            name=name, jac_dims=len(jac), expr=fun,
+            theta_t=declstruct(widen_theta(pfunc.dtype, real),
+                               f'{name}_theta_t'),
+            jac=[f'j[{i}] = {e};' for i, e in enumerate(jac)] + [''],
+        )
+
+    @staticmethod
+    def pack_state(obj, diff_grid=False, diff_eps=1e-2):
+        """[state] or, with diff_grid, [state, state(theta_0 e^+eps),
+        state(theta_0 e^-eps), ...] (reference: _backend_cuda.py:230-245)."""
+        pack = [obj.state]
+        if diff_grid is True:
+            logtheta = np.log(list(flatten(obj.theta)))
+            for i in range(len(logtheta)):
+                for delta in (diff_eps, -diff_eps):
+                    o = copy.deepcopy(obj)
+                    t = logtheta.copy()
+                    t[i] += delta
+                    o.theta = fold_like(np.exp(t), o.theta)
+                    pack.append(o.state)
+        return pack
+
+    def _params_dtype(self, node_kernel, edge_kernel, p):
+        def theta(obj):
+            dt = widen_theta(obj.dtype, self.real)
+            return dt if dt.itemsize else np.dtype(np.uint8)
+        P = np.uintp
+        return np.dtype([
+            ('graphs', P), ('jobs', P), ('order', P), ('starts', P),
+            ('gramian', P), ('gradient', P), ('iters', P),
+            ('n_launch_jobs', np.uint32), ('nX', np.uint32),
+            ('nY', np.uint32), ('nJ', np.uint32), ('flags', np.uint32),
+            ('order_offset', np.uint32),
+            ('q', self.real), ('q0', self.real), ('eps', self.real),
+            ('ftol', self.real), ('gtol', self.real),
+            ('node_kernel', theta(node_kernel)),
+            ('edge_kernel', theta(edge_kernel)),
+            ('p_start', theta(p)),
+        ], align=True)
+
+    @staticmethod
+    def kernel_name(v, C):
+        return f'mgk_W{v.W}_S{v.S}_R{v.R}_C{C}'
+
+    def _entry_point(self, v, C):
+        threads = 64 * v.W * (4 if v.W == 1 else 1)
+        return Template(r'''
+extern "C" __global__ __launch_bounds__(${threads})
+void ${name}(params_t prm) {
+    using solver = graphdot::mgk::pair_solver<real_t, ${S}, ${R}, ${W}, ${C},
+        graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
+    __shared__ typename solver::lds_t lds;
+    solver::run(prm, lds);
+}
+''').render(threads=threads, name=self.kernel_name(v, C), S=v.S, R=v.R,
+            W=v.W, C=C)
+
+    def render_source(self, node_kernel, edge_kernel, p, node_t, edge_t,
+                      variants, C):
+        """Full translation unit for the given solver variants."""
+        pd = self._params_dtype(node_kernel, edge_kernel, p)
+        return Template(_TEMPLATE).render(
+            real=_real_name(self.real),
+            node_t=declstruct(node_t, 'node_t'),
+            edge_t=declstruct(edge_t, 'edge_t'),
+            node_kernel=self.gencode_kernel(node_kernel, 'node_kernel',
+                                            self.real),
+            edge_kernel=self.gencode_kernel(edge_kernel, 'edge_kernel',
+                                            self.real),
+            p_start=self.gencode_probability(p, 'p_start', self.real),
+            node_size=np.dtype(node_t).itemsize,
+            edge_size=max(np.dtype(edge_t).itemsize, 1),
+            params_size=pd.itemsize,
+            entry_points=[self._entry_point(v, C) for v in variants] + [''],
+        )
+
+    def _module(self, source):
+        key = jit.cache_key(source, self.hipcc_extra)
+        mod = self._modules.get(key)
+        if mod is None:
+            path = jit.compile_source(source, self.hipcc_extra)
+            mod = self._modules[key] = runtime.Module(jit.load_image(path))
+        return mod
+
+    # -- job partitioning ---------------------------------------------------------
+    def lds_bytes(self, v, C):
+        wpb = 4 if v.W == 1 else 1
+        nv = v.R * 64 * v.W
+        return (wpb * 2 * nv * C + wpb * 2 * v.W) * np.dtype(self.real).itemsize
+
+    def classify(self, ji, jj, n_node, n_nz, C):
+        """Assign every job the cheapest variant it fits and its tile shape.
+
+        Returns (variant_index[n_jobs], log2_tb[n_jobs], tiles[n_jobs])."""
+        n1, n2 = n_node[ji], n_node[jj]
+        z1, z2 = n_nz[ji], n_nz[jj]
+        N = n1 * n2
+        sh = np.arange(7)[:, None]
+        tiles_all = (-(-z1[None, :] // (64 >> sh))) * (-(-z2[None, :] // (1 << sh)))
+        best = np.argmin(tiles_all, axis=0)
+        tiles = tiles_all[best, np.arange(len(ji))]
+        choice = np.full(len(ji), -1, dtype=np.int64)
+        for k, v in enumerate(self.variants):
+            if self.lds_bytes(v, C) > LDS_LIMIT:
+                continue
+            fits = ((choice < 0) & (tiles <= v.S * v.W)
+                    & (N <= 64 * v.W * v.R) & (N <= 0xFFFF))
+            choice[fits] = k
+        if np.any(choice < 0):
+            bad = int(np.argmax(choice < 0))
+            raise NotImplementedError(
+                f'graph pair ({ji[bad]}, {jj[bad]}) with {n1[bad]}x{n2[bad]} '
+                f'nodes and {z1[bad]}x{z2[bad]} adjacency nonzeros exceeds '
+                'the largest register-resident solver variant; the '
+                'global-memory fallback is not built yet')
+        return choice, best, tiles
+
+    # -- the three phases -----------------------------------------------------------
+    def _frontend(self, graphs, node_kernel, edge_kernel, p, jobs, traits,
+                  timer=None):
+        """Host-only half of `prepare`: pack graphs, partition the jobs and
+        render one translation unit per solver variant in use."""
+        tic = timer.tic if timer else (lambda *_: None)
+        toc = timer.toc if timer else (lambda *_: None)
+        tic('transferring graphs to GPU')
+        dgraphs = []
+        for i, g in enumerate(graphs):
+            dg = self._register_graph(g)
+            if i > 0:
+                self._assert_homogeneous(dgraphs[0], dg)
+            dgraphs.append(dg)
+        toc('transferring graphs to GPU')
+
+        if traits.eval_gradient is True and traits.nodal is not False:
+            raise NotImplementedError(
+                'nodal gradients (finite-difference path of the reference, '
+                'template.cu:226-418) are not built yet')
+        C = 2 if traits.eval_gradient is True else 1
+
+        tic('code generation')
+        if dgraphs[0].weighted:
+            edge_kernel = TensorProduct(weight=Product(), label=edge_kernel)
+        jobs = np.ascontiguousarray(jobs)
+        ji = jobs['i'].astype(np.int64)
+        jj = jobs['j'].astype(np.int64)
+        n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
+        n_nz = np.array([g.n_nz for g in dgraphs], dtype=np.int64)
+        choice, shape, tiles = self.classify(ji, jj, n_node, n_nz, C)
+        used = sorted(set(choice.tolist()))
+        sources = {k: self.render_source(node_kernel, edge_kernel, p,
+                                         dgraphs[0].node_t, dgraphs[0].edge_t,
+                                         [self.variants[k]], C)
+                   for k in used}
+        toc('code generation')
+        return dgraphs, edge_kernel, jobs, C, choice, shape, tiles, used, \
+            sources
+
+    def precompile(self, graphs, node_kernel, edge_kernel, p, jobs, traits):
+        """Compile (into the on-disk JIT cache) every code object that
+        `prepare` would need for this call.  Needs hipcc but no device."""
+        *_, sources = self._frontend(graphs, node_kernel, edge_kernel, p,
+                                     jobs, traits)
+        return jit.compile_many(list(sources.values()), self.hipcc_extra)
+
+    def prepare(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
+                jobs, starts, nX, nY, nJ, traits, timer=None, packed=False):
+        """Upload graphs / jobs, generate + compile code, partition the jobs.
+        Returns a Plan whose launches can be replayed."""
+        tic = timer.tic if timer else (lambda *_: None)
+        toc = timer.toc if timer else (lambda *_: None)
+        runtime.ensure_device(self.device)
+        (dgraphs, edge_kernel, jobs, C, choice, shape, tiles, used,
+         sources) = self._frontend(graphs, node_kernel, edge_kernel, p, jobs,
+                                   traits, timer)
+        arena, arena_buf, _ = self._arena(dgraphs)
+
+        tic('JIT')
+        missing = [s for s in sources.values()
+                   if jit.cache_key(s, self.hipcc_extra) not in self._modules]
+        if len(missing) > 1:
+            jit.compile_many(missing, self.hipcc_extra)
+        modules = {k: self._module(s) for k, s in sources.items()}
+        toc('JIT')
+
+        tic('calculating launch configuration')
+        plan = Plan()
+        plan.traits, plan.C, plan.n_jobs = traits, C, len(jobs)
+        plan.nX, plan.nY, plan.nJ = int(nX), int(nY), int(nJ)
+        plan.packed = packed
+        plan.keep = (arena, arena_buf, dgraphs)
+        flags = 0
+        if traits.nodal is True or traits.nodal == 'block':
+            flags |= F_NODAL
+        if traits.nodal == 'block':
+            flags |= F_BLOCK
+        if traits.diagonal:
+            flags |= F_DIAGONAL
+        if traits.symmetric:
+            flags |= F_SYMMETRIC
+        if traits.lmin == 1:
+            flags |= F_LMIN1
+        if packed:
+            flags |= F_PACKED
+        rsize = np.dtype(self.real).itemsize
+        n_out = len(jobs) if packed else plan.nX * plan.nY
+        plan.n_out = n_out
+        plan.n_grad = n_out * plan.nJ if C == 2 else 0
+
+        order_all = np.empty(len(jobs), dtype=np.uint32)
+        launches, cursor = [], 0
+        for k in used:
+            v = self.variants[k]
+            idx = np.flatnonzero(choice == k)
+            idx = idx[np.argsort(-tiles[idx], kind='stable')]
+            order_all[cursor:cursor + len(idx)] = (
+                idx.astype(np.uint32) | (shape[idx].astype(np.uint32) << 29))
+            wpb = 4 if v.W == 1 else 1
+            threads = 64 * v.W * wpb
+            bpc = self.blocks_per_cu if v.W <= 4 else max(
+                1, self.blocks_per_cu // 4)
+            grid = int(min(-(-len(idx) // wpb),
+                           self.props.compute_units * bpc))
+            launches.append(dict(variant=v, k=k, offset=cursor,
+                                 count=len(idx), grid=grid, threads=threads,
+                                 fn=modules[k].function(self.kernel_name(v, C)),
+                                 module=modules[k]))
+            cursor += len(idx)
+        plan.order_host = order_all
+        plan.launches = launches
+
+        # device buffers
+        b_jobs = self._buffer('jobs', jobs.nbytes)
+        b_order = self._buffer('order', order_all.nbytes)
+        b_starts = self._buffer('starts', np.asarray(starts).nbytes)
+        b_out = self._buffer('gramian', n_out * rsize)
+        b_grad = self._buffer('gradient', plan.n_grad * rsize) \
+            if C == 2 else None
+        b_iters = self._buffer('iters', 4 * len(jobs)) \
+            if self.record_iterations else None
+        b_jobs.upload(jobs.view(np.uint32))
+        b_order.upload(order_all)
+        b_starts.upload(np.ascontiguousarray(starts, dtype=np.uint32))
+        plan.buffers = dict(jobs=b_jobs, order=b_order, starts=b_starts,
+                            gramian=b_out, gradient=b_grad, iters=b_iters)
+
+        # kernel argument blocks
+        pd = self._params_dtype(node_kernel, edge_kernel, p)
+        base = np.zeros((), dtype=pd)
+        base['graphs'] = arena_buf.ptr
+        base['jobs'] = b_jobs.ptr
+        base['starts'] = b_starts.ptr
+        base['gramian'] = b_out.ptr
+        base['gradient'] = b_grad.ptr if b_grad is not None else 0
+        base['iters'] = b_iters.ptr if b_iters is not None else 0
+        base['nX'], base['nY'], base['nJ'] = plan.nX, plan.nY, plan.nJ
+        base['flags'] = flags
+        base['q'] = q
+        base['q0'] = q
+        base['eps'], base['ftol'], base['gtol'] = eps, ftol, gtol
+        for field, obj in (('node_kernel', node_kernel),
+                           ('edge_kernel', edge_kernel), ('p_start', p)):
+            dt, val = pack_theta(obj, self.real)
+            if val is not None:
+                base[field] = val
+        for L in launches:
+            a = base.copy()
+            a['order'] = b_order.ptr + 4 * L['offset']
+            a['n_launch_jobs'] = L['count']
+            a['order_offset'] = L['offset']
+            L['args'] = a.tobytes()
+        plan.params_dtype = pd
+        toc('calculating launch configuration')
+        self.last_plan = plan
+        return plan
+
+    def launch(self, plan, stream=None):
+        """Enqueue every solver launch of `plan` (asynchronous)."""
+        for L in plan.launches:
+            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                           stream=stream)
+
+    def collect(self, plan, gramian=None, gradient=None):
+        """Copy results back.  With a packed plan the per-job values come
+        back in *job order* (not launch order)."""
+        runtime.synchronize()
+        rs = np.dtype(self.real)
+        out = np.empty(plan.n_out, dtype=rs)
+        plan.buffers['gramian'].download(out)
+        grad = None
+        if plan.C == 2:
+            grad = np.empty(plan.n_grad, dtype=rs)
+            plan.buffers['gradient'].download(grad)
+        if plan.packed:
+            ids = plan.order_host & np.uint32(0x1FFFFFFF)
+            unsorted = np.empty_like(out)
+            unsorted[ids] = out
+            out = unsorted
+            if grad is not None:
+                g = grad.reshape(plan.n_jobs, -1)
+                gu = np.empty_like(g)
+                gu[ids] = g
+                grad = gu
+        if gramian is not None:
+            gramian[:] = out
+        if gradient is not None and grad is not None:
+            gradient[:] = grad.reshape(gradient.shape) if plan.packed \
+                else grad
+        return out, grad
+
+    def iterations(self, plan):
+        if plan.buffers['iters'] is None:
+            raise RuntimeError('create the backend with '
+                               'record_iterations=True')
+        it = np.empty(plan.n_jobs, dtype=np.uint32)
+        plan.buffers['iters'].download(it)
+        return it
+
+    # -- the reference's backend call ---------------------------------------------------
+    def __call__(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol,
+                 gtol, jobs, starts, gramian, gradient, nX, nY, nJ, traits,
+                 timer):
+        plan = self.prepare(graphs, node_kernel, edge_kernel, p, q, eps, ftol,
+                            gtol, jobs, starts, nX, nY, nJ, traits, timer)
+        timer.tic('GPU kernel execution')
+        self.launch(plan)
+        runtime.synchronize()
+        timer.toc('GPU kernel execution')
+        self.collect(plan, gramian, gradient)

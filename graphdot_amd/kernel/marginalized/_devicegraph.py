@@ -1,0 +1,303 @@
+"""Host-side packer of the device graph format (``csrc/device/graph.h``).
+
+Takes the role of the reference's ``OctileGraph``
+(``graphdot/kernel/marginalized/_octilegraph.py:37-177``) and keeps its
+*semantics* -- AoS node labels indexed by node id, fp32 degrees as sums of
+incident weights with a self loop counted once and ``0 -> 1``, both
+orientations of every edge, ``{weight, label}`` edge structs for weighted
+graphs, phantom ``labeled`` fields for unlabeled graphs, variable-length
+attributes as ``frozen_array`` views -- but not its 8x8 octile tiling: the
+MI355X solver consumes a flat list of directed nonzeros (see ``graph.h`` for
+why and for the ordering rule).
+
+Each graph packs into one relocatable byte blob::
+
+    [degree f32[n]] [nodes node_t[n]] [nz u16x2[nnz]] [edges edge_t[nnz]]
+    [variable-length attribute payloads ...]
+
+with every section 16-byte aligned; pointers inside the blob (frozen_array
+views) are stored as blob-relative offsets plus a relocation list, so blobs of
+many graphs are concatenated into one arena and uploaded with a single copy.
+"""
+import itertools as it
+import numpy as np
+from ...codegen.cpptool import cpptype
+from ...codegen.typetool import common_min_type, is_scalar_type
+
+_ALIGN = 16
+
+#: device-side header, mirrors graphdot::graph_t (40 bytes)
+HEADER_DTYPE = np.dtype([
+    ('n_node', np.int32), ('n_nz', np.int32), ('degree', np.uintp),
+    ('node', np.uintp), ('nz', np.uintp), ('edge', np.uintp)], align=True)
+assert HEADER_DTYPE.itemsize == 40
+
+NZ_DTYPE = np.dtype([('i', np.uint16), ('j', np.uint16)])
+
+
+@cpptype(ptr=np.intp, size=np.int32)
+class FrozenArray(np.ndarray):
+    """An ndarray slice that packs as {pointer, length}; the pointer is a
+    blob-relative offset until the arena is relocated."""
+    _offset = 0
+
+    @property
+    def ptr(self):
+        return self._offset
+
+    @property
+    def size(self):
+        return len(self)
+
+
+def _pad(n, a=_ALIGN):
+    return (n + a - 1) // a * a
+
+
+def _widen(dtype, real):
+    """Map float32 attribute fields to `real` (fp64 builds compute on the
+    attributes in double precision)."""
+    if real == np.float32:
+        return dtype
+    dtype = np.dtype(dtype)
+    if dtype.names is not None:
+        return np.dtype([(k, _widen(dtype.fields[k][0], real))
+                         for k in dtype.names], align=True)
+    return np.dtype(real) if dtype == np.float32 else dtype
+
+
+class DeviceGraph:
+    """Packed image of one :py:class:`graphdot_amd.graph.Graph`.
+
+    Attributes
+    ----------
+    node_t, edge_t: numpy aligned struct dtypes (the C++ node/edge types)
+    weighted: bool
+    n_node, n_nz: int
+    degree: float32[n_node]
+    nz: (i, j) uint16 pairs of the directed nonzeros, in device order
+    blob: uint8 array, relocatable image
+    offsets: dict section -> byte offset in blob
+    relocs: byte offsets (in blob) of uint64 words that hold blob-relative
+        pointers
+    """
+
+    def __init__(self, graph, real=np.float32):
+        real = np.dtype(real).type
+        nodes = graph.nodes.copy(deep=False)
+        edges = graph.edges.copy(deep=False)
+        self.n_node = n = len(nodes)
+        if n > 0xFFFF:
+            raise ValueError('graphs with more than 65535 nodes are not '
+                             'supported by the device format')
+
+        varlen = []     # (payload ndarray) in blob order
+        for df in (nodes, edges):
+            for key in list(df.columns):
+                col = df[key]
+                if is_scalar_type(col.dtype):
+                    continue
+                if col.concrete_type not in (list, tuple, np.ndarray) and \
+                        not (isinstance(col.concrete_type, type) and
+                             issubclass(col.concrete_type,
+                                        (list, tuple, np.ndarray))):
+                    raise TypeError(
+                        f'Unsupported non-scalar attribute {key} of type '
+                        f'{col.concrete_type}')
+                inner = common_min_type.of_types(
+                    [x.dtype if isinstance(x, np.ndarray)
+                     else common_min_type.of_values(x) for x in col])
+                if not is_scalar_type(inner):
+                    raise TypeError(
+                        'List-like graph attributes must have scalar '
+                        f'elements. Attribute {key} is {inner}.')
+                inner = np.dtype(_widen(np.dtype(inner), real))
+                flat = np.fromiter(it.chain.from_iterable(col), dtype=inner)
+                sizes = np.fromiter(map(len, col), dtype=np.int64,
+                                    count=len(col))
+                heads = np.cumsum(sizes) - sizes
+                views = np.empty(len(col), dtype=object)
+                for k, (h, s) in enumerate(zip(heads, sizes)):
+                    v = flat[h:h + s].view(FrozenArray)
+                    v._payload = len(varlen)
+                    v._head = int(h) * inner.itemsize
+                    views[k] = v
+                varlen.append(flat)
+                tag = f'${key}::frozen_array::{inner.str}'
+                df[tag] = views
+                df.drop([key], inplace=True)
+
+        # phantom labels keep node_t / edge_t non-empty
+        if len(nodes.columns) == 1:
+            nodes['labeled'] = np.zeros(n, np.bool_)
+        if len(edges.columns) == 2:     # only !i, !j: unweighted, unlabeled
+            edges['labeled'] = np.zeros(len(edges), np.bool_)
+
+        # ---- nodes: AoS indexed by node id ---------------------------------
+        idx = np.asarray(nodes['!i']).astype(np.int64)
+        nodes.drop(['!i'], inplace=True)
+        self.node_t = node_t = _widen(nodes.rowtype(), real)
+        nodes_aos = np.zeros(n, dtype=node_t)
+        node_fa = []          # (row, field, FrozenArray)
+        self._fill(nodes_aos, idx, nodes, node_t, node_fa)
+
+        # ---- directed nonzeros, degrees --------------------------------------
+        ei = np.asarray(edges['!i']).astype(np.int64)
+        ej = np.asarray(edges['!j']).astype(np.int64)
+        m = len(ei)
+        self.weighted = '!w' in edges
+        w = (np.asarray(edges['!w']).astype(np.float32) if self.weighted
+             else np.ones(m, np.float32))
+        degree = np.zeros(n, np.float32)
+        np.add.at(degree, ei, w)
+        np.add.at(degree, ej, w)
+        loops = ei == ej
+        np.subtract.at(degree, ei[loops], w[loops])
+        degree[degree == 0] = 1.0
+        self.degree = degree
+
+        label_df = edges.drop(['!i', '!j', '!w'])
+        label_t = _widen(label_df.rowtype(), real)
+        if self.weighted:
+            edge_t = np.dtype([('weight', real), ('label', label_t)],
+                              align=True)
+        else:
+            edge_t = label_t
+        self.edge_t = edge_t
+
+        # both orientations; duplicates (self loops, repeated edges) collapse
+        # onto their first occurrence like the reference's np.unique
+        src = np.concatenate((ei, ej))
+        dst = np.concatenate((ej, ei))
+        eid = np.concatenate((np.arange(m), np.arange(m)))
+        key = src * n + dst
+        _, first = np.unique(key, return_index=True)
+        src, dst, eid = src[first], dst[first], eid[first]
+        # device order: rank within the source row first, then source -- so
+        # neighbouring entries have distinct sources (graph.h)
+        by_row = np.lexsort((dst, src))
+        src, dst, eid = src[by_row], dst[by_row], eid[by_row]
+        row_start = np.searchsorted(src, src, side='left')
+        rank = np.arange(len(src)) - row_start
+        order = np.lexsort((src, rank))
+        src, dst, eid = src[order], dst[order], eid[order]
+        self.n_nz = nnz = len(src)
+        self.nz = np.zeros(nnz, dtype=NZ_DTYPE)
+        self.nz['i'], self.nz['j'] = src, dst
+        self.edge_index = eid
+
+        edges_aos = np.zeros(nnz, dtype=edge_t)
+        edge_fa = []
+        target = edges_aos['label'] if self.weighted and label_t.itemsize \
+            else edges_aos
+        if self.weighted:
+            edges_aos['weight'] = w[eid]
+        if label_t.itemsize:
+            self._fill(target, np.arange(nnz), label_df, label_t, edge_fa,
+                       take=eid)
+            if self.weighted:
+                edges_aos['label'] = target
+
+        # ---- blob ---------------------------------------------------------------
+        sections, cursor = {}, 0
+        for name, arr in (('degree', degree), ('node', nodes_aos),
+                          ('nz', self.nz), ('edge', edges_aos)):
+            sections[name] = (cursor, arr)
+            cursor += _pad(arr.nbytes)
+        payload_off = []
+        for arr in varlen:
+            payload_off.append(cursor)
+            sections[f'payload{len(payload_off) - 1}'] = (cursor, arr)
+            cursor += _pad(arr.nbytes)
+        blob = np.zeros(max(cursor, _ALIGN), dtype=np.uint8)
+        for off, arr in sections.values():
+            blob[off:off + arr.nbytes] = arr.view(np.uint8).ravel() \
+                if arr.nbytes else []
+        self.offsets = {k: v[0] for k, v in sections.items()}
+
+        relocs = []
+        for base_name, base_t, fa_list in (('node', node_t, node_fa),
+                                           ('edge', edge_t, edge_fa)):
+            for row, field_off, v in fa_list:
+                where = (self.offsets[base_name] + row * base_t.itemsize
+                         + field_off)
+                word = blob[where:where + 8].view(np.uint64)
+                word[0] = payload_off[v._payload] + v._head
+                relocs.append(where)
+        self.relocs = np.array(relocs, dtype=np.int64)
+        self.blob = blob
+
+    @staticmethod
+    def _field_offset(dtype, name):
+        return dtype.fields[name][1]
+
+    def _fill(self, aos, index, frame, dtype, fa_out, take=None, base=0):
+        """Scatter the columns of `frame` into struct array `aos` at rows
+        `index`; frozen_array cells get {offset placeholder, size} and are
+        recorded in `fa_out` as (row, byte offset of the pointer, view)."""
+        for name in dtype.names:
+            col = frame[name]
+            if take is not None:
+                col = np.asarray(col)[take] if is_scalar_type(col.dtype) \
+                    else [col[k] for k in take]
+            ft, foff = dtype.fields[name][0], dtype.fields[name][1]
+            if name.startswith('$'):
+                for row, v in zip(index, col):
+                    aos[name]['size'][row] = len(v)
+                    fa_out.append((int(row), base + foff
+                                   + ft.fields['ptr'][1], v))
+            else:
+                aos[name][index] = np.asarray(col).astype(ft)
+
+    # -- reference-compatible read-only views ---------------------------------
+    @property
+    def state(self):
+        raise AttributeError(
+            'DeviceGraph has no absolute-address state; headers are produced '
+            'by GraphArena once the blob has a device address.')
+
+
+class GraphArena:
+    """Concatenation of DeviceGraph blobs + the graph_t header table, ready
+    for one host-to-device copy.  Layout: [headers][blob 0][blob 1]..."""
+
+    def __init__(self, dgraphs):
+        self.n = len(dgraphs)
+        hdr_bytes = _pad(self.n * HEADER_DTYPE.itemsize)
+        sizes = np.array([len(g.blob) for g in dgraphs], dtype=np.int64)
+        starts = hdr_bytes + np.concatenate(([0], np.cumsum(sizes)[:-1])) \
+            if self.n else np.zeros(0, np.int64)
+        self.nbytes = int(hdr_bytes + sizes.sum())
+        self.host = np.zeros(self.nbytes, dtype=np.uint8)
+        self.blob_start = starts
+        self._relocs = []
+        hdr = np.zeros(self.n, dtype=HEADER_DTYPE)
+        for k, (g, s) in enumerate(zip(dgraphs, starts)):
+            self.host[s:s + len(g.blob)] = g.blob
+            hdr['n_node'][k] = g.n_node
+            hdr['n_nz'][k] = g.n_nz
+            for name in ('degree', 'node', 'nz', 'edge'):
+                hdr[name][k] = s + g.offsets[name]   # arena-relative for now
+            if len(g.relocs):
+                self._relocs.append(g.relocs + s)
+                words = self.host
+                for where in g.relocs + s:
+                    word = words[where:where + 8].view(np.uint64)
+                    word[0] += np.uint64(s)
+        self._hdr = hdr
+        self._relocs = (np.concatenate(self._relocs) if self._relocs
+                        else np.zeros(0, np.int64))
+        self.n_node = hdr['n_node'].astype(np.int64)
+        self.n_nz = hdr['n_nz'].astype(np.int64)
+
+    def relocated(self, base):
+        """Byte image with every pointer rebased onto device address `base`."""
+        img = self.host.copy()
+        hdr = self._hdr.copy()
+        for name in ('degree', 'node', 'nz', 'edge'):
+            hdr[name] += np.uintp(base)
+        img[:hdr.nbytes] = hdr.view(np.uint8)
+        for where in self._relocs:
+            word = img[where:where + 8].view(np.uint64)
+            word[0] += np.uint64(base)
+        return img

@@ -1,0 +1,96 @@
+/*
+ * gdhip.h -- C ABI of libgdhip.so, the drop-in boundary of the MI355X
+ * marginalized-graph-kernel path.
+ *
+ * The reference (yhtang/GraphDot v0.8.1) is a Python library whose only
+ * foreign-function interface for this path is PyCUDA's driver API.  Every
+ * entry point below replaces one PyCUDA call site of
+ * /root/reference/graphdot/kernel/marginalized/_backend_cuda.py (cited per
+ * function as "ref:") with a plain-C equivalent over the HIP runtime, so that
+ * the reference's backend seam (`Backend.__call__`, _backend.py:6-9) can be
+ * served by a ctypes stub -- see INTEGRATION.md.
+ *
+ * Conventions: every function returns 0 on success and a non-zero HIP error
+ * code (or -1) on failure; gd_last_error() then returns a thread-local,
+ * human-readable message.  No torch / C++ types cross this boundary: only
+ * integers, sizes and raw pointers.  All device work is issued on the stream
+ * passed in (0 = the HIP null stream).
+ */
+#ifndef GDHIP_H_
+#define GDHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gd_module_s *gd_module_t;     /* a loaded gfx950 code object  */
+typedef struct gd_function_s *gd_function_t; /* a __global__ inside a module */
+typedef struct gd_stream_s *gd_stream_t;     /* hipStream_t                  */
+typedef struct gd_event_s *gd_event_t;       /* hipEvent_t                   */
+
+typedef struct {
+    char name[256];         /* marketing name                                 */
+    char arch[64];          /* gcnArchName, e.g. "gfx950:sramecc+:xnack-"     */
+    int32_t compute_units;  /* multiProcessorCount (ref: MULTIPROCESSOR_COUNT,
+                               _backend_cuda.py:303)                          */
+    int32_t wavefront_size; /* ref: WARP_SIZE, _backend_cuda.py:309           */
+    int32_t max_threads_per_block;
+    int32_t clock_khz;
+    int64_t lds_per_block;  /* sharedMemPerBlock                              */
+    int64_t total_mem;      /* bytes of HBM                                   */
+} gd_device_props_t;
+
+/* ---- context (ref: graphdot/cuda/__init__.py:3-7, pycuda.autoinit) ------ */
+int gd_device_count(int *count);
+int gd_init(int device);                       /* hipSetDevice + warm-up    */
+int gd_device_props(int device, gd_device_props_t *out);
+int gd_device_sync(void);                      /* ref: ctx.synchronize(), _backend_cuda.py:367 */
+const char *gd_last_error(void);
+const char *gd_version(void);
+
+/* ---- memory (ref: graphdot/cuda/array.py:14-31 managed_* allocators;
+ *      _backend_cuda.py:326,331-335,338 memcpy_htod) ----------------------- */
+int gd_malloc(void **dptr, size_t bytes);
+int gd_free(void *dptr);
+int gd_host_alloc(void **hptr, size_t bytes);  /* pinned, for async copies  */
+int gd_host_free(void *hptr);
+int gd_memcpy_h2d(void *dst, const void *src, size_t bytes, gd_stream_t s);
+int gd_memcpy_d2h(void *dst, const void *src, size_t bytes, gd_stream_t s);
+int gd_memcpy_d2d(void *dst, const void *src, size_t bytes, gd_stream_t s);
+int gd_memset(void *dst, int value, size_t bytes, gd_stream_t s);
+
+/* ---- code objects (ref: pycuda.compiler.SourceModule, _backend_cuda.py:118-134;
+ *      module.get_function :298; module.get_global :305,325-337) ----------- */
+int gd_module_load(const void *image, size_t bytes, gd_module_t *out);
+int gd_module_unload(gd_module_t m);
+int gd_module_get_function(gd_module_t m, const char *name, gd_function_t *out);
+int gd_module_get_global(gd_module_t m, const char *name, void **dptr, size_t *bytes);
+/* static resource usage of a kernel: VGPRs are not exposed by HIP, LDS and
+ * max threads are (used to size launches) */
+int gd_function_attributes(gd_function_t f, int *static_lds_bytes,
+                           int *max_threads_per_block, int *num_regs);
+
+/* ---- launch (ref: kernel(..., grid=, block=, shared=), _backend_cuda.py:346-366).
+ * `args` is the kernel-argument buffer laid out exactly as the kernel's
+ * parameter list (natural alignment); it is copied before the call returns. */
+int gd_launch(gd_function_t f, uint32_t grid_x, uint32_t block_x,
+              uint32_t dynamic_lds_bytes, gd_stream_t s, const void *args,
+              size_t args_bytes);
+
+/* ---- streams & events (timing of the launched kernels on their own stream) */
+int gd_stream_create(gd_stream_t *out);
+int gd_stream_destroy(gd_stream_t s);
+int gd_stream_sync(gd_stream_t s);
+int gd_event_create(gd_event_t *out);
+int gd_event_destroy(gd_event_t e);
+int gd_event_record(gd_event_t e, gd_stream_t s);
+int gd_event_sync(gd_event_t e);
+int gd_event_elapsed_ms(gd_event_t start, gd_event_t stop, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDHIP_H_ */

@@ -1,0 +1,179 @@
+"""Workloads shared by the GPU parity tests, ``__graft_entry__.build()``
+(which pre-compiles their code objects) and ``bench.py``.
+
+Everything is synthetic and seeded; nothing here reads /root/reference.
+"""
+import numpy as np
+import networkx as nx
+from graphdot_amd.graph import Graph
+from graphdot_amd.microkernel import (
+    Constant, KroneckerDelta, SquareExponential, TensorProduct)
+
+
+# -- config 1: example/unlabeled-unweighted.py + 10 ER graphs ------
+def config1_graphs():
+    g1 = nx.Graph(); g1.add_edges_from([(0, 1)])
+    g2 = nx.Graph(); g2.add_edges_from([(0, 1), (1, 2)])
+    g3 = nx.Graph(); g3.add_edges_from([(0, 1), (0, 2), (1, 2)])
+    out = [g1, g2, g3]
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        n = int(rng.integers(3, 9))
+        g = nx.Graph()
+        g.add_nodes_from(range(n))
+        for i in range(n):
+            for j in range(i):
+                if rng.random() < 0.5:
+                    g.add_edge(i, j)
+        for i in range(n):          # re-wire isolated nodes
+            if g.degree[i] == 0:
+                g.add_edge(i, (i + 1) % n)
+        out.append(g)
+    return Graph.unify_datatype([Graph.from_networkx(g) for g in out])
+
+
+def config1_kernels():
+    return Constant(1.0), Constant(1.0), 0.05
+
+
+# -- config 2: node-labeled, weighted random graphs ---------------------------------
+def nlw_example_graphs():
+    """The three graphs of the reference's example/nodelabeled-weighted.py."""
+    g1 = nx.Graph()
+    g1.add_node(0, radius=1.0, category=1)
+    g1.add_node(1, radius=2.0, category=1)
+    g1.add_edge(0, 1, w=1.0)
+    g2 = nx.Graph()
+    g2.add_node(0, radius=1.0, category=1)
+    g2.add_node(1, radius=2.0, category=1)
+    g2.add_node(2, radius=1.0, category=2)
+    g2.add_edge(0, 1, w=1.0)
+    g2.add_edge(1, 2, w=2.0)
+    g3 = nx.Graph()
+    g3.add_node(0, radius=1.0, category=1)
+    g3.add_node(1, radius=2.0, category=1)
+    g3.add_node(2, radius=1.0, category=2)
+    g3.add_edge(0, 1, w=1.0)
+    g3.add_edge(0, 2, w=0.5)
+    g3.add_edge(1, 2, w=2.0)
+    return Graph.unify_datatype(
+        [Graph.from_networkx(g, weight='w') for g in (g1, g2, g3)])
+
+
+def config2_graphs(n_graphs=256, nmin=8, nmax=48, seed=0):
+    """Newman-Watts-Strogatz graphs (k=5, p=0.05) as in the reference's
+    benchmark/kernel/marginalized/time_kernel.py:14-29, with node attributes
+    radius/category, edge weight w and edge attribute length."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_graphs):
+        n = int(rng.integers(nmin, nmax + 1))
+        g = nx.newman_watts_strogatz_graph(n, 5, 0.05,
+                                           seed=int(rng.integers(1 << 30)))
+        for i in g.nodes:
+            g.nodes[i]['radius'] = float(rng.choice([1.0, 1.5, 2.0]))
+            g.nodes[i]['category'] = int(rng.choice([1, 2, 3]))
+        for e in g.edges:
+            g.edges[e]['w'] = float(rng.choice([0.5, 1.0, 2.0]))
+            g.edges[e]['length'] = float(rng.uniform(0.5, 2.5))
+        out.append(Graph.from_networkx(g, weight='w'))
+    return Graph.unify_datatype(out)
+
+
+def config2a_kernels():
+    """script-faithful: example/nodelabeled-weighted.py:44-52"""
+    return (TensorProduct(radius=SquareExponential(0.5),
+                          category=KroneckerDelta(0.5)),
+            Constant(1.0), 0.05)
+
+
+def config2b_kernels():
+    """BASELINE.json-faithful: KroneckerDelta node x SquareExponential edge"""
+    return (TensorProduct(category=KroneckerDelta(0.5)),
+            TensorProduct(length=SquareExponential(1.0)), 0.05)
+
+
+# -- config 3: synthetic QM7-like molecules -------------------------------
+_VALENCE = {6: 4, 7: 3, 8: 2, 16: 2}
+
+
+def qm7_like_molecule(rng):
+    """A random molecule-like graph in the size range of QM7: up to 7 heavy
+    atoms (C, N, O, S) joined as a random tree respecting valence, 0-2 ring
+    closures, some double/aromatic bonds, then hydrogens on every free
+    valence (at most 23 atoms in total).  Node and edge attributes follow the
+    reference's Graph.from_rdkit (graph/_from_rdkit.py:219-243)."""
+    n_heavy = int(np.clip(round(rng.normal(6.3, 1.0)), 1, 7))
+    Z = rng.choice([6, 7, 8, 16], size=n_heavy, p=[0.72, 0.12, 0.14, 0.02])
+    Z[0] = 6
+    cap = np.array([_VALENCE[int(z)] for z in Z])
+    used = np.zeros(n_heavy, dtype=int)
+    bonds = {}
+    for v in range(1, n_heavy):
+        cand = [u for u in range(v) if used[u] < cap[u] - (u == 0 and v < 2)]
+        cand = [u for u in cand if used[u] < cap[u]]
+        if not cand:                    # saturated so far: open up a carbon
+            u = int(rng.integers(0, v))
+            Z[u], cap[u] = 6, 4
+        else:
+            u = int(rng.choice(cand))
+        bonds[(u, v)] = 1.0
+        used[u] += 1
+        used[v] += 1
+    for _ in range(int(rng.integers(0, 3))):       # ring closures
+        free = [u for u in range(n_heavy) if used[u] < cap[u]]
+        if len(free) >= 2:
+            u, v = sorted(rng.choice(free, size=2, replace=False).tolist())
+            if (u, v) not in bonds:
+                bonds[(u, v)] = 1.0
+                used[u] += 1
+                used[v] += 1
+    for (u, v) in list(bonds):                     # double / aromatic bonds
+        if used[u] < cap[u] and used[v] < cap[v] and rng.random() < 0.15:
+            bonds[(u, v)] = float(rng.choice([1.5, 2.0]))
+            used[u] += 1
+            used[v] += 1
+    free = np.maximum(cap - used, 0)
+    h_nodes = []
+    for u in rng.permutation(n_heavy):
+        for _ in range(int(free[u])):
+            if n_heavy + len(h_nodes) < 23:
+                h_nodes.append(int(u))
+    hcount = np.bincount(np.array(h_nodes, dtype=int), minlength=n_heavy)
+    g = nx.Graph()
+    for u in range(n_heavy):
+        mult = [o for (a, b), o in bonds.items() if u in (a, b)]
+        g.add_node(u, atomic_number=int(Z[u]), charge=0, hcount=int(hcount[u]),
+                   hybridization=int(4 - min(3, sum(o > 1 for o in mult))),
+                   aromatic=bool(any(o == 1.5 for o in mult)), chiral=0)
+    for k, u in enumerate(h_nodes):
+        h = n_heavy + k
+        g.add_node(h, atomic_number=1, charge=0, hcount=0, hybridization=1,
+                   aromatic=False, chiral=0)
+        g.add_edge(u, h, order=1.0, aromatic=False, conjugated=False,
+                   stereo=0, ring_stereo=0.0)
+    for (u, v), o in bonds.items():
+        g.add_edge(u, v, order=float(o), aromatic=bool(o == 1.5),
+                   conjugated=bool(o > 1.0), stereo=0, ring_stereo=0.0)
+    if g.number_of_edges() == 0:                   # fully unsaturated atom
+        g.add_node(n_heavy, atomic_number=1, charge=0, hcount=0,
+                   hybridization=1, aromatic=False, chiral=0)
+        g.add_edge(0, n_heavy, order=1.0, aromatic=False, conjugated=False,
+                   stereo=0, ring_stereo=0.0)
+    return g
+
+
+def config3_graphs(n_graphs=1000, seed=7165):
+    rng = np.random.default_rng(seed)
+    return Graph.unify_datatype(
+        [Graph.from_networkx(qm7_like_molecule(rng))
+         for _ in range(n_graphs)])
+
+
+def config3_kernels():
+    node = TensorProduct(atomic_number=KroneckerDelta(0.5),
+                         hcount=SquareExponential(1.0),
+                         aromatic=KroneckerDelta(0.8))
+    edge = TensorProduct(order=SquareExponential(0.5),
+                         conjugated=KroneckerDelta(0.5))
+    return node, edge, 0.01

@@ -1,0 +1,334 @@
+"""Parity of the HIP path against the CPU oracle and the golden vectors.
+
+These are the reference's own result tests
+(/root/reference/test/kernel/marginalized/test_kernel.py:195-569) restated
+against ``HIPBackend``; tolerances are the reference's (fp32 device
+arithmetic vs an fp64 oracle):  rel 1e-5 on kernel values, exact symmetry,
+normalised self-similarity 1 +- 2e-7 ... see each test.
+"""
+import numpy as np
+import pytest
+from _fixtures import load, graphs_from, kernel_from_repr
+from graphdot_amd.graph import Graph
+from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+from graphdot_amd.microkernel import (
+    Constant, KroneckerDelta, SquareExponential, TensorProduct)
+from oracle import mgk as oracle
+import cases
+
+pytestmark = pytest.mark.gpu
+
+MLGK = load('mlgk_cases.json')
+FAMILIES = ['unlabeled', 'labeled', 'weighted', 'vario-features']
+
+
+@pytest.fixture(scope='module')
+def backend():
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    return HIPBackend(record_iterations=True)
+
+
+def family(name):
+    case = MLGK[name]
+    return (graphs_from(case['graphs']), kernel_from_repr(case['knode']),
+            kernel_from_repr(case['kedge']), case)
+
+
+@pytest.mark.parametrize('name', FAMILIES)
+def test_self_similarity_vs_golden(backend, name):
+    """test_kernel.py:195-217"""
+    G, knode, kedge, case = family(name)
+    for qi, q in enumerate(case['q']):
+        mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+        R = mlgk(G)
+        d = np.diag(R)**-0.5
+        K = np.diag(d).dot(R).dot(np.diag(d))
+        assert R.shape == (len(G), len(G))
+        assert np.count_nonzero(R - R.T) == 0
+        for g in range(len(G)):
+            assert R[g, g] == pytest.approx(case['R'][qi][g], rel=1e-5)
+            assert K[g, g] == pytest.approx(1, abs=2e-7)
+        # off-diagonal entries: dense fp64 oracle
+        ref = oracle.gram(G, knode, kedge, q=q)
+        assert np.allclose(R, ref, rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize('name', FAMILIES)
+def test_cross_similarity_blocks(backend, name):
+    """test_kernel.py:220-241"""
+    G, knode, kedge, case = family(name)
+    for q in case['q']:
+        mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+        R = mlgk(G)
+        assert np.allclose(mlgk(G[:1], G), R[:1, :], rtol=1e-6)
+        assert np.allclose(mlgk(G[1:], G), R[1:, :], rtol=1e-6)
+        assert np.allclose(mlgk(G, G[:1]), R[:, :1], rtol=1e-6)
+        assert np.allclose(mlgk(G, G[1:]), R[:, 1:], rtol=1e-6)
+
+
+@pytest.mark.parametrize('name', FAMILIES)
+def test_gradient_vs_oracle(backend, name):
+    """Analytic graph-level gradient (marginalized_kernel.h:806-997) against
+    the fp64 restatement: rel 2e-3 (fp32 solves), and against central finite
+    differences like test_kernel.py:244-289 (rtol = atol = 0.05)."""
+    G, knode, kedge, case = family(name)
+    for q in case['q']:
+        mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+        R, dR = mlgk(G, eval_gradient=True)
+        Ro, dRo = oracle.gram(G, knode, kedge, q=q, eval_gradient=True)
+        assert np.allclose(R, Ro, rtol=1e-5)
+        mask = mlgk.active_theta_mask
+        scale = np.abs(dRo[:, :, mask]).max(axis=(0, 1), keepdims=True)
+        assert np.all(np.abs(dR - dRo[:, :, mask]) <= 2e-3 * scale + 1e-6)
+        assert np.count_nonzero(dR - dR.transpose(1, 0, 2)) == 0
+
+
+@pytest.mark.parametrize('name', FAMILIES)
+def test_diag_and_nodal(backend, name):
+    """test_kernel.py:292-340"""
+    G, knode, kedge, case = family(name)
+    for qi, q in enumerate(case['q']):
+        mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+        R = mlgk(G)
+        D = mlgk.diag(G)
+        assert np.allclose(D, np.diag(R), rtol=1e-7)
+        R_nodal = mlgk(G, nodal=True)
+        n = np.array([len(g.nodes) for g in G])
+        N = np.cumsum(n)
+        assert R_nodal.shape == (N[-1], N[-1])
+        assert np.count_nonzero(R_nodal - R_nodal.T) == 0
+        for k, (i, j) in enumerate(zip(N - n, N)):
+            gnd = np.array(case['R_nodal'][qi][k])
+            assert np.allclose(R_nodal[i:j, i:j], gnd, rtol=1e-5)
+        d = np.diag(R_nodal)**-0.5
+        Kn = np.diag(d).dot(R_nodal).dot(np.diag(d))
+        assert np.allclose(np.diag(Kn), 1, atol=2e-7)
+        assert np.allclose(R_nodal, oracle.gram(G, knode, kedge, q=q,
+                                                nodal=True), rtol=1e-5)
+        D_nodal = mlgk.diag(G, nodal=True)
+        assert np.allclose(D_nodal, np.diag(R_nodal), rtol=1e-7)
+        blocks = mlgk.diag(G, nodal='block')
+        for k, (i, j) in enumerate(zip(N - n, N)):
+            assert np.allclose(blocks[k], R_nodal[i:j, i:j], rtol=1e-7)
+
+
+@pytest.mark.parametrize('name', FAMILIES)
+def test_diag_gradient(backend, name):
+    """test_kernel.py:343-386 (graph-level part)"""
+    G, knode, kedge, case = family(name)
+    q = 0.05
+    mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    D, dD = mlgk.diag(G, eval_gradient=True)
+    R, dR = mlgk(G, eval_gradient=True)
+    assert np.allclose(D, np.diag(R), rtol=1e-7)
+    for k in range(dD.shape[1]):
+        assert np.allclose(dD[:, k], np.diag(dR[:, :, k]), rtol=1e-6)
+
+
+@pytest.mark.parametrize('name', FAMILIES)
+def test_lmin(backend, name):
+    """test_kernel.py:389-408: R(lmin=0) = R(lmin=1) + kappa_v"""
+    G, knode, kedge, case = family(name)
+    for q in case['q']:
+        mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+        g = G[0]
+        R0 = mlgk([g], nodal=True, lmin=0)
+        R1 = mlgk([g], nodal=True, lmin=1)
+        for i, n1 in g.nodes.iterrows():
+            for j, n2 in g.nodes.iterrows():
+                assert R0[i, j] == pytest.approx(R1[i, j] + knode(n1, n2),
+                                                 abs=1e-6 * max(1, R0[i, j]))
+        assert mlgk([g], lmin=1).item() == pytest.approx(
+            oracle.gram([g], knode, kedge, q=q, lmin=1).item(), rel=1e-5)
+
+
+@pytest.mark.parametrize('name', FAMILIES)
+def test_starting_probability(backend, name):
+    """test_kernel.py:411-439"""
+    G, knode, kedge, case = family(name)
+    for qi, q in enumerate(case['q']):
+        mlgk = MarginalizedGraphKernel(knode, kedge, q=q, p=2.0,
+                                       backend=backend)
+        R = mlgk(G)
+        for g in range(len(G)):
+            assert R[g, g] == pytest.approx(case['R'][qi][g] * 4, rel=1e-5)
+        R_nodal = mlgk(G, nodal=True)
+        n = np.array([len(g.nodes) for g in G])
+        N = np.cumsum(n)
+        for i1, j1, g1 in zip(N - n, N, G):
+            for i2, j2, g2 in zip(N - n, N, G):
+                sub = mlgk([g1], [g2], nodal=True)
+                assert np.allclose(sub, R_nodal[i1:j1, i2:j2], rtol=1e-5)
+
+
+def test_adhoc_starting_probability(backend):
+    G, knode, kedge, case = family('labeled')
+    p = (lambda nodes: np.asarray(nodes['hybridization'], dtype=float) + 1.0,
+         'n.hybridization + 1.0f')
+    mlgk = MarginalizedGraphKernel(knode, kedge, q=0.1, p=p, backend=backend)
+    R = mlgk(G)
+    assert np.allclose(R, oracle.gram(G, knode, kedge, p=mlgk.p, q=0.1),
+                       rtol=1e-5)
+
+
+def test_m3_cross_pairs(backend):
+    """Cross pairs of the reference CPU solver M3._mlgk (m3.py:52-106).  That
+    code assembles its system partly in float32, so it pins results to about
+    1e-6 only."""
+    for name, case in load('m3_cross.json').items():
+        G = graphs_from(case['graphs'])
+        knode = kernel_from_repr(case['knode'])
+        kedge = kernel_from_repr(case['kedge'])
+        mlgk = MarginalizedGraphKernel(knode, kedge, q=case['q'],
+                                       backend=backend)
+        R = mlgk(G, nodal=True)
+        n = np.array([len(g.nodes) for g in G])
+        N = np.cumsum(n)
+        for a, (i1, j1) in enumerate(zip(N - n, N)):
+            for b, (i2, j2) in enumerate(zip(N - n, N)):
+                ref = np.array(case['R_nodal'][a][b])
+                assert np.allclose(R[i1:j1, i2:j2], ref, rtol=1e-5)
+
+
+def test_self_loops(backend):
+    """test_kernel.py:507-525 family (golden values from MLGK)"""
+    mlgk = MarginalizedGraphKernel(Constant(1.0), Constant(1.0), q=0.1,
+                                   backend=backend)
+    for c in MLGK['self-loops']:
+        g = graphs_from([c['graph']])
+        assert mlgk(g).item() == pytest.approx(c['R'], rel=5e-4)
+
+
+def test_example_unlabeled(backend):
+    """config 1: known answer R = n1 n2 / (1 - (1-q)^2), normalised K == 1"""
+    G = cases.config1_graphs()
+    knode, kedge, q = cases.config1_kernels()
+    mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    R = mlgk(G)
+    n = np.array([len(g.nodes) for g in G], dtype=float)
+    assert np.allclose(R, np.outer(n, n) / (1 - (1 - q)**2), rtol=1e-5)
+    d = np.diag(R)**-0.5
+    assert np.allclose(d[:, None] * R * d[None, :], 1, atol=1e-5)
+
+
+def test_example_nodelabeled_weighted(backend):
+    """config 2 (script): golden R from SURVEY 8c(4) / m3 fixture"""
+    G = cases.nlw_example_graphs()
+    knode, kedge, q = cases.config2a_kernels()
+    mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    R = mlgk(G)
+    ref = oracle.gram(G, knode, kedge, q=q)
+    assert np.allclose(R, ref, rtol=1e-5)
+    assert R[0, 0] == pytest.approx(20.8211405, rel=2e-6)
+    assert R[1, 2] == pytest.approx(13.6964659, rel=2e-6)
+
+
+def test_permutation_invariance(backend):
+    """test_kernel.py:492-504 on a synthetic molecule"""
+    rng = np.random.default_rng(5)
+    g = cases.config3_graphs(3, seed=11)[2]
+    knode, kedge, q = cases.config3_kernels()
+    mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    ref = mlgk([g]).item()
+    for _ in range(5):
+        h = g.permute(rng.permutation(len(g.nodes)))
+        assert mlgk([g], [h]).item() == pytest.approx(ref, rel=2e-6)
+
+
+def test_fixed_hyperparameters(backend):
+    """test_kernel.py:528-569"""
+    import networkx as nx
+    g = nx.Graph()
+    g.add_node(0, feature=0)
+    g.add_node(1, feature=1)
+    g.add_node(2, feature=0)
+    g.add_edge(0, 1, attribute=1.0)
+    g.add_edge(0, 2, attribute=2.0)
+    G = [Graph.from_networkx(g)]
+    knodeV = TensorProduct(feature=KroneckerDelta(0.5))
+    knodeF = TensorProduct(feature=KroneckerDelta(0.5, h_bounds='fixed'))
+    kedgeV = TensorProduct(attribute=SquareExponential(1.0))
+    kedgeF = TensorProduct(
+        attribute=SquareExponential(1.0, length_scale_bounds='fixed'))
+    kVV = MarginalizedGraphKernel(knodeV, kedgeV, backend=backend)
+    kVF = MarginalizedGraphKernel(knodeV, kedgeF, backend=backend)
+    kFV = MarginalizedGraphKernel(knodeF, kedgeV, backend=backend)
+    kFF = MarginalizedGraphKernel(knodeF, kedgeF, backend=backend)
+    Rvv, dRvv = kVV(G, eval_gradient=True)
+    Rvf, dRvf = kVF(G, eval_gradient=True)
+    Rfv, dRfv = kFV(G, eval_gradient=True)
+    Rff, dRff = kFF(G, eval_gradient=True)
+    assert Rvv == pytest.approx(Rvf)
+    assert Rvv == pytest.approx(Rfv)
+    assert Rvv == pytest.approx(Rff)
+    assert dRvv.shape[2] == dRvf.shape[2] + 1
+    assert dRvv.shape[2] == dRff.shape[2] + 2
+    assert dRvv[:, :, kVF.active_theta_mask] == pytest.approx(dRvf)
+    assert dRvv[:, :, kFV.active_theta_mask] == pytest.approx(dRfv)
+    assert dRvv[:, :, kFF.active_theta_mask] == pytest.approx(dRff)
+
+
+def test_dtype(backend):
+    """test_kernel.py:465-489"""
+    G = cases.config1_graphs()[:2]
+    for dtype in [float, np.float32, np.float64]:
+        mlgk = MarginalizedGraphKernel(Constant(1.0), Constant(1.0), q=0.5,
+                                       dtype=dtype, backend=backend)
+        assert mlgk(G).dtype == dtype
+        assert mlgk.diag(G).dtype == dtype
+
+
+def test_typecheck(backend):
+    """test_kernel.py:173-192"""
+    import networkx as nx
+    a = nx.Graph(); a.add_edge(0, 1)
+    b = nx.Graph(); b.add_node(0, x=1); b.add_node(1, x=2); b.add_edge(0, 1, y=1.0)
+    mlgk = MarginalizedGraphKernel(Constant(1.0), Constant(1.0), q=0.5,
+                                   backend=backend)
+    G = [Graph.from_networkx(a), Graph.from_networkx(b)]
+    with pytest.raises(TypeError):
+        mlgk([G[0], G[1]])
+    with pytest.raises(TypeError):
+        mlgk([G[1], G[0]])
+
+
+@pytest.mark.parametrize('variant', ['2a', '2b'])
+def test_random_graphs_all_variants(backend, variant):
+    """Graphs of 8..48 nodes exercise the multi-wave solver variants; checked
+    against the C restatement of the reference PCG (fp32) and the dense fp64
+    oracle on a sample of pairs, and through the iteration counts."""
+    G = cases.config2_graphs(24, seed=3)
+    knode, kedge, q = (cases.config2a_kernels() if variant == '2a'
+                       else cases.config2b_kernels())
+    mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    R = mlgk(G)
+    assert np.count_nonzero(R - R.T) == 0
+    used = {L['variant'].W for L in backend.last_plan.launches}
+    assert len(used) >= 2, used
+    rng = np.random.default_rng(0)
+    for _ in range(12):
+        a, b = rng.integers(0, len(G), size=2)
+        ref = oracle.gram([G[a]], knode, kedge, Y=[G[b]], q=q).item()
+        assert R[a, b] == pytest.approx(ref, rel=2e-5)
+    it = backend.iterations(backend.last_plan)
+    assert it.min() >= 1 and it.max() < 200
+
+
+def test_qm7_like_sample(backend):
+    """config 3 family at a size the oracle finishes in seconds."""
+    G = cases.config3_graphs(40, seed=99)
+    knode, kedge, q = cases.config3_kernels()
+    mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    R = mlgk(G)
+    batch = oracle.TensorProductBatch(G, knode, kedge)
+    i, j = np.triu_indices(len(G))
+    ref, iters = batch.run(i, j, q=q, real='f64', tol=1e-14)
+    assert np.allclose(R[i, j], ref, rtol=2e-5)
+    d = np.diag(R)**-0.5
+    K = d[:, None] * R * d[None, :]
+    assert np.all(K <= 1 + 1e-5) and np.all(K > 0)
+    Rg, dR = mlgk(G[:8], eval_gradient=True)
+    Ro, dRo = oracle.gram(G[:8], knode, kedge, q=q, eval_gradient=True)
+    mask = mlgk.active_theta_mask
+    scale = np.abs(dRo[:, :, mask]).max(axis=(0, 1), keepdims=True)
+    assert np.all(np.abs(dR - dRo[:, :, mask]) <= 2e-3 * scale)
