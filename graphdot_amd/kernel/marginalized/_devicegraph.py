@@ -194,7 +194,8 @@ class DeviceGraph:
             edges_aos['weight'] = w[eid]
         if label_t.itemsize:
             self._fill(target, np.arange(nnz), label_df, label_t, edge_fa,
-                       take=eid)
+                       take=eid,
+                       base=edge_t.fields['label'][1] if self.weighted else 0)
             if self.weighted:
                 edges_aos['label'] = target
 
