@@ -1,0 +1,262 @@
+#!/usr/bin/env python
+"""Gram-matrix throughput of the marginalized graph kernel on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--graphs 1000] [--dtype f32|f64] [--gradient]
+
+A *step* is one full pass of the hot path over the batch: every pair of the
+symmetric Gram matrix of the synthetic QM7-like set (config 3 of
+BASELINE.json) is solved from device-resident graphs, job list
+and hyperparameters into the device-resident result.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) the pairs are sharded over the ranks
+and one RCCL all-gather per step reassembles the packed results.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with the
+extra objects "roofline" (dominant kernel, HIP-event timed inside the timed
+region) and "cpu_baseline" (the C oracle timed on this host, rank 0, N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--graphs', type=int, default=1000)
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
+    ap.add_argument('--gradient', action='store_true',
+                    help='also evaluate dK/dtheta (config 5 kernel part)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(arena, ji, jj, rsize, n_cols):
+    """compulsory HBM bytes of a pair = both graph images (as
+    packed in HBM) + the result."""
+    blob = np.diff(np.concatenate((arena.blob_start, [arena.nbytes])))
+    hdr = 40
+    return (blob[ji] + blob[jj] + 2 * hdr + rsize * n_cols).astype(np.int64)
+
+
+def algorithmic_flops(n_node, n_nz, ji, jj, iters, Fv=9, Fe=8):
+    """SURVEY 8(d) with cached edge/node kernel tables:
+    k (2 nnzx + 17 N) + nnzx F_e + N F_v."""
+    N = n_node[ji] * n_node[jj]
+    nnzx = n_nz[ji] * n_nz[jj]
+    return iters * (2 * nnzx + 17 * N) + nnzx * Fe + N * Fv
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+
+    import cases
+    from graphdot_amd.hip import runtime
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    from graphdot_amd.kernel.marginalized._sharded import ShardPlan
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device(
+            'cuda', local_rank))
+    real = np.float32 if args.dtype == 'f32' else np.float64
+    backend = HIPBackend(device=local_rank, real=real, record_iterations=True)
+
+    graphs = cases.config3_graphs(args.graphs)
+    knode, kedge, q = cases.config3_kernels()
+    kernel = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    n = len(graphs)
+    i, j = np.triu_indices(n)
+    job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
+    all_jobs = np.column_stack((i, j)).astype(np.uint32).ravel().view(job_t)
+    n_pairs = len(all_jobs)
+    traits = kernel.traits(symmetric=True, eval_gradient=args.gradient)
+    nJ = kernel.n_dims
+    n_cols = 1 + (nJ if args.gradient else 0)
+    starts = np.arange(n + 1, dtype=np.uint32)
+
+    # ---- shard (world == 1: the single shard is the whole job list) ---------
+    dgs = [backend._register_graph(g) for g in graphs]
+    n_node = np.array([g.n_node for g in dgs], dtype=np.int64)
+    n_nz = np.array([g.n_nz for g in dgs], dtype=np.int64)
+    shard = ShardPlan(i, j, n_node, n_nz, n, n, True, rank, world)
+    local_jobs = all_jobs[shard.local] if world > 1 else all_jobs
+    plan = backend.prepare(graphs, knode, kedge, kernel.p, kernel.q,
+                           kernel.eps, kernel.ftol, kernel.gtol, local_jobs,
+                           starts, n, n, nJ, traits, packed=(world > 1))
+    if world > 1:
+        cap = shard.capacity
+        local_out = torch.zeros(cap * n_cols, dtype=torch.float32
+                                if real is np.float32 else torch.float64,
+                                device='cuda')
+        gathered = torch.empty(world * cap * n_cols, dtype=local_out.dtype,
+                               device='cuda')
+
+    events = [runtime.Event() for _ in range(len(plan.launches) + 1)]
+    kernel_ms = np.zeros(len(plan.launches))
+
+    def step(timed):
+        if timed:
+            events[0].record()
+        for k, L in enumerate(plan.launches):
+            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'])
+            if timed:
+                events[k + 1].record()
+        if world > 1:
+            # packed slab -> torch tensor (device-to-device), then all-gather
+            rs = np.dtype(real).itemsize
+            runtime.check(runtime.lib().gd_memcpy_d2d(
+                local_out.data_ptr(), plan.buffers['gramian'].ptr,
+                plan.n_jobs * rs, None))
+            if args.gradient:
+                runtime.check(runtime.lib().gd_memcpy_d2d(
+                    local_out.data_ptr() + cap * rs,
+                    plan.buffers['gradient'].ptr, plan.n_jobs * nJ * rs, None))
+            dist.all_gather_into_tensor(gathered, local_out)
+
+    def sync():
+        runtime.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step(False)
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+        # per-kernel durations from the events of this step
+        events[-1].sync()
+        for k in range(len(plan.launches)):
+            kernel_ms[k] += events[k].elapsed_ms(events[k + 1])
+    sync()
+    barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms /= max(args.steps, 1)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_pairs / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel -------------------------------------
+    arena = plan.keep[0]
+    dom = int(np.argmax(kernel_ms))
+    L = plan.launches[dom]
+    ids = plan.order_host[L['offset']:L['offset'] + L['count']] & 0x1FFFFFFF
+    lj = local_jobs[ids]
+    lji, ljj = lj['i'].astype(np.int64), lj['j'].astype(np.int64)
+    iters = backend.iterations(plan)[ids].astype(np.int64)
+    rsize = np.dtype(real).itemsize
+    abytes = int(algorithmic_bytes(arena, lji, ljj, rsize, n_cols).sum())
+    aflops = int(algorithmic_flops(n_node, n_nz, lji, ljj, iters).sum()
+                 * (2 if args.gradient else 1))
+    dur = kernel_ms[dom] * 1e-3
+    v = L['variant']
+    roofline = {
+        'bound': 'hbm', 'kernel': backend.kernel_name(v, plan.C),
+        'achieved': abytes / dur / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+        'frac': abytes / dur / 1e9 / 8000.0, 'traffic': None,
+        'algorithmic_bytes_per_launch': abytes,
+        'pairs_per_launch': int(L['count']),
+        'avg_launch_ms': float(kernel_ms[dom]),
+        'note': 'the solver is LDS/VALU-bound by design (CG vectors and the '
+                'product-graph operator live in LDS/registers); see compute',
+    }
+    peak_tf = 157.3 if real is np.float32 else 78.6
+    compute = {
+        'bound': 'valu', 'achieved': aflops / dur / 1e12, 'peak': peak_tf,
+        'unit': 'TFLOP/s', 'frac': aflops / dur / 1e12 / peak_tf,
+        'algorithmic_flops_per_launch': aflops,
+        'mean_cg_iterations': float(iters.mean()),
+    }
+    per_kernel = [
+        {'kernel': backend.kernel_name(l['variant'], plan.C),
+         'pairs': int(l['count']), 'grid': int(l['grid']),
+         'avg_ms': float(ms)} for l, ms in zip(plan.launches, kernel_ms)]
+
+    # ---- CPU baseline (oracle, 1 core, bounded sample), N = 1 only -----------
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and not args.gradient:
+        from oracle import mgk
+        batch = mgk.TensorProductBatch(graphs, knode, kedge)
+        rng = np.random.default_rng(0)
+        probe = rng.choice(n_pairs, size=min(2000, n_pairs), replace=False)
+        t1 = time.perf_counter()
+        batch.run(i[probe], j[probe], q=q, real=args.dtype)
+        rate = len(probe) / (time.perf_counter() - t1)
+        size = int(min(n_pairs, max(2000, rate * args.cpu_seconds)))
+        sample = rng.choice(n_pairs, size=size, replace=False)
+        t1 = time.perf_counter()
+        ref, _ = batch.run(i[sample], j[sample], q=q, real=args.dtype)
+        dt = time.perf_counter() - t1
+        cpu = {'value': size / dt, 'unit': 'graph-pairs/s', 'cores': 1,
+               'kind': 'port',
+               'sample': f'{size} uniformly sampled pairs of the same '
+                         f'{n}-graph set, oracle/mgk_oracle.c '
+                         f'mgk_gram_tp_{args.dtype}, 1 thread'}
+        # the sample doubles as an on-line parity check of the timed result
+        got, _ = backend.collect(plan)
+        K = got.reshape(n, n, order='F')
+        err = np.max(np.abs(K[i[sample], j[sample]] / ref - 1))
+        cpu['max_rel_diff_vs_gpu'] = float(err)
+
+    line = {
+        'metric': 'graph-pairs/sec (Gram matrix)', 'value': value,
+        'unit': 'graph-pairs/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'strong',
+        'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+        'config': {
+            'workload': f'QM7-like synthetic set ({n} molecules, seed 7165, '
+                        f'{n_pairs} pairs incl. diagonal), TensorProduct '
+                        'atom/bond microkernels, q=0.01'
+                        + (', value + gradient' if args.gradient else ''),
+            'graphs': n, 'pairs': n_pairs,
+            'parallelism': f'pair-sharded x{world}' if world > 1 else 'single',
+        },
+        'roofline': roofline, 'compute': compute, 'kernels': per_kernel,
+        'cpu_baseline': cpu,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

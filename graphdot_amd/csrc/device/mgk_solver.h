@@ -229,10 +229,13 @@ struct pair_solver {
                 // Ap -= W . p     (register-resident nonzeros, LDS gather/scatter)
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    const unsigned col = rc[s] & 0xFFFFu, row = rc[s] >> 16;
+                    if (s * W + wv >= ntiles) break;  // wave-uniform: no work left
+                    if (val[s] != real(0)) {          // lanes past the tile edge
+                        const unsigned col = rc[s] & 0xFFFFu, row = rc[s] >> 16;
 #pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        lds_add(&lAp[row * C + c], -val[s] * lp[col * C + c]);
+                        for (int c = 0; c < C; ++c)
+                            lds_add(&lAp[row * C + c], -val[s] * lp[col * C + c]);
+                    }
                 }
                 job_sync<W>();
                 real Ap[C][R];

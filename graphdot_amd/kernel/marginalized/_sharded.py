@@ -1,0 +1,82 @@
+"""Pair-sharded Gram matrix over the GPUs of one node.
+
+New capability (the reference has no multi-GPU code):
+every graph pair is independent (reference job loop: template.cu:57-70), so the
+job list is dealt to the ranks in cost order, every rank solves its shard into
+a *packed* per-job slab (the output shape of the reference's
+``alt_graph_kernel_solver``, experimental/alterantive_mgk/template.cu:71,103-118)
+and one all-gather of equal-sized slabs reassembles the matrix.  There is no
+other data-path collective.
+
+The class is transport- and device-agnostic: ``solve_local(job_ids)`` computes
+the shard (the HIP plan on a GPU, the oracle in the CPU tests) and
+``all_gather(local)`` is ``torch.distributed.all_gather_into_tensor`` over RCCL
+(backend "nccl") on GPUs or gloo on CPU.
+"""
+import numpy as np
+
+
+def predict_cost(n_node, n_nz, ji, jj):
+    """Relative cost of a pair: product-graph nonzeros plus vector work."""
+    return n_nz[ji] * n_nz[jj] + 4 * n_node[ji] * n_node[jj]
+
+
+def partition(cost, world_size):
+    """Deal jobs to ranks in descending-cost snake order (LPT-like).  Returns
+    a list of job-id arrays, one per rank, each sorted by descending cost."""
+    order = np.argsort(-cost, kind='stable')
+    k = np.arange(len(order))
+    rnd, pos = k // world_size, k % world_size
+    rank = np.where(rnd % 2 == 0, pos, world_size - 1 - pos)
+    return [order[rank == r] for r in range(world_size)]
+
+
+class ShardPlan:
+    """Static description of one rank's share and of the reassembly."""
+
+    def __init__(self, ji, jj, n_node, n_nz, nX, nY, symmetric, rank,
+                 world_size):
+        self.rank, self.world_size = rank, world_size
+        self.ji, self.jj = np.asarray(ji), np.asarray(jj)
+        self.nX, self.nY, self.symmetric = nX, nY, symmetric
+        cost = predict_cost(np.asarray(n_node), np.asarray(n_nz),
+                            self.ji, self.jj)
+        self.shards = partition(cost, world_size)
+        self.capacity = max(len(s) for s in self.shards) if len(cost) else 0
+        self.local = self.shards[rank]
+        # position of every job in the gathered [world_size, capacity] slab
+        self.slot = np.empty(len(cost), dtype=np.int64)
+        for r, s in enumerate(self.shards):
+            self.slot[s] = r * self.capacity + np.arange(len(s))
+
+    def scatter_index(self, starts_x, starts_y):
+        """Flat F-order destinations (and mirrored destinations) of the
+        gathered slab entries -- K(I1, I2) = gathered[slot]
+        (tensor_view column-major: graphdot/cpp/tensor_view.h:22-33)."""
+        a = starts_x[self.ji].astype(np.int64)
+        b = starts_y[self.jj].astype(np.int64)
+        dst = a + self.nX * b
+        if self.symmetric:
+            off = self.ji != self.jj
+            mdst = b[off] + self.nX * a[off]
+            return dst, self.slot, mdst, self.slot[off]
+        return dst, self.slot, None, None
+
+    def assemble(self, gathered, n_cols=1):
+        """Host reassembly of the gathered slabs into the (nX, nY[, n_cols])
+        matrix (graph-level outputs: starts are 0..n)."""
+        sx = np.arange(self.nX + 1)
+        sy = np.arange(self.nY + 1) if not self.symmetric else sx
+        jy = self.jj if self.symmetric else self.jj - self.nX
+        saved = self.jj
+        self.jj = jy
+        dst, src, mdst, msrc = self.scatter_index(sx, sy)
+        self.jj = saved
+        g = np.asarray(gathered).reshape(self.world_size * self.capacity,
+                                         n_cols)
+        out = np.zeros((self.nX * self.nY, n_cols), dtype=g.dtype)
+        out[dst] = g[src]
+        if mdst is not None:
+            out[mdst] = g[msrc]
+        out = out.reshape(self.nY, self.nX, n_cols).transpose(1, 0, 2)
+        return out[:, :, 0] if n_cols == 1 else out
