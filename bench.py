@@ -47,7 +47,7 @@ def algorithmic_bytes(arena, ji, jj, rsize, n_cols):
     """compulsory HBM bytes of a pair = both graph images (as
     packed in HBM) + the result."""
     blob = np.diff(np.concatenate((arena.blob_start, [arena.nbytes])))
-    hdr = 40
+    hdr = 56
     return (blob[ji] + blob[jj] + 2 * hdr + rsize * n_cols).astype(np.int64)
 
 
@@ -120,7 +120,8 @@ def main():
         if timed:
             events[0].record()
         for k, L in enumerate(plan.launches):
-            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'])
+            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                           dynamic_lds=L['dynamic_lds'])
             if timed:
                 events[k + 1].record()
         if world > 1:
@@ -178,7 +179,7 @@ def main():
     arena = plan.keep[0]
     dom = int(np.argmax(kernel_ms))
     L = plan.launches[dom]
-    ids = plan.order_host[L['offset']:L['offset'] + L['count']] & 0x1FFFFFFF
+    ids = plan.order_host[L['offset']:L['offset'] + L['count']]
     lj = local_jobs[ids]
     lji, ljj = lj['i'].astype(np.int64), lj['j'].astype(np.int64)
     iters = backend.iterations(plan)[ids].astype(np.int64)

@@ -11,17 +11,23 @@
 //
 //  * one wavefront (W = 1) or one workgroup of W wavefronts owns one pair;
 //  * the product-graph operator is *materialised once per pair in registers*:
-//    every lane keeps S (value, row, column) triples of off-diagonal nonzeros
-//    -- kappa_e(e1, e2) * w1 * w2 is evaluated once, not once per CG iteration
-//    (the reference re-evaluates the edge kernel for every nonzero in every
-//    iteration) -- plus the R rows of x, r, p and the Jacobi diagonal it owns;
-//  * the only per-iteration memory traffic is LDS: p is published to LDS, the
-//    mat-vec gathers p[col] with ds_read and scatters with ds_add_f32 into
-//    Ap[row]; there are no global-memory CG vectors and no global atomics;
-//  * 64 consecutive nonzero pairs form a ta x tb tile of (nonzeros of G1) x
-//    (nonzeros of G2); since the packer orders nonzeros so that neighbouring
-//    entries have distinct sources, the 64 scatter targets of one instruction
-//    are distinct rows (no same-address serialisation);
+//    kappa_e(e1, e2) * w1 * w2 is evaluated once per nonzero, not once per
+//    nonzero per CG iteration as the reference does, and kept with its gather
+//    address in S register slots per lane; each lane also keeps the R rows of
+//    x, r, p and the Jacobi diagonal it owns;
+//  * the only per-iteration memory traffic is LDS: p is published to LDS and
+//    the Kronecker mat-vec runs as two atomic-free stages
+//        U[a, i2]    = sum_{b in adj(i2)} E[a, b] p[j1(a), j2(b)]    (stage 1)
+//        (Wp)[i1,i2] = sum_{a in adj(i1)} U[a, i2]                    (stage 2)
+//    (a, b index directed nonzeros of G1, G2).  A lane owns whole tasks
+//    (a, i2) and whole rows (i1, i2), so sums accumulate in registers and
+//    are written once -- no ds_add_f32, whose throughput on gfx950 turned out
+//    to saturate the LDS pipe (profiles/r01_v1_atomic_scatter_pmc.csv);
+//  * nodes are renumbered by descending degree (packer), tasks/rows are dealt
+//    to lanes in that order, so the 64 tasks of one wave instruction have
+//    (nearly) the same trip count and the wave-uniform maximum is the trip
+//    count of its first task: padding is a few percent and *all control flow
+//    in the iteration is wave-uniform* (a 64-bit flush mask, scalar loops);
 //  * dot products are wave reductions (DPP + readlane), W > 1 adds one LDS
 //    exchange per reduction;
 //  * jobs are statically strided over the resident waves/workgroups in cost
@@ -61,7 +67,7 @@ struct job_t {
 template<class real, class Graph, class NodeK, class EdgeK, class PStart> struct params_t {
     Graph const *graphs;
     job_t const *jobs;
-    std::uint32_t const *order;  // job ids for this launch; top 3 bits = log2(tb)
+    std::uint32_t const *order;  // job ids of this launch, cost-descending
     std::uint32_t const *starts;
     real *gramian;
     real *gradient;
@@ -70,6 +76,7 @@ template<class real, class Graph, class NodeK, class EdgeK, class PStart> struct
     std::uint32_t nX, nY, nJ;
     std::uint32_t flags;
     std::uint32_t order_offset;  // slot of order[0] in the packed output
+    std::uint32_t u_capacity;    // tasks per pair slot in the dynamic LDS region
     real q, q0, eps, ftol, gtol;
     NodeK node_kernel;
     EdgeK edge_kernel;
@@ -115,52 +122,61 @@ template<class real> __device__ __forceinline__ void lds_add(real *p, real v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// S: off-diagonal nonzeros per lane, R: rows per lane, W: waves per pair,
-// C: right-hand sides (1 = value, 2 = value + analytic gradient).
+// S: register slots per lane for stage-1 nonzeros, R: rows per lane,
+// W: waves per pair, C: right-hand sides (1 = value, 2 = value + gradient).
 template<class real, int S, int R, int W, int C, class Graph, class NodeK, class EdgeK, class PStart>
 struct pair_solver {
     using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
     using node_t = typename Graph::node_t;
     using edge_t = typename Graph::edge_t;
     constexpr static int T = 64 * W;   // threads per pair
-    constexpr static int NV = R * T;   // vector capacity
+    constexpr static int NV = R * T;   // capacity of p (rows)
     constexpr static int WPB = (W == 1) ? 4 : 1;  // independent pairs per workgroup
     constexpr static int threads = 64 * W * WPB;
+    constexpr static int NM = (S + 63) / 64;      // 64-bit flush-mask words
     constexpr static int n_jac = PStart::jac_dims + 1 + NodeK::jac_dims + EdgeK::jac_dims;
     constexpr static int off_q = PStart::jac_dims;
     constexpr static int off_v = off_q + 1;
     constexpr static int off_e = off_v + NodeK::jac_dims;
 
+    // p and the reduction scratch are static LDS; U (one entry per stage-1
+    // task, at most u_capacity per pair) lives in the dynamic LDS region,
+    // sized per launch from the largest pair in it.
     struct lds_t {
         real p[WPB][NV * C];
-        real Ap[WPB][NV * C];
         real red[WPB][2 * W];
     };
 
-    __device__ static __forceinline__ void run(P const &prm, lds_t &lds) {
+    // wave-uniform integer (kept in an SGPR)
+    __device__ static __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+    __device__ static __forceinline__ void run(P const &prm, lds_t &lds, real *dyn) {
         const int lane = wave::laneid();
         const int slot = (W == 1) ? (threadIdx.x / 64) : 0;          // pair slot in workgroup
         const int tid = (W == 1) ? lane : (int)threadIdx.x;           // thread within pair
-        const int wv = (W == 1) ? 0 : (int)(threadIdx.x / 64);        // wave within pair
+        const int wv = (W == 1) ? 0 : uni((int)(threadIdx.x / 64));   // wave within pair
         real *const lp = lds.p[slot];
-        real *const lAp = lds.Ap[slot];
+        real *const lU = dyn + (size_t)slot * prm.u_capacity * C;
         real *const red = lds.red[slot];
 
         const unsigned n_units = gridDim.x * WPB;
         for (unsigned t = blockIdx.x * WPB + slot; t < prm.n_launch_jobs; t += n_units) {
-            const unsigned ord = prm.order[t];
-            const unsigned job_id = ord & 0x1FFFFFFFu;
-            const int sh = ord >> 29;  // log2(tb)
+            const unsigned job_id = prm.order[t];
             const job_t job = prm.jobs[job_id];
             const Graph g1 = prm.graphs[job.i];
             const Graph g2 = prm.graphs[job.j];
             const int n1 = g1.n_node, n2 = g2.n_node, N = n1 * n2;
+            const int nnz1 = g1.n_nz;
+            const int ntask = nnz1 * n2;       // stage-1 tasks (a, i2), i2-major
             const real q = prm.q, q0 = prm.q0;
             const real inv1q2 = real(1) / ((real(1) - q) * (real(1) - q));
             const real bscale = q * q / (q0 * q0);
 
-            // ---- rows owned by this thread: Jacobi diagonal, start vectors --
+            // ---- rows owned by this thread ------------------------------------
+            // row i = k*T + tid = (i1, i2); Jacobi diagonal, start vectors, and
+            // for stage 2 the first task index / trip count of the row.
             real dg[R], mi[R], x[C][R], r[C][R], p[C][R];
+            int ubase[R], udeg[R], D1[R];
             real rTz = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
@@ -172,6 +188,13 @@ struct pair_solver {
                 const real vx = prm.node_kernel(v1, v2);
                 dg[k] = ok ? dx / vx : real(0);
                 mi[k] = ok ? vx / dx : real(0);
+                const int rs = g1.rowptr[i1];
+                ubase[k] = i2 * nnz1 + rs;
+                udeg[k] = ok ? (int)g1.rowptr[i1 + 1] - rs : 0;
+                // rows of one wave are consecutive: the first has the largest degree
+                const int f = k * T + 64 * wv;
+                const int f1 = f < N ? f / n2 : 0;
+                D1[k] = f < N ? uni((int)g1.rowptr[f1 + 1] - (int)g1.rowptr[f1]) : 0;
                 const real b = ok ? dx * bscale : real(0);
                 x[0][k] = 0;
                 r[0][k] = b;
@@ -186,31 +209,66 @@ struct pair_solver {
                 }
             }
 
-            // ---- off-diagonal nonzeros owned by this thread ------------------
-            const int tb = 1 << sh, ta = 64 >> sh;
-            const int la = lane >> sh, lb = lane & (tb - 1);
-            const int nnz1 = g1.n_nz, nnz2 = g2.n_nz;
-            const int ntb = (nnz2 + tb - 1) >> sh;
-            const int nta = (nnz1 + ta - 1) / ta;
-            const int ntiles = nta * ntb;
+            // ---- stage-1 nonzeros owned by this thread ------------------------
+            // batch kb = tasks [kb*T, kb*T + T); this lane's task is kb*T + tid.
+            // All lanes of a wave walk D = deg2(first task of the wave) slots
+            // per batch; the slot after which a batch ends is marked in `fm`.
             real val[S];
-            unsigned rc[S];  // (row << 16) | col
+            unsigned adr[S];   // gather index into p (row-major product index)
+            unsigned long long fm[NM];
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const int tile = s * W + wv;
-                const int ti = tile / ntb, tj = tile - ti * ntb;
-                const int a = ti * ta + la, b = tj * tb + lb;
-                const bool ok = tile < ntiles && a < nnz1 && b < nnz2;
-                const int ac = ok ? a : 0, bc = ok ? b : 0;
-                const nz_t z1 = g1.nz[ac], z2 = g2.nz[bc];
-                const edge_t e1 = g1.edge[ac], e2 = g2.edge[bc];
-                const real e = prm.edge_kernel(e1, e2);
-                val[s] = ok ? e : real(0);
-                rc[s] = ok ? ((unsigned)(z1.i * n2 + z2.i) << 16) | (unsigned)(z1.j * n2 + z2.j) : 0u;
+            for (int w = 0; w < NM; ++w) fm[w] = 0;
+            int n_slots = 0;
+            {
+                int kb = 0, d = 0, D = 0;
+                bool okT = false;
+                int a = 0, rs2 = 0, deg = 0;
+                nz_t z1 = {0, 0};
+                edge_t e1 = g1.edge[0];
+                auto open_batch = [&]() {
+                    const int f = kb * T + 64 * wv;   // first task of this wave
+                    if (f < ntask) {
+                        const int fi2 = f / nnz1;
+                        D = uni((int)g2.rowptr[fi2 + 1] - (int)g2.rowptr[fi2]);
+                        D = D < 1 ? 1 : D;
+                    } else {
+                        D = 0;
+                    }
+                    const int tk = kb * T + tid;
+                    okT = tk < ntask;
+                    const int i2 = okT ? tk / nnz1 : 0;
+                    a = okT ? tk - i2 * nnz1 : 0;
+                    rs2 = g2.rowptr[i2];
+                    deg = okT ? (int)g2.rowptr[i2 + 1] - rs2 : 0;
+                    z1 = g1.nz[a];
+                    e1 = g1.edge[a];
+                    d = 0;
+                };
+                open_batch();
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    val[s] = 0;
+                    adr[s] = 0;
+                    if (D > 0) {   // wave-uniform
+                        const bool ok = okT && d < deg;
+                        const int b = ok ? rs2 + d : 0;
+                        const nz_t z2 = g2.nz[b];
+                        const edge_t e2 = g2.edge[b];
+                        const real e = prm.edge_kernel(e1, e2);
+                        val[s] = ok ? e : real(0);
+                        adr[s] = ok ? (unsigned)(z1.j * n2 + z2.j) : 0u;
+                        n_slots = s + 1;
+                        if (++d == D) {
+                            fm[s / 64] |= 1ull << (s % 64);
+                            ++kb;
+                            open_batch();
+                        }
+                    }
+                }
             }
 
             // ---- publish p ---------------------------------------------------
-            job_sync<W>();  // previous pair's readers of lp/lAp are done
+            job_sync<W>();  // previous pair's readers of lp/lU are done
 #pragma unroll
             for (int k = 0; k < R; ++k)
 #pragma unroll
@@ -220,33 +278,50 @@ struct pair_solver {
             const real tol = (C == 2) ? real(1e-10) * real(2 * N) : prm.ftol * real(N);
             unsigned it = 0;
             for (; it < (unsigned)N && rTz != real(0); ++it) {
-                // Ap = diag . p   (own rows)
+                job_sync<W>();   // p published
+                // stage 1: U[task] = sum_b E[a, b] p[j1(a), j2(b)]
+                {
+                    real acc[C];
 #pragma unroll
-                for (int k = 0; k < R; ++k)
+                    for (int c = 0; c < C; ++c) acc[c] = 0;
+                    int kb = 0;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) lAp[(k * T + tid) * C + c] = dg[k] * p[c][k];
-                job_sync<W>();
-                // Ap -= W . p     (register-resident nonzeros, LDS gather/scatter)
+                    for (int s = 0; s < S; ++s) {
+                        if (s < n_slots) {   // wave-uniform
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if (s * W + wv >= ntiles) break;  // wave-uniform: no work left
-                    if (val[s] != real(0)) {          // lanes past the tile edge
-                        const unsigned col = rc[s] & 0xFFFFu, row = rc[s] >> 16;
+                            for (int c = 0; c < C; ++c) acc[c] += val[s] * lp[adr[s] * C + c];
+                            if ((fm[s / 64] >> (s % 64)) & 1ull) {   // wave-uniform
 #pragma unroll
-                        for (int c = 0; c < C; ++c)
-                            lds_add(&lAp[row * C + c], -val[s] * lp[col * C + c]);
+                                for (int c = 0; c < C; ++c) {
+                                    lU[(kb * T + tid) * C + c] = acc[c];
+                                    acc[c] = 0;
+                                }
+                                ++kb;
+                            }
+                        }
                     }
                 }
                 job_sync<W>();
+                // stage 2: Ap = diag.p - sum_{a in adj(i1)} U[a, i2]
                 real Ap[C][R];
                 real pAp = 0;
 #pragma unroll
-                for (int k = 0; k < R; ++k)
+                for (int k = 0; k < R; ++k) {
+                    real acc[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] = 0;
+                    for (int d = 0; d < D1[k]; ++d) {   // wave-uniform trip count
+                        if (d < udeg[k]) {
+#pragma unroll
+                            for (int c = 0; c < C; ++c) acc[c] += lU[(ubase[k] + d) * C + c];
+                        }
+                    }
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
-                        Ap[c][k] = lAp[(k * T + tid) * C + c];
+                        Ap[c][k] = dg[k] * p[c][k] - acc[c];
                         pAp += p[c][k] * Ap[c][k];
                     }
+                }
                 pAp = block_reduce<real, W>::sum(pAp, red);
                 if (pAp == real(0)) break;
                 const real alpha = rTz / pAp;
@@ -276,8 +351,6 @@ struct pair_solver {
                         lp[(k * T + tid) * C + c] = p[c][k];
                     }
                 rTz = rTz_next;
-                // the p just published is read after the job_sync that follows
-                // the Ap = diag.p stores of the next iteration
             }
             if (prm.iters != nullptr && tid == 0) prm.iters[job_id] = it;
 
@@ -298,13 +371,15 @@ struct pair_solver {
                 const real rv = ok ? xi * pp : real(0);
                 ksum += rv;
                 if ((flags & F_NODAL) && ok) {
+                    // back to the caller's node numbering
+                    const unsigned o1 = g1.perm[i1], o2 = g2.perm[i2];
                     if (flags & F_BLOCK) {
-                        prm.gramian[I1 + i1 + i2 * n2] = rv;
+                        prm.gramian[I1 + o1 + o2 * n2] = rv;
                     } else if (flags & F_DIAGONAL) {
-                        if (i1 == i2) prm.gramian[I1 + i1] = rv;
+                        if (o1 == o2) prm.gramian[I1 + o1] = rv;
                     } else {
-                        prm.gramian[(size_t)(I1 + i1) + (size_t)prm.nX * (I2 + i2)] = rv;
-                        if (mirror) prm.gramian[(size_t)(I2 + i2) + (size_t)prm.nX * (I1 + i1)] = rv;
+                        prm.gramian[(size_t)(I1 + o1) + (size_t)prm.nX * (I2 + o2)] = rv;
+                        if (mirror) prm.gramian[(size_t)(I2 + o2) + (size_t)prm.nX * (I1 + o1)] = rv;
                     }
                 }
             }
@@ -359,19 +434,37 @@ struct pair_solver {
                 }
                 job_sync<W>();
                 if constexpr (EdgeK::jac_dims > 0) {
+                    // walk the stage-1 nonzeros again: row = (i1(a), i2), col = adr
+                    int kb = 0;
+                    auto task = [&](int kk, bool &okT, int &a, int &i2, int &rs2, int &deg) {
+                        const int tk = kk * T + tid;
+                        okT = tk < ntask;
+                        i2 = okT ? tk / nnz1 : 0;
+                        a = okT ? tk - i2 * nnz1 : 0;
+                        rs2 = g2.rowptr[i2];
+                        deg = okT ? (int)g2.rowptr[i2 + 1] - rs2 : 0;
+                    };
+                    bool okT;
+                    int a, i2, rs2, deg, d = 0;
+                    task(0, okT, a, i2, rs2, deg);
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        const int tile = s * W + wv;
-                        const int ti = tile / ntb, tj = tile - ti * ntb;
-                        const int a = ti * ta + la, b = tj * tb + lb;
-                        const bool ok = tile < ntiles && a < nnz1 && b < nnz2;
-                        const int ac = ok ? a : 0, bc = ok ? b : 0;
-                        const edge_t e1 = g1.edge[ac], e2 = g2.edge[bc];
-                        auto de = prm.edge_kernel._j_a_c_o_b_i_a_n_(e1, e2);
-                        const unsigned col = rc[s] & 0xFFFFu, row = rc[s] >> 16;
-                        const real w = ok ? lp[row * 2 + 1] * lp[col * 2 + 0] : real(0);
+                        if (s < n_slots) {   // wave-uniform
+                            const bool ok = okT && d < deg;
+                            const int b = ok ? rs2 + d : 0;
+                            const edge_t e1 = g1.edge[a], e2 = g2.edge[b];
+                            auto de = prm.edge_kernel._j_a_c_o_b_i_a_n_(e1, e2);
+                            const int row = g1.nz[a].i * n2 + i2;
+                            const real w = ok ? lp[row * 2 + 1] * lp[adr[s] * 2 + 0] : real(0);
 #pragma unroll
-                        for (int j = 0; j < EdgeK::jac_dims; ++j) jac[off_e + j] += w * real(de[j]);
+                            for (int j = 0; j < EdgeK::jac_dims; ++j) jac[off_e + j] += w * real(de[j]);
+                            ++d;
+                            if ((fm[s / 64] >> (s % 64)) & 1ull) {   // wave-uniform
+                                ++kb;
+                                d = 0;
+                                task(kb, okT, a, i2, rs2, deg);
+                            }
+                        }
                     }
                 }
 #pragma unroll

@@ -158,6 +158,13 @@ int gd_function_attributes(gd_function_t f, int *static_lds_bytes,
     return 0;
 }
 
+int gd_function_set_max_dynamic_lds(gd_function_t f, int bytes) {
+    if (!f) return fail("gd_function_set_max_dynamic_lds: null function");
+    GD_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(f),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return 0;
+}
+
 int gd_launch(gd_function_t f, uint32_t grid_x, uint32_t block_x,
               uint32_t dynamic_lds_bytes, gd_stream_t s, const void *args,
               size_t args_bytes) {

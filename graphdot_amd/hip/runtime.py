@@ -54,6 +54,7 @@ SIGNATURES = {
     'gd_module_get_global': [_vp, ctypes.c_char_p, _P(_vp), _P(_sz)],
     'gd_function_attributes': [_vp, _P(ctypes.c_int), _P(ctypes.c_int),
                                _P(ctypes.c_int)],
+    'gd_function_set_max_dynamic_lds': [_vp, ctypes.c_int],
     'gd_launch': [_vp, _u32, _u32, _u32, _vp, _vp, _sz],
     'gd_stream_create': [_P(_vp)],
     'gd_stream_destroy': [_vp],
@@ -233,6 +234,13 @@ def launch(function, grid, block, args: bytes, stream=None, dynamic_lds=0):
     buf = ctypes.create_string_buffer(args, len(args))
     check(lib().gd_launch(function, grid, block, dynamic_lds, stream, buf,
                           len(args)))
+
+
+def set_max_dynamic_lds(function, nbytes):
+    """Best effort: module-loaded kernels on ROCm accept large dynamic LDS
+    requests directly; a refusal here is not fatal (the launch itself reports
+    an over-size request)."""
+    return lib().gd_function_set_max_dynamic_lds(function, int(nbytes)) == 0
 
 
 def synchronize(stream=None):

@@ -33,7 +33,7 @@ F_NODAL, F_DIAGONAL, F_SYMMETRIC, F_LMIN1, F_BLOCK, F_PACKED = \
 Variant = namedtuple('Variant', 'W S R')
 
 #: register-resident solver menu, cheapest first.  A pair fits a variant if
-#: its best 64-lane tiling needs <= S*W tiles and N = n1*n2 <= 64*W*R.
+#: its stage-1 walk needs <= S slots per lane and N = n1*n2 <= 64*W*R.
 VARIANTS = [
     Variant(1, 8, 2), Variant(1, 16, 4), Variant(1, 24, 6),
     Variant(1, 32, 9), Variant(1, 48, 9), Variant(1, 64, 16),
@@ -322,7 +322,7 @@ struct ${name}_t : ${name}_theta_t {
             ('gramian', P), ('gradient', P), ('iters', P),
             ('n_launch_jobs', np.uint32), ('nX', np.uint32),
             ('nY', np.uint32), ('nJ', np.uint32), ('flags', np.uint32),
-            ('order_offset', np.uint32),
+            ('order_offset', np.uint32), ('u_capacity', np.uint32),
             ('q', self.real), ('q0', self.real), ('eps', self.real),
             ('ftol', self.real), ('gtol', self.real),
             ('node_kernel', theta(node_kernel)),
@@ -342,7 +342,8 @@ void ${name}(params_t prm) {
     using solver = graphdot::mgk::pair_solver<real_t, ${S}, ${R}, ${W}, ${C},
         graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
     __shared__ typename solver::lds_t lds;
-    solver::run(prm, lds);
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    solver::run(prm, lds, reinterpret_cast<real_t *>(dyn_lds));
 }
 ''').render(threads=threads, name=self.kernel_name(v, C), S=v.S, R=v.R,
             W=v.W, C=C)
@@ -375,37 +376,77 @@ void ${name}(params_t prm) {
         return mod
 
     # -- job partitioning ---------------------------------------------------------
-    def lds_bytes(self, v, C):
+    def lds_bytes(self, v, C, ntask=0):
+        """LDS bytes of one workgroup: static p + scratch, dynamic U."""
         wpb = 4 if v.W == 1 else 1
-        nv = v.R * 64 * v.W
-        return (wpb * 2 * nv * C + wpb * 2 * v.W) * np.dtype(self.real).itemsize
+        T = 64 * v.W
+        ucap = -(-np.asarray(ntask) // 64) * 64
+        return ((v.R * T + ucap) * C * wpb + wpb * 2 * v.W) \
+            * np.dtype(self.real).itemsize
 
-    def classify(self, ji, jj, n_node, n_nz, C):
-        """Assign every job the cheapest variant it fits and its tile shape.
+    @staticmethod
+    def slots_needed(nnz1, n2, jj, deg_sorted, W):
+        """Register slots per lane that the stage-1 walk of mgk_solver.h takes
+        for each job: tasks (a, i2) are dealt i2-major in batches of T = 64 W,
+        and wave w of batch k walks max(1, deg2(i2 of its first task)) slots.
+        Returns the maximum over the W waves."""
+        T = 64 * W
+        ntask = nnz1 * n2
+        worst = np.zeros(len(nnz1), dtype=np.int64)
+        nb = int(-(-ntask.max() // T)) if len(ntask) else 0
+        for w in range(W):
+            total = np.zeros(len(nnz1), dtype=np.int64)
+            for k in range(nb):
+                first = k * T + 64 * w
+                live = first < ntask
+                if not live.any():
+                    break
+                i2 = np.where(live, first // np.maximum(nnz1, 1), 0)
+                d = np.maximum(deg_sorted[jj, i2], 1)
+                total += np.where(live, d, 0)
+            worst = np.maximum(worst, total)
+        return worst
 
-        Returns (variant_index[n_jobs], log2_tb[n_jobs], tiles[n_jobs])."""
+    def classify(self, ji, jj, dgraphs, C):
+        """Assign every job the cheapest solver variant it fits.
+        Returns (variant_index[n_jobs], cost[n_jobs])."""
+        n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
+        n_nz = np.array([g.n_nz for g in dgraphs], dtype=np.int64)
+        width = int(n_node.max())
+        deg_sorted = np.zeros((len(dgraphs), width), dtype=np.int64)
+        for k, g in enumerate(dgraphs):
+            deg_sorted[k, :g.n_node] = g.adjacency_count
         n1, n2 = n_node[ji], n_node[jj]
-        z1, z2 = n_nz[ji], n_nz[jj]
+        nnz1 = n_nz[ji]
         N = n1 * n2
-        sh = np.arange(7)[:, None]
-        tiles_all = (-(-z1[None, :] // (64 >> sh))) * (-(-z2[None, :] // (1 << sh)))
-        best = np.argmin(tiles_all, axis=0)
-        tiles = tiles_all[best, np.arange(len(ji))]
+        cost = n_nz[ji] * n_nz[jj] + 4 * N
         choice = np.full(len(ji), -1, dtype=np.int64)
+        slots = {}
+        ntask = nnz1 * n2
         for k, v in enumerate(self.variants):
-            if self.lds_bytes(v, C) > LDS_LIMIT:
+            todo = choice < 0
+            if not todo.any():
+                break
+            fits = (todo & (N <= 64 * v.W * v.R) & (N <= 0xFFFF)
+                    & (self.lds_bytes(v, C, ntask) <= LDS_LIMIT))
+            if not fits.any():
                 continue
-            fits = ((choice < 0) & (tiles <= v.S * v.W)
-                    & (N <= 64 * v.W * v.R) & (N <= 0xFFFF))
+            if v.W not in slots:
+                idx = np.flatnonzero(todo)
+                sl = np.full(len(ji), np.iinfo(np.int64).max, dtype=np.int64)
+                sl[idx] = self.slots_needed(nnz1[idx], n2[idx], jj[idx],
+                                            deg_sorted, v.W)
+                slots[v.W] = sl
+            fits &= slots[v.W] <= v.S
             choice[fits] = k
         if np.any(choice < 0):
             bad = int(np.argmax(choice < 0))
             raise NotImplementedError(
                 f'graph pair ({ji[bad]}, {jj[bad]}) with {n1[bad]}x{n2[bad]} '
-                f'nodes and {z1[bad]}x{z2[bad]} adjacency nonzeros exceeds '
-                'the largest register-resident solver variant; the '
+                f'nodes and {nnz1[bad]}x{n_nz[jj[bad]]} adjacency nonzeros '
+                'exceeds the largest register-resident solver variant; the '
                 'global-memory fallback is not built yet')
-        return choice, best, tiles
+        return choice, cost, ntask
 
     # -- the three phases -----------------------------------------------------------
     def _frontend(self, graphs, node_kernel, edge_kernel, p, jobs, traits,
@@ -435,16 +476,14 @@ void ${name}(params_t prm) {
         jobs = np.ascontiguousarray(jobs)
         ji = jobs['i'].astype(np.int64)
         jj = jobs['j'].astype(np.int64)
-        n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
-        n_nz = np.array([g.n_nz for g in dgraphs], dtype=np.int64)
-        choice, shape, tiles = self.classify(ji, jj, n_node, n_nz, C)
+        choice, cost, ntask = self.classify(ji, jj, dgraphs, C)
         used = sorted(set(choice.tolist()))
         sources = {k: self.render_source(node_kernel, edge_kernel, p,
                                          dgraphs[0].node_t, dgraphs[0].edge_t,
                                          [self.variants[k]], C)
                    for k in used}
         toc('code generation')
-        return dgraphs, edge_kernel, jobs, C, choice, shape, tiles, used, \
+        return dgraphs, edge_kernel, jobs, C, choice, cost, ntask, used, \
             sources
 
     def precompile(self, graphs, node_kernel, edge_kernel, p, jobs, traits):
@@ -461,7 +500,7 @@ void ${name}(params_t prm) {
         tic = timer.tic if timer else (lambda *_: None)
         toc = timer.toc if timer else (lambda *_: None)
         runtime.ensure_device(self.device)
-        (dgraphs, edge_kernel, jobs, C, choice, shape, tiles, used,
+        (dgraphs, edge_kernel, jobs, C, choice, cost, ntask, used,
          sources) = self._frontend(graphs, node_kernel, edge_kernel, p, jobs,
                                    traits, timer)
         arena, arena_buf, _ = self._arena(dgraphs)
@@ -503,18 +542,23 @@ void ${name}(params_t prm) {
         for k in used:
             v = self.variants[k]
             idx = np.flatnonzero(choice == k)
-            idx = idx[np.argsort(-tiles[idx], kind='stable')]
-            order_all[cursor:cursor + len(idx)] = (
-                idx.astype(np.uint32) | (shape[idx].astype(np.uint32) << 29))
+            idx = idx[np.argsort(-cost[idx], kind='stable')]
+            order_all[cursor:cursor + len(idx)] = idx.astype(np.uint32)
             wpb = 4 if v.W == 1 else 1
             threads = 64 * v.W * wpb
             bpc = self.blocks_per_cu if v.W <= 4 else max(
                 1, self.blocks_per_cu // 4)
             grid = int(min(-(-len(idx) // wpb),
                            self.props.compute_units * bpc))
-            launches.append(dict(variant=v, k=k, offset=cursor,
+            ucap = int(-(-ntask[idx].max() // 64) * 64)
+            dyn = ucap * C * wpb * rsize
+            fn = modules[k].function(self.kernel_name(v, C))
+            if dyn > 64 * 1024:
+                runtime.set_max_dynamic_lds(fn, dyn)
+            launches.append(dict(variant=v, k=k, offset=cursor, ucap=ucap,
+                                 dynamic_lds=dyn,
                                  count=len(idx), grid=grid, threads=threads,
-                                 fn=modules[k].function(self.kernel_name(v, C)),
+                                 fn=fn,
                                  module=modules[k]))
             cursor += len(idx)
         plan.order_host = order_all
@@ -559,6 +603,7 @@ void ${name}(params_t prm) {
             a['order'] = b_order.ptr + 4 * L['offset']
             a['n_launch_jobs'] = L['count']
             a['order_offset'] = L['offset']
+            a['u_capacity'] = L['ucap']
             L['args'] = a.tobytes()
         plan.params_dtype = pd
         toc('calculating launch configuration')
@@ -569,7 +614,7 @@ void ${name}(params_t prm) {
         """Enqueue every solver launch of `plan` (asynchronous)."""
         for L in plan.launches:
             runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                           stream=stream)
+                           stream=stream, dynamic_lds=L['dynamic_lds'])
 
     def collect(self, plan, gramian=None, gradient=None):
         """Copy results back.  With a packed plan the per-job values come
@@ -583,7 +628,7 @@ void ${name}(params_t prm) {
             grad = np.empty(plan.n_grad, dtype=rs)
             plan.buffers['gradient'].download(grad)
         if plan.packed:
-            ids = plan.order_host & np.uint32(0x1FFFFFFF)
+            ids = plan.order_host
             unsorted = np.empty_like(out)
             unsorted[ids] = out
             out = unsorted

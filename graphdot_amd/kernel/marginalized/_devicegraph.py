@@ -12,8 +12,12 @@ why and for the ordering rule).
 
 Each graph packs into one relocatable byte blob::
 
-    [degree f32[n]] [nodes node_t[n]] [nz u16x2[nnz]] [edges edge_t[nnz]]
-    [variable-length attribute payloads ...]
+    [degree f32[n]] [nodes node_t[n]] [rowptr u16[n+1]] [nz u16x2[nnz]]
+    [edges edge_t[nnz]] [perm u16[n]] [variable-length attribute payloads ...]
+
+Nodes are renumbered by descending adjacency count (``perm[new] = original
+id``); the directed nonzeros are stored in CSR order of the new numbering.
+The solver's degree-batched mat-vec relies on that order (mgk_solver.h).
 
 with every section 16-byte aligned; pointers inside the blob (frozen_array
 views) are stored as blob-relative offsets plus a relocation list, so blobs of
@@ -29,8 +33,10 @@ _ALIGN = 16
 #: device-side header, mirrors graphdot::graph_t (40 bytes)
 HEADER_DTYPE = np.dtype([
     ('n_node', np.int32), ('n_nz', np.int32), ('degree', np.uintp),
-    ('node', np.uintp), ('nz', np.uintp), ('edge', np.uintp)], align=True)
-assert HEADER_DTYPE.itemsize == 40
+    ('node', np.uintp), ('rowptr', np.uintp), ('nz', np.uintp),
+    ('edge', np.uintp), ('perm', np.uintp)], align=True)
+assert HEADER_DTYPE.itemsize == 56
+SECTIONS = ('degree', 'node', 'rowptr', 'nz', 'edge', 'perm')
 
 NZ_DTYPE = np.dtype([('i', np.uint16), ('j', np.uint16)])
 
@@ -74,8 +80,9 @@ class DeviceGraph:
     node_t, edge_t: numpy aligned struct dtypes (the C++ node/edge types)
     weighted: bool
     n_node, n_nz: int
-    degree: float32[n_node]
-    nz: (i, j) uint16 pairs of the directed nonzeros, in device order
+    perm: uint16[n_node], perm[new id] = original node id
+    degree: float32[n_node] (new numbering)
+    rowptr, nz: CSR of the directed nonzeros (new numbering)
     blob: uint8 array, relocatable image
     offsets: dict section -> byte offset in blob
     relocs: byte offsets (in blob) of uint64 words that hold blob-relative
@@ -133,15 +140,9 @@ class DeviceGraph:
         if len(edges.columns) == 2:     # only !i, !j: unweighted, unlabeled
             edges['labeled'] = np.zeros(len(edges), np.bool_)
 
-        # ---- nodes: AoS indexed by node id ---------------------------------
+        # ---- directed nonzeros, degrees --------------------------------------
         idx = np.asarray(nodes['!i']).astype(np.int64)
         nodes.drop(['!i'], inplace=True)
-        self.node_t = node_t = _widen(nodes.rowtype(), real)
-        nodes_aos = np.zeros(n, dtype=node_t)
-        node_fa = []          # (row, field, FrozenArray)
-        self._fill(nodes_aos, idx, nodes, node_t, node_fa)
-
-        # ---- directed nonzeros, degrees --------------------------------------
         ei = np.asarray(edges['!i']).astype(np.int64)
         ej = np.asarray(edges['!j']).astype(np.int64)
         m = len(ei)
@@ -154,8 +155,41 @@ class DeviceGraph:
         loops = ei == ej
         np.subtract.at(degree, ei[loops], w[loops])
         degree[degree == 0] = 1.0
-        self.degree = degree
 
+        # both orientations; duplicates (self loops, repeated edges) collapse
+        # onto their first occurrence like the reference's np.unique
+        src = np.concatenate((ei, ej))
+        dst = np.concatenate((ej, ei))
+        eid = np.concatenate((np.arange(m), np.arange(m)))
+        _, first = np.unique(src * n + dst, return_index=True)
+        src, dst, eid = src[first], dst[first], eid[first]
+
+        # renumber nodes by descending adjacency count (stable)
+        count = np.bincount(src, minlength=n)
+        perm = np.argsort(-count, kind='stable')        # new -> original
+        rank = np.empty(n, dtype=np.int64)
+        rank[perm] = np.arange(n)                       # original -> new
+        self.perm = perm.astype(np.uint16)
+        self.rank = rank
+        self.degree = degree = degree[perm]
+        self.adjacency_count = count[perm]
+        src, dst = rank[src], rank[dst]
+        order = np.lexsort((dst, src))                  # CSR order
+        src, dst, eid = src[order], dst[order], eid[order]
+        self.n_nz = nnz = len(src)
+        self.nz = np.zeros(nnz, dtype=NZ_DTYPE)
+        self.nz['i'], self.nz['j'] = src, dst
+        self.rowptr = np.concatenate(
+            ([0], np.cumsum(count[perm]))).astype(np.uint16)
+        self.edge_index = eid
+
+        # ---- nodes: AoS indexed by the *new* node id ---------------------------
+        self.node_t = node_t = _widen(nodes.rowtype(), real)
+        nodes_aos = np.zeros(n, dtype=node_t)
+        node_fa = []          # (row, field, FrozenArray)
+        self._fill(nodes_aos, rank[idx], nodes, node_t, node_fa)
+
+        # ---- edges ---------------------------------------------------------------
         label_df = edges.drop(['!i', '!j', '!w'])
         label_t = _widen(label_df.rowtype(), real)
         if self.weighted:
@@ -164,28 +198,6 @@ class DeviceGraph:
         else:
             edge_t = label_t
         self.edge_t = edge_t
-
-        # both orientations; duplicates (self loops, repeated edges) collapse
-        # onto their first occurrence like the reference's np.unique
-        src = np.concatenate((ei, ej))
-        dst = np.concatenate((ej, ei))
-        eid = np.concatenate((np.arange(m), np.arange(m)))
-        key = src * n + dst
-        _, first = np.unique(key, return_index=True)
-        src, dst, eid = src[first], dst[first], eid[first]
-        # device order: rank within the source row first, then source -- so
-        # neighbouring entries have distinct sources (graph.h)
-        by_row = np.lexsort((dst, src))
-        src, dst, eid = src[by_row], dst[by_row], eid[by_row]
-        row_start = np.searchsorted(src, src, side='left')
-        rank = np.arange(len(src)) - row_start
-        order = np.lexsort((src, rank))
-        src, dst, eid = src[order], dst[order], eid[order]
-        self.n_nz = nnz = len(src)
-        self.nz = np.zeros(nnz, dtype=NZ_DTYPE)
-        self.nz['i'], self.nz['j'] = src, dst
-        self.edge_index = eid
-
         edges_aos = np.zeros(nnz, dtype=edge_t)
         edge_fa = []
         target = edges_aos['label'] if self.weighted and label_t.itemsize \
@@ -202,7 +214,8 @@ class DeviceGraph:
         # ---- blob ---------------------------------------------------------------
         sections, cursor = {}, 0
         for name, arr in (('degree', degree), ('node', nodes_aos),
-                          ('nz', self.nz), ('edge', edges_aos)):
+                          ('rowptr', self.rowptr), ('nz', self.nz),
+                          ('edge', edges_aos), ('perm', self.perm)):
             sections[name] = (cursor, arr)
             cursor += _pad(arr.nbytes)
         payload_off = []
@@ -277,7 +290,7 @@ class GraphArena:
             self.host[s:s + len(g.blob)] = g.blob
             hdr['n_node'][k] = g.n_node
             hdr['n_nz'][k] = g.n_nz
-            for name in ('degree', 'node', 'nz', 'edge'):
+            for name in SECTIONS:
                 hdr[name][k] = s + g.offsets[name]   # arena-relative for now
             if len(g.relocs):
                 self._relocs.append(g.relocs + s)
@@ -295,7 +308,7 @@ class GraphArena:
         """Byte image with every pointer rebased onto device address `base`."""
         img = self.host.copy()
         hdr = self._hdr.copy()
-        for name in ('degree', 'node', 'nz', 'edge'):
+        for name in SECTIONS:
             hdr[name] += np.uintp(base)
         img[:hdr.nbytes] = hdr.view(np.uint8)
         for where in self._relocs:

@@ -73,6 +73,10 @@ int gd_module_get_global(gd_module_t m, const char *name, void **dptr, size_t *b
 int gd_function_attributes(gd_function_t f, int *static_lds_bytes,
                            int *max_threads_per_block, int *num_regs);
 
+/* opt a kernel in to more than the default dynamic-LDS limit (gfx950 has
+ * 160 KiB per workgroup); needed before gd_launch with a larger request */
+int gd_function_set_max_dynamic_lds(gd_function_t f, int bytes);
+
 /* ---- launch (ref: kernel(..., grid=, block=, shared=), _backend_cuda.py:346-366).
  * `args` is the kernel-argument buffer laid out exactly as the kernel's
  * parameter list (natural alignment); it is copied before the call returns. */
