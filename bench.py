@@ -47,7 +47,7 @@ def algorithmic_bytes(arena, ji, jj, rsize, n_cols):
     """compulsory HBM bytes of a pair = both graph images (as
     packed in HBM) + the result."""
     blob = np.diff(np.concatenate((arena.blob_start, [arena.nbytes])))
-    hdr = 56
+    hdr = 32
     return (blob[ji] + blob[jj] + 2 * hdr + rsize * n_cols).astype(np.int64)
 
 

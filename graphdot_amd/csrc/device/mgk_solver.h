@@ -65,7 +65,7 @@ struct job_t {
 // travel here (SGPR-resident kernargs) instead of __constant__ symbols
 // (reference: _backend_cuda.py:318-340).
 template<class real, class Graph, class NodeK, class EdgeK, class PStart> struct params_t {
-    Graph const *graphs;
+    char const *arena;           // base of the graph arena (headers first)
     job_t const *jobs;
     std::uint32_t const *order;  // job ids of this launch, cost-descending
     std::uint32_t const *starts;
@@ -122,6 +122,32 @@ template<class real> __device__ __forceinline__ void lds_add(real *p, real v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Walks (hi, lo) = divmod(index, n) for index = start, start + step, ...
+// without a division per step.
+struct divmod_walk {
+    int hi, lo, qs, rs, n;
+    __device__ __forceinline__ divmod_walk(int start, int step, int n_) : n(n_) {
+        // start, step < 2^22: float reciprocal + fix-up is exact
+        const float inv = 1.0f / (float)n;
+        hi = (int)((float)start * inv);
+        hi -= (hi * n > start);
+        hi += ((hi + 1) * n <= start);
+        lo = start - hi * n;
+        qs = (int)((float)step * inv);
+        qs -= (qs * n > step);
+        qs += ((qs + 1) * n <= step);
+        rs = step - qs * n;
+    }
+    __device__ __forceinline__ void next() {
+        hi += qs;
+        lo += rs;
+        if (lo >= n) {
+            lo -= n;
+            ++hi;
+        }
+    }
+};
+
 // S: register slots per lane for stage-1 nonzeros, R: rows per lane,
 // W: waves per pair, C: right-hand sides (1 = value, 2 = value + gradient).
 template<class real, int S, int R, int W, int C, class Graph, class NodeK, class EdgeK, class PStart>
@@ -134,6 +160,8 @@ struct pair_solver {
     constexpr static int WPB = (W == 1) ? 4 : 1;  // independent pairs per workgroup
     constexpr static int threads = 64 * W * WPB;
     constexpr static int NM = (S + 63) / 64;      // 64-bit flush-mask words
+    constexpr static int SETUP_CHUNK = 4;
+    constexpr static int GCH = 8;                 // stage-1 gathers in flight
     constexpr static int n_jac = PStart::jac_dims + 1 + NodeK::jac_dims + EdgeK::jac_dims;
     constexpr static int off_q = PStart::jac_dims;
     constexpr static int off_v = off_q + 1;
@@ -150,21 +178,28 @@ struct pair_solver {
     // wave-uniform integer (kept in an SGPR)
     __device__ static __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+    // stage-1 task of lane `tid` in batch kb: task index kb*T + tid = i2*nnz1 + a
+    struct task_t {
+        bool ok;
+        int a, i2, rs2, deg;
+    };
+
     __device__ static __forceinline__ void run(P const &prm, lds_t &lds, real *dyn) {
         const int lane = wave::laneid();
-        const int slot = (W == 1) ? (threadIdx.x / 64) : 0;          // pair slot in workgroup
-        const int tid = (W == 1) ? lane : (int)threadIdx.x;           // thread within pair
-        const int wv = (W == 1) ? 0 : uni((int)(threadIdx.x / 64));   // wave within pair
+        const int slot = (W == 1) ? uni((int)(threadIdx.x / 64)) : 0;  // pair slot in workgroup
+        const int tid = (W == 1) ? lane : (int)threadIdx.x;             // thread within pair
+        const int wv = (W == 1) ? 0 : uni((int)(threadIdx.x / 64));     // wave within pair
         real *const lp = lds.p[slot];
         real *const lU = dyn + (size_t)slot * prm.u_capacity * C;
         real *const red = lds.red[slot];
+        graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
 
         const unsigned n_units = gridDim.x * WPB;
         for (unsigned t = blockIdx.x * WPB + slot; t < prm.n_launch_jobs; t += n_units) {
             const unsigned job_id = prm.order[t];
             const job_t job = prm.jobs[job_id];
-            const Graph g1 = prm.graphs[job.i];
-            const Graph g2 = prm.graphs[job.j];
+            const Graph g1(prm.arena, headers[job.i]);
+            const Graph g2(prm.arena, headers[job.j]);
             const int n1 = g1.n_node, n2 = g2.n_node, N = n1 * n2;
             const int nnz1 = g1.n_nz;
             const int ntask = nnz1 * n2;       // stage-1 tasks (a, i2), i2-major
@@ -172,40 +207,56 @@ struct pair_solver {
             const real inv1q2 = real(1) / ((real(1) - q) * (real(1) - q));
             const real bscale = q * q / (q0 * q0);
 
+            // ---- stage the CSR row pointers of both graphs in LDS (as ints) ----
+            // lrp1[0..n1], lrp2[0..n2] live at the head of the U region, which
+            // is idle until the first mat-vec.
+            int *const lrp1 = reinterpret_cast<int *>(lU);
+            int *const lrp2 = lrp1 + n1 + 1;
+            job_sync<W>();  // previous pair is done with lU
+#pragma nounroll
+            for (int i = tid; i <= n1; i += T) lrp1[i] = g1.rowptr[i];
+#pragma nounroll
+            for (int i = tid; i <= n2; i += T) lrp2[i] = g2.rowptr[i];
+            job_sync<W>();
+
             // ---- rows owned by this thread ------------------------------------
             // row i = k*T + tid = (i1, i2); Jacobi diagonal, start vectors, and
             // for stage 2 the first task index / trip count of the row.
             real dg[R], mi[R], x[C][R], r[C][R], p[C][R];
             int ubase[R], udeg[R], D1[R];
             real rTz = 0;
+            {
+                divmod_walk row(tid, T, n2);         // per lane
+                divmod_walk first(64 * wv, T, n2);   // first row of this wave (uniform)
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const int i = k * T + tid;
-                const bool ok = i < N;
-                const int i1 = ok ? i / n2 : 0, i2 = ok ? i - (i / n2) * n2 : 0;
-                const node_t v1 = g1.node[i1], v2 = g2.node[i2];
-                const real dx = real(g1.degree[i1]) * real(g2.degree[i2]) * inv1q2;
-                const real vx = prm.node_kernel(v1, v2);
-                dg[k] = ok ? dx / vx : real(0);
-                mi[k] = ok ? vx / dx : real(0);
-                const int rs = g1.rowptr[i1];
-                ubase[k] = i2 * nnz1 + rs;
-                udeg[k] = ok ? (int)g1.rowptr[i1 + 1] - rs : 0;
-                // rows of one wave are consecutive: the first has the largest degree
-                const int f = k * T + 64 * wv;
-                const int f1 = f < N ? f / n2 : 0;
-                D1[k] = f < N ? uni((int)g1.rowptr[f1 + 1] - (int)g1.rowptr[f1]) : 0;
-                const real b = ok ? dx * bscale : real(0);
-                x[0][k] = 0;
-                r[0][k] = b;
-                p[0][k] = b * mi[k];
-                rTz += r[0][k] * p[0][k];
-                if constexpr (C == 2) {
-                    const real bx = ok ? real(prm.p_start(v1)) * real(prm.p_start(v2)) : real(0);
-                    x[1][k] = 0;
-                    r[1][k] = bx;
-                    p[1][k] = bx * mi[k];
-                    rTz += r[1][k] * p[1][k];
+                for (int k = 0; k < R; ++k) {
+                    const bool ok = k * T + tid < N;
+                    const int i1 = ok ? row.hi : 0, i2 = ok ? row.lo : 0;
+                    const node_t v1 = g1.node[i1], v2 = g2.node[i2];
+                    const real dx = real(g1.degree[i1]) * real(g2.degree[i2]) * inv1q2;
+                    const real vx = prm.node_kernel(v1, v2);
+                    dg[k] = ok ? dx / vx : real(0);
+                    mi[k] = ok ? vx / dx : real(0);
+                    const int rs = lrp1[i1];
+                    ubase[k] = i2 * nnz1 + rs;
+                    udeg[k] = ok ? lrp1[i1 + 1] - rs : 0;
+                    // rows of one wave are consecutive: the first has the largest degree
+                    const int f1 = uni(first.hi);
+                    D1[k] = (k * T + 64 * wv < N) ? uni(lrp1[f1 + 1] - lrp1[f1]) : 0;
+                    const real b = ok ? dx * bscale : real(0);
+                    x[0][k] = 0;
+                    r[0][k] = b;
+                    p[0][k] = b * mi[k];
+                    rTz += r[0][k] * p[0][k];
+                    if constexpr (C == 2) {
+                        const real bx = ok ? real(prm.p_start(v1)) * real(prm.p_start(v2)) : real(0);
+                        x[1][k] = 0;
+                        r[1][k] = bx;
+                        p[1][k] = bx * mi[k];
+                        rTz += r[1][k] * p[1][k];
+                    }
+                    row.next();
+                    first.next();
                 }
             }
 
@@ -213,62 +264,80 @@ struct pair_solver {
             // batch kb = tasks [kb*T, kb*T + T); this lane's task is kb*T + tid.
             // All lanes of a wave walk D = deg2(first task of the wave) slots
             // per batch; the slot after which a batch ends is marked in `fm`.
+            // Pass 1 (index walk, needs only the CSR row pointers of G2 which
+            // were staged in LDS) records per slot the nonzero pair (a, b);
+            // pass 2 then issues all label loads back to back and evaluates
+            // the edge kernel.
             real val[S];
-            unsigned adr[S];   // gather index into p (row-major product index)
+            unsigned adr[S];       // pass 1 scratch: (a << 16) | b, or ~0u
+            unsigned adr2[(S + 1) / 2];  // gather indices into p, two 16-bit per register
             unsigned long long fm[NM];
 #pragma unroll
             for (int w = 0; w < NM; ++w) fm[w] = 0;
             int n_slots = 0;
             {
-                int kb = 0, d = 0, D = 0;
-                bool okT = false;
-                int a = 0, rs2 = 0, deg = 0;
-                nz_t z1 = {0, 0};
-                edge_t e1 = g1.edge[0];
-                auto open_batch = [&]() {
-                    const int f = kb * T + 64 * wv;   // first task of this wave
-                    if (f < ntask) {
-                        const int fi2 = f / nnz1;
-                        D = uni((int)g2.rowptr[fi2 + 1] - (int)g2.rowptr[fi2]);
-                        D = D < 1 ? 1 : D;
-                    } else {
-                        D = 0;
-                    }
-                    const int tk = kb * T + tid;
-                    okT = tk < ntask;
-                    const int i2 = okT ? tk / nnz1 : 0;
-                    a = okT ? tk - i2 * nnz1 : 0;
-                    rs2 = g2.rowptr[i2];
-                    deg = okT ? (int)g2.rowptr[i2 + 1] - rs2 : 0;
-                    z1 = g1.nz[a];
-                    e1 = g1.edge[a];
-                    d = 0;
+                divmod_walk tk(tid, T, nnz1);          // per lane: (i2, a)
+                divmod_walk tf(64 * wv, T, nnz1);      // first task of the wave (uniform)
+                int kb = 0;
+                auto batch_depth = [&]() -> int {
+                    if (kb * T + 64 * wv >= ntask) return 0;
+                    const int fi2 = uni(tf.hi);
+                    const int D = uni(lrp2[fi2 + 1] - lrp2[fi2]);
+                    return D < 1 ? 1 : D;
                 };
-                open_batch();
+                auto open_task = [&]() -> task_t {
+                    task_t k;
+                    k.ok = kb * T + tid < ntask;
+                    k.i2 = k.ok ? tk.hi : 0;
+                    k.a = k.ok ? tk.lo : 0;
+                    k.rs2 = lrp2[k.i2];
+                    k.deg = k.ok ? lrp2[k.i2 + 1] - k.rs2 : 0;
+                    return k;
+                };
+                int D = batch_depth(), d = 0;
+                task_t cur = open_task();
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    val[s] = 0;
-                    adr[s] = 0;
+                    adr[s] = ~0u;
                     if (D > 0) {   // wave-uniform
-                        const bool ok = okT && d < deg;
-                        const int b = ok ? rs2 + d : 0;
-                        const nz_t z2 = g2.nz[b];
-                        const edge_t e2 = g2.edge[b];
-                        const real e = prm.edge_kernel(e1, e2);
-                        val[s] = ok ? e : real(0);
-                        adr[s] = ok ? (unsigned)(z1.j * n2 + z2.j) : 0u;
+                        if (cur.ok && d < cur.deg) adr[s] = ((unsigned)cur.a << 16) | (unsigned)(cur.rs2 + d);
                         n_slots = s + 1;
-                        if (++d == D) {
+                        if (++d == D) {   // wave-uniform
                             fm[s / 64] |= 1ull << (s % 64);
                             ++kb;
-                            open_batch();
+                            tk.next();
+                            tf.next();
+                            D = batch_depth();
+                            d = 0;
+                            cur = open_task();
                         }
                     }
                 }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    // bound the loads in flight (and with them the live
+                    // registers) to SETUP_CHUNK slots
+                    if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
+                    const bool ok = adr[s] != ~0u;
+                    const int a = ok ? (int)(adr[s] >> 16) : 0, b = ok ? (int)(adr[s] & 0xFFFFu) : 0;
+                    const nz_t z1 = g1.nz[a], z2 = g2.nz[b];
+                    const edge_t e1 = g1.edge[a], e2 = g2.edge[b];
+                    const real e = prm.edge_kernel(e1, e2);
+                    val[s] = ok ? e : real(0);
+                    unsigned col = ok ? (unsigned)(z1.j * n2 + z2.j) : 0u;
+                    // pin the evaluation here: otherwise it is sunk below the
+                    // last chunk and every slot's raw labels stay live
+                    asm volatile("" : "+v"(val[s]), "+v"(col));
+                    if (s % 2 == 0) adr2[s / 2] = col;
+                    else adr2[s / 2] |= col << 16;
+                }
             }
+            auto gather_index = [&](int s) -> unsigned {
+                return (s % 2 == 0) ? (adr2[s / 2] & 0xFFFFu) : (adr2[s / 2] >> 16);
+            };
 
             // ---- publish p ---------------------------------------------------
-            job_sync<W>();  // previous pair's readers of lp/lU are done
+            job_sync<W>();  // everyone is done with the staged row pointers
 #pragma unroll
             for (int k = 0; k < R; ++k)
 #pragma unroll
@@ -276,27 +345,49 @@ struct pair_solver {
             rTz = block_reduce<real, W>::sum(rTz, red);
 
             const real tol = (C == 2) ? real(1e-10) * real(2 * N) : prm.ftol * real(N);
+            const real tol2 = tol * tol;
             unsigned it = 0;
             for (; it < (unsigned)N && rTz != real(0); ++it) {
                 job_sync<W>();   // p published
                 // stage 1: U[task] = sum_b E[a, b] p[j1(a), j2(b)]
                 {
+                    // gathers are issued GCH at a time ahead of their use
+                    // (padding slots read p[0]); the segmented sums flush at
+                    // wave-uniform positions
                     real acc[C];
 #pragma unroll
                     for (int c = 0; c < C; ++c) acc[c] = 0;
                     int kb = 0;
+                    // keep the flush mask as data (s_bitcmp per slot) instead of
+                    // letting LICM expand it into S precomputed SGPR pairs
+                    unsigned long long fmv[NM];
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        if (s < n_slots) {   // wave-uniform
+                    for (int w = 0; w < NM; ++w) {
+                        fmv[w] = fm[w];
+                        asm volatile("" : "+s"(fmv[w]));
+                    }
 #pragma unroll
-                            for (int c = 0; c < C; ++c) acc[c] += val[s] * lp[adr[s] * C + c];
-                            if ((fm[s / 64] >> (s % 64)) & 1ull) {   // wave-uniform
+                    for (int s0 = 0; s0 < S; s0 += GCH) {
+                        real g[C][GCH];
 #pragma unroll
-                                for (int c = 0; c < C; ++c) {
-                                    lU[(kb * T + tid) * C + c] = acc[c];
-                                    acc[c] = 0;
+                        for (int j = 0; j < GCH; ++j)
+#pragma unroll
+                            for (int c = 0; c < C; ++c)
+                                g[c][j] = (s0 + j < S) ? lp[gather_index(s0 + j) * C + c] : real(0);
+#pragma unroll
+                        for (int j = 0; j < GCH; ++j) {
+                            const int s = s0 + j;
+                            if (s < S) {
+#pragma unroll
+                                for (int c = 0; c < C; ++c) acc[c] += val[s] * g[c][j];
+                                if ((fmv[s / 64] >> (s % 64)) & 1ull) {   // wave-uniform
+#pragma unroll
+                                    for (int c = 0; c < C; ++c) {
+                                        lU[(kb * T + tid) * C + c] = acc[c];
+                                        acc[c] = 0;
+                                    }
+                                    ++kb;
                                 }
-                                ++kb;
                             }
                         }
                     }
@@ -305,22 +396,32 @@ struct pair_solver {
                 // stage 2: Ap = diag.p - sum_{a in adj(i1)} U[a, i2]
                 real Ap[C][R];
                 real pAp = 0;
+                {
+                    real acc[C][R];
 #pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    real acc[C];
+                    for (int k = 0; k < R; ++k)
 #pragma unroll
-                    for (int c = 0; c < C; ++c) acc[c] = 0;
-                    for (int d = 0; d < D1[k]; ++d) {   // wave-uniform trip count
-                        if (d < udeg[k]) {
+                        for (int c = 0; c < C; ++c) acc[c][k] = 0;
+                    // D1[0] >= D1[k]: rows are dealt in descending-degree order
+                    for (int d = 0; d < D1[0]; ++d) {   // wave-uniform trip count
+                        real u[C][R];
 #pragma unroll
-                            for (int c = 0; c < C; ++c) acc[c] += lU[(ubase[k] + d) * C + c];
+                        for (int k = 0; k < R; ++k)
+#pragma unroll
+                            for (int c = 0; c < C; ++c)
+                                u[c][k] = (d < udeg[k]) ? lU[(ubase[k] + d) * C + c] : real(0);
+#pragma unroll
+                        for (int k = 0; k < R; ++k)
+#pragma unroll
+                            for (int c = 0; c < C; ++c) acc[c][k] += u[c][k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < R; ++k)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            Ap[c][k] = dg[k] * p[c][k] - acc[c][k];
+                            pAp += p[c][k] * Ap[c][k];
                         }
-                    }
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        Ap[c][k] = dg[k] * p[c][k] - acc[c];
-                        pAp += p[c][k] * Ap[c][k];
-                    }
                 }
                 pAp = block_reduce<real, W>::sum(pAp, red);
                 if (pAp == real(0)) break;
@@ -338,7 +439,7 @@ struct pair_solver {
                         rTz_next += r[c][k] * z[c][k];
                     }
                 block_reduce<real, W>::sum2(rTr, rTz_next, red);
-                if (sqrt(rTr) < tol) {
+                if (rTr < tol2) {   // sqrt(rTr) < tol
                     ++it;
                     break;
                 }
@@ -359,27 +460,30 @@ struct pair_solver {
             const unsigned I1 = prm.starts[job.i], I2 = prm.starts[job.j];
             const bool mirror = (flags & F_SYMMETRIC) && job.i != job.j;
             real ksum = 0;
+            {
+                divmod_walk row(tid, T, n2);
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const int i = k * T + tid;
-                const bool ok = i < N;
-                const int i1 = ok ? i / n2 : 0, i2 = ok ? i - (i / n2) * n2 : 0;
-                const node_t v1 = g1.node[i1], v2 = g2.node[i2];
-                real xi = x[0][k];
-                if (flags & F_LMIN1) xi -= real(prm.node_kernel(v1, v2)) * bscale;
-                const real pp = real(prm.p_start(v1)) * real(prm.p_start(v2));
-                const real rv = ok ? xi * pp : real(0);
-                ksum += rv;
-                if ((flags & F_NODAL) && ok) {
-                    // back to the caller's node numbering
-                    const unsigned o1 = g1.perm[i1], o2 = g2.perm[i2];
-                    if (flags & F_BLOCK) {
-                        prm.gramian[I1 + o1 + o2 * n2] = rv;
-                    } else if (flags & F_DIAGONAL) {
-                        if (o1 == o2) prm.gramian[I1 + o1] = rv;
-                    } else {
-                        prm.gramian[(size_t)(I1 + o1) + (size_t)prm.nX * (I2 + o2)] = rv;
-                        if (mirror) prm.gramian[(size_t)(I2 + o2) + (size_t)prm.nX * (I1 + o1)] = rv;
+                for (int k = 0; k < R; ++k) {
+                    const bool ok = k * T + tid < N;
+                    const int i1 = ok ? row.hi : 0, i2 = ok ? row.lo : 0;
+                    row.next();
+                    const node_t v1 = g1.node[i1], v2 = g2.node[i2];
+                    real xi = x[0][k];
+                    if (flags & F_LMIN1) xi -= real(prm.node_kernel(v1, v2)) * bscale;
+                    const real pp = real(prm.p_start(v1)) * real(prm.p_start(v2));
+                    const real rv = ok ? xi * pp : real(0);
+                    ksum += rv;
+                    if ((flags & F_NODAL) && ok) {
+                        // back to the caller's node numbering
+                        const unsigned o1 = g1.perm[i1], o2 = g2.perm[i2];
+                        if (flags & F_BLOCK) {
+                            prm.gramian[I1 + o1 + o2 * n2] = rv;
+                        } else if (flags & F_DIAGONAL) {
+                            if (o1 == o2) prm.gramian[I1 + o1] = rv;
+                        } else {
+                            prm.gramian[(size_t)(I1 + o1) + (size_t)prm.nX * (I2 + o2)] = rv;
+                            if (mirror) prm.gramian[(size_t)(I2 + o2) + (size_t)prm.nX * (I1 + o1)] = rv;
+                        }
                     }
                 }
             }
@@ -410,59 +514,63 @@ struct pair_solver {
 #pragma unroll
                 for (int j = 0; j < n_jac; ++j) jac[j] = 0;
                 const real Q = real(1) / (real(1) - q), Q3 = Q * Q * Q;
+                {
+                    divmod_walk row(tid, T, n2);
 #pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    const int i = k * T + tid;
-                    const bool ok = i < N;
-                    const int i1 = ok ? i / n2 : 0, i2 = ok ? i - (i / n2) * n2 : 0;
-                    const node_t v1 = g1.node[i1], v2 = g2.node[i2];
-                    const real p1 = prm.p_start(v1), p2 = prm.p_start(v2);
-                    const real dox = real(g1.degree[i1]) * real(g2.degree[i2]);
-                    const real dx = dox * inv1q2;
-                    const real v = prm.node_kernel(v1, v2);
-                    const real YDq = ok ? x[0][k] : real(0), Yp = ok ? x[1][k] : real(0);
-                    auto dp1 = prm.p_start._j_a_c_o_b_i_a_n_(v1);
-                    auto dp2 = prm.p_start._j_a_c_o_b_i_a_n_(v2);
-                    auto dv = prm.node_kernel._j_a_c_o_b_i_a_n_(v1, v2);
+                    for (int k = 0; k < R; ++k) {
+                        const bool ok = k * T + tid < N;
+                        const int i1 = ok ? row.hi : 0, i2 = ok ? row.lo : 0;
+                        row.next();
+                        const node_t v1 = g1.node[i1], v2 = g2.node[i2];
+                        const real p1 = prm.p_start(v1), p2 = prm.p_start(v2);
+                        const real dox = real(g1.degree[i1]) * real(g2.degree[i2]);
+                        const real dx = dox * inv1q2;
+                        const real v = prm.node_kernel(v1, v2);
+                        const real YDq = ok ? x[0][k] : real(0), Yp = ok ? x[1][k] : real(0);
+                        auto dp1 = prm.p_start._j_a_c_o_b_i_a_n_(v1);
+                        auto dp2 = prm.p_start._j_a_c_o_b_i_a_n_(v2);
+                        auto dv = prm.node_kernel._j_a_c_o_b_i_a_n_(v1, v2);
 #pragma unroll
-                    for (int j = 0; j < PStart::jac_dims; ++j)
-                        jac[j] += (real(dp1[j]) * p2 + p1 * real(dp2[j])) * YDq;
-                    jac[off_q] += real(2) * Q * p1 * p2 * YDq - real(2) * Q3 * Yp * dox / v * YDq;
+                        for (int j = 0; j < PStart::jac_dims; ++j)
+                            jac[j] += (real(dp1[j]) * p2 + p1 * real(dp2[j])) * YDq;
+                        jac[off_q] += real(2) * Q * p1 * p2 * YDq - real(2) * Q3 * Yp * dox / v * YDq;
 #pragma unroll
-                    for (int j = 0; j < NodeK::jac_dims; ++j)
-                        jac[off_v + j] += dx * Yp * YDq / (v * v) * real(dv[j]);
+                        for (int j = 0; j < NodeK::jac_dims; ++j)
+                            jac[off_v + j] += dx * Yp * YDq / (v * v) * real(dv[j]);
+                    }
                 }
                 job_sync<W>();
                 if constexpr (EdgeK::jac_dims > 0) {
                     // walk the stage-1 nonzeros again: row = (i1(a), i2), col = adr
-                    int kb = 0;
-                    auto task = [&](int kk, bool &okT, int &a, int &i2, int &rs2, int &deg) {
-                        const int tk = kk * T + tid;
-                        okT = tk < ntask;
-                        i2 = okT ? tk / nnz1 : 0;
-                        a = okT ? tk - i2 * nnz1 : 0;
-                        rs2 = g2.rowptr[i2];
-                        deg = okT ? (int)g2.rowptr[i2 + 1] - rs2 : 0;
+                    divmod_walk tk(tid, T, nnz1);
+                    int kb = 0, d = 0;
+                    auto open_task = [&]() -> task_t {
+                        task_t k;
+                        k.ok = kb * T + tid < ntask;
+                        k.i2 = k.ok ? tk.hi : 0;
+                        k.a = k.ok ? tk.lo : 0;
+                        k.rs2 = g2.rowptr[k.i2];
+                        k.deg = k.ok ? (int)g2.rowptr[k.i2 + 1] - k.rs2 : 0;
+                        return k;
                     };
-                    bool okT;
-                    int a, i2, rs2, deg, d = 0;
-                    task(0, okT, a, i2, rs2, deg);
+                    task_t cur = open_task();
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         if (s < n_slots) {   // wave-uniform
-                            const bool ok = okT && d < deg;
-                            const int b = ok ? rs2 + d : 0;
-                            const edge_t e1 = g1.edge[a], e2 = g2.edge[b];
+                            const bool ok = cur.ok && d < cur.deg;
+                            const int b = ok ? cur.rs2 + d : 0;
+                            const edge_t e1 = g1.edge[cur.a], e2 = g2.edge[b];
                             auto de = prm.edge_kernel._j_a_c_o_b_i_a_n_(e1, e2);
-                            const int row = g1.nz[a].i * n2 + i2;
-                            const real w = ok ? lp[row * 2 + 1] * lp[adr[s] * 2 + 0] : real(0);
+                            const int row = g1.nz[cur.a].i * n2 + cur.i2;
+                            const real w = ok ? lp[row * 2 + 1] * lp[gather_index(s) * 2 + 0] : real(0);
 #pragma unroll
                             for (int j = 0; j < EdgeK::jac_dims; ++j) jac[off_e + j] += w * real(de[j]);
                             ++d;
                             if ((fm[s / 64] >> (s % 64)) & 1ull) {   // wave-uniform
                                 ++kb;
                                 d = 0;
-                                task(kb, okT, a, i2, rs2, deg);
+                                tk.next();
+                                cur = open_task();
                             }
                         }
                     }

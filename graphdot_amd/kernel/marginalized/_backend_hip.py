@@ -144,8 +144,9 @@ class HIPBackend(Backend):
     device: int or None
         HIP device ordinal (default: ``$LOCAL_RANK`` or 0).
     real: numpy float32 (reference arithmetic, default) or float64
-    blocks_per_cu: int
-        Persistent workgroups launched per compute unit.
+    jobs_per_unit: int
+        Graph pairs handled by one wave (small pairs) or workgroup (large
+        pairs) before it retires; sets the launch grid.
     hipcc_extra: list of str
         Extra compiler flags.
     """
@@ -166,10 +167,17 @@ class HIPBackend(Backend):
         self.uuid = uuid.uuid4()
         self.device = kwargs.pop('device', None)
         self.real = np.dtype(kwargs.pop('real', np.float32)).type
-        self.blocks_per_cu = kwargs.pop('blocks_per_cu', 8)
+        self.jobs_per_unit = kwargs.pop('jobs_per_unit', 8)
         self.hipcc_extra = list(kwargs.pop('hipcc_extra', []))
         self.variants = list(kwargs.pop('variants', VARIANTS))
         self.record_iterations = kwargs.pop('record_iterations', False)
+        self.occupancy = kwargs.pop('occupancy', None)
+        if self.occupancy is None and os.environ.get('GD_OCCUPANCY'):
+            # e.g. GD_OCCUPANCY="1:16:5,1:24:4"  (W:S:waves)
+            self.occupancy = {
+                (int(a), int(b)): int(c) for a, b, c in
+                (item.split(':') for item in
+                 os.environ['GD_OCCUPANCY'].split(','))}
         if kwargs:
             raise TypeError(f'unknown HIPBackend options {sorted(kwargs)}')
         runtime.lib()                      # fail loudly if the library is absent
@@ -318,7 +326,7 @@ struct ${name}_t : ${name}_theta_t {
             return dt if dt.itemsize else np.dtype(np.uint8)
         P = np.uintp
         return np.dtype([
-            ('graphs', P), ('jobs', P), ('order', P), ('starts', P),
+            ('arena', P), ('jobs', P), ('order', P), ('starts', P),
             ('gramian', P), ('gradient', P), ('iters', P),
             ('n_launch_jobs', np.uint32), ('nX', np.uint32),
             ('nY', np.uint32), ('nJ', np.uint32), ('flags', np.uint32),
@@ -334,10 +342,27 @@ struct ${name}_t : ${name}_theta_t {
     def kernel_name(v, C):
         return f'mgk_W{v.W}_S{v.S}_R{v.R}_C{C}'
 
+    def waves_per_eu(self, v, C):
+        """Occupancy target handed to the register allocator.  The solver's
+        live state is ~2.5 registers per slot plus ~8 per row (x C); asking
+        for more waves than that allows makes the compiler spill, but only in
+        the once-per-pair setup / epilogue code, not in the CG loop."""
+        if self.occupancy is not None:
+            for (W, S), n in self.occupancy.items():
+                if (W, S) == (v.W, v.S):
+                    return n
+        need = (2.5 * v.S + 8 * v.R) * (1 if C == 1 else 1.6) + 16
+        floor = -(-64 * v.W * (4 if v.W == 1 else 1) // 256)  # block must fit
+        for n in (8, 6, 5, 4, 3, 2):
+            if need <= 512 // n:
+                return max(n, floor)
+        return max(1, floor)
+
     def _entry_point(self, v, C):
         threads = 64 * v.W * (4 if v.W == 1 else 1)
         return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
+__attribute__((amdgpu_waves_per_eu(${waves})))
 void ${name}(params_t prm) {
     using solver = graphdot::mgk::pair_solver<real_t, ${S}, ${R}, ${W}, ${C},
         graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
@@ -346,7 +371,7 @@ void ${name}(params_t prm) {
     solver::run(prm, lds, reinterpret_cast<real_t *>(dyn_lds));
 }
 ''').render(threads=threads, name=self.kernel_name(v, C), S=v.S, R=v.R,
-            W=v.W, C=C)
+            W=v.W, C=C, waves=self.waves_per_eu(v, C))
 
     def render_source(self, node_kernel, edge_kernel, p, node_t, edge_t,
                       variants, C):
@@ -546,10 +571,13 @@ void ${name}(params_t prm) {
             order_all[cursor:cursor + len(idx)] = idx.astype(np.uint32)
             wpb = 4 if v.W == 1 else 1
             threads = 64 * v.W * wpb
-            bpc = self.blocks_per_cu if v.W <= 4 else max(
-                1, self.blocks_per_cu // 4)
-            grid = int(min(-(-len(idx) // wpb),
-                           self.props.compute_units * bpc))
+            # Many small workgroups (a few pairs per wave) rather than one
+            # persistent grid: the hardware dispatcher then balances the load
+            # whatever the achieved residency is (a grid of exactly
+            # CUs x blocks_per_cu left a near-idle second round when only
+            # blocks_per_cu - 1 workgroups fitted a CU).
+            per_unit = self.jobs_per_unit
+            grid = int(max(1, -(-len(idx) // (wpb * per_unit))))
             ucap = int(-(-ntask[idx].max() // 64) * 64)
             dyn = ucap * C * wpb * rsize
             fn = modules[k].function(self.kernel_name(v, C))
@@ -582,7 +610,7 @@ void ${name}(params_t prm) {
         # kernel argument blocks
         pd = self._params_dtype(node_kernel, edge_kernel, p)
         base = np.zeros((), dtype=pd)
-        base['graphs'] = arena_buf.ptr
+        base['arena'] = arena_buf.ptr
         base['jobs'] = b_jobs.ptr
         base['starts'] = b_starts.ptr
         base['gramian'] = b_out.ptr

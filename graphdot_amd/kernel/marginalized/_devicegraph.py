@@ -30,12 +30,13 @@ from ...codegen.typetool import common_min_type, is_scalar_type
 
 _ALIGN = 16
 
-#: device-side header, mirrors graphdot::graph_t (40 bytes)
+#: device-side header, mirrors graphdot::graph_header_t (32 bytes); the
+#: section fields are byte offsets from the arena base
 HEADER_DTYPE = np.dtype([
-    ('n_node', np.int32), ('n_nz', np.int32), ('degree', np.uintp),
-    ('node', np.uintp), ('rowptr', np.uintp), ('nz', np.uintp),
-    ('edge', np.uintp), ('perm', np.uintp)], align=True)
-assert HEADER_DTYPE.itemsize == 56
+    ('n_node', np.int32), ('n_nz', np.int32), ('degree', np.uint32),
+    ('node', np.uint32), ('rowptr', np.uint32), ('nz', np.uint32),
+    ('edge', np.uint32), ('perm', np.uint32)], align=True)
+assert HEADER_DTYPE.itemsize == 32
 SECTIONS = ('degree', 'node', 'rowptr', 'nz', 'edge', 'perm')
 
 NZ_DTYPE = np.dtype([('i', np.uint16), ('j', np.uint16)])
@@ -94,7 +95,7 @@ class DeviceGraph:
         nodes = graph.nodes.copy(deep=False)
         edges = graph.edges.copy(deep=False)
         self.n_node = n = len(nodes)
-        if n > 0xFFFF:
+        if n > 0xFFFF or 2 * len(edges) > 0xFFFF:
             raise ValueError('graphs with more than 65535 nodes are not '
                              'supported by the device format')
 
@@ -306,11 +307,10 @@ class GraphArena:
 
     def relocated(self, base):
         """Byte image with every pointer rebased onto device address `base`."""
+        if self.nbytes >= 2**32:
+            raise ValueError('graph arena exceeds the 4 GiB offset range')
         img = self.host.copy()
-        hdr = self._hdr.copy()
-        for name in SECTIONS:
-            hdr[name] += np.uintp(base)
-        img[:hdr.nbytes] = hdr.view(np.uint8)
+        img[:self._hdr.nbytes] = self._hdr.view(np.uint8)
         for where in self._relocs:
             word = img[where:where + 8].view(np.uint64)
             word[0] += np.uint64(base)
