@@ -178,8 +178,11 @@ class MarginalizedGraphKernel:
                 starts[nx:] = np.arange(ny + 1)
                 output_shape = (nx, ny)
         n_out = int(np.prod(output_shape))
-        gramian = backend.empty(n_out, np.float32)
-        gradient = (backend.empty(self.n_dims * n_out, np.float32)
+        # fp32 like the reference (_kernel.py:212-216) unless the backend
+        # computes in double precision
+        real = getattr(backend, 'real', np.float32)
+        gramian = backend.empty(n_out, real)
+        gradient = (backend.empty(self.n_dims * n_out, real)
                     if traits.eval_gradient is True else None)
         timer.toc('creating output buffer')
 
@@ -251,8 +254,9 @@ class MarginalizedGraphKernel:
         else:
             raise ValueError("Invalid 'nodal' option '%s'" % nodal)
         output_length = int(starts[-1])
-        gramian = backend.empty(output_length, np.float32)
-        gradient = (backend.empty(self.n_dims * output_length, np.float32)
+        real = getattr(backend, 'real', np.float32)
+        gramian = backend.empty(output_length, real)
+        gradient = (backend.empty(self.n_dims * output_length, real)
                     if traits.eval_gradient is True else None)
         timer.toc('creating output buffer')
 

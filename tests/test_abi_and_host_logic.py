@@ -1,0 +1,189 @@
+"""CPU-only checks of the drop-in boundary and of the backend's host logic:
+the C-ABI library builds, loads and exports every symbol of include/gdhip.h;
+code generation, job partitioning and the pair sharding are exercised without
+a device (no compute calls)."""
+import ctypes
+import os
+import re
+import sys
+import numpy as np
+import pytest
+import cases
+from graphdot_amd.hip import jit, runtime
+from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+from graphdot_amd.kernel.marginalized._backend_hip import (
+    HIPBackend, VARIANTS, Variant, declstruct)
+from graphdot_amd.kernel.marginalized._sharded import ShardPlan, partition
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'gdhip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(gd_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = runtime.lib()
+    names = declared_symbols()
+    assert len(names) >= 28
+    for name in names:
+        assert hasattr(L, name), name
+        assert name in runtime.SIGNATURES or name in (
+            'gd_last_error', 'gd_version'), f'{name} has no ctypes signature'
+    assert b'gfx950' in L.gd_version()
+
+
+def test_device_calls_fail_loudly_without_a_gpu():
+    """No silent CPU fallback: with no device the ABI reports an error."""
+    L = runtime.lib()
+    n = ctypes.c_int(-1)
+    rc = L.gd_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip('a GPU is present')
+    assert rc != 0 or n.value == 0
+    with pytest.raises(runtime.HIPError):
+        runtime.check(L.gd_init(0))
+    assert L.gd_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'graphdot_amd')):
+        for f in files:
+            if f.endswith(('.py', '.h', '.cpp', '.hip')):
+                text = open(os.path.join(dirpath, f), errors='replace').read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', text, re.M) \
+                        or 'mgk_oracle' in text:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_jit_compiles_for_gfx950_and_caches(tmp_path, monkeypatch):
+    monkeypatch.setattr(jit, 'CACHE_DIR', str(tmp_path))
+    src = ('#include <hip/hip_runtime.h>\n'
+           'extern "C" __global__ void k(float *x) { x[threadIdx.x] = 1.f; }\n')
+    path = jit.compile_source(src)
+    assert os.path.getsize(path) > 0
+    with open(path, 'rb') as f:          # clang offload bundle of one target
+        assert b'gfx950' in f.read()
+    mtime = os.path.getmtime(path)
+    assert jit.compile_source(src) == path
+    assert os.path.getmtime(path) == mtime
+    with pytest.raises(jit.CompileError):
+        jit.compile_source('this is not HIP')
+
+
+def test_solver_translation_unit_compiles_all_modes():
+    """The generated TU (value and value+gradient, float and double) builds
+    for gfx950; static_asserts inside tie the host packing to the device
+    structs."""
+    G = cases.nlw_example_graphs()
+    knode, kedge, q = cases.config2a_kernels()
+    job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
+    jobs = np.array([(0, 0), (0, 1), (1, 2)], dtype=job_t)
+    for real in (np.float32, np.float64):
+        backend = HIPBackend(real=real)
+        k = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+        for eg in (False, True):
+            paths = backend.precompile(
+                G, knode, kedge, k.p, jobs,
+                k.traits(symmetric=True, eval_gradient=eg))
+            assert all(os.path.getsize(p) > 0 for p in paths)
+
+
+def test_declstruct_names_nested_and_empty_members():
+    dt = np.dtype([('weight', np.dtype([])),
+                   ('label', np.dtype([('h', np.float32)], align=True))],
+                  align=True)
+    text = declstruct(dt, 'T')
+    assert 'constexpr static _empty weight' in text
+    assert 'struct T_label {float32 h;} label;' in text
+
+
+def test_job_classification_respects_variant_capacity():
+    G = cases.config2_graphs(12, seed=1)
+    backend = HIPBackend()
+    dgs = [backend._register_graph(g) for g in G]
+    i, j = np.triu_indices(len(G))
+    choice, cost, ntask = backend.classify(i, j, dgs, 1)
+    n = np.array([d.n_node for d in dgs])
+    nz = np.array([d.n_nz for d in dgs])
+    assert np.all(choice >= 0)
+    for k, (a, b) in enumerate(zip(i, j)):
+        v = backend.variants[choice[k]]
+        assert n[a] * n[b] <= 64 * v.W * v.R
+        assert ntask[k] == nz[a] * n[b]
+        # brute-force the stage-1 walk of mgk_solver.h for this job
+        T = 64 * v.W
+        deg = dgs[b].adjacency_count
+        worst = 0
+        for w in range(v.W):
+            total, kb = 0, 0
+            while kb * T + 64 * w < ntask[k]:
+                total += max(1, deg[(kb * T + 64 * w) // nz[a]])
+                kb += 1
+            worst = max(worst, total)
+        assert worst <= v.S
+        assert backend.lds_bytes(v, 1, ntask[k]) <= 160 * 1024
+    # with only the smallest variant available, large pairs must be refused
+    small = HIPBackend(variants=[Variant(1, 8, 2)])
+    with pytest.raises(NotImplementedError):
+        small.classify(i, j, dgs, 1)
+
+
+def test_partition_is_balanced_and_complete():
+    rng = np.random.default_rng(0)
+    cost = rng.integers(1, 1000, size=1001)
+    shards = partition(cost, 8)
+    allj = np.sort(np.concatenate(shards))
+    assert allj.tolist() == list(range(1001))
+    loads = np.array([cost[s].sum() for s in shards])
+    assert loads.max() / loads.mean() < 1.02
+    assert max(map(len, shards)) - min(map(len, shards)) <= 1
+
+
+def _shard_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle import mgk
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    G = cases.config3_graphs(10, seed=3)
+    knode, kedge, q = cases.config3_kernels()
+    n = len(G)
+    i, j = np.triu_indices(n)
+    n_node = np.array([len(g.nodes) for g in G])
+    n_nz = np.array([mgk._side(g).nnz for g in G])
+    plan = ShardPlan(i, j, n_node, n_nz, n, n, True, rank, world)
+    # local shard through the oracle (the GPU path plugs its HIP plan here)
+    batch = mgk.TensorProductBatch(G, knode, kedge)
+    local, _ = batch.run(i[plan.local], j[plan.local], q=q, real='f64',
+                         tol=1e-13)
+    slab = torch.zeros(plan.capacity, dtype=torch.float64)
+    slab[:len(local)] = torch.from_numpy(local)
+    gathered = torch.empty(world * plan.capacity, dtype=torch.float64)
+    dist.all_gather_into_tensor(gathered, slab)
+    K = plan.assemble(gathered.numpy())
+    np.save(os.path.join(tmp, f'K{rank}.npy'), K)
+    dist.destroy_process_group()
+
+
+def test_pair_sharding_world_size_2_gloo(tmp_path):
+    """The multi-GPU path (shard -> packed slab -> all-gather -> reassembly)
+    with two gloo ranks on CPU, local shards computed by the oracle."""
+    import torch.multiprocessing as mp
+    from oracle import mgk
+    port = 29500 + os.getpid() % 1000
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2,
+             join=True)
+    G = cases.config3_graphs(10, seed=3)
+    knode, kedge, q = cases.config3_kernels()
+    ref = mgk.gram(G, knode, kedge, q=q)
+    for r in range(2):
+        K = np.load(os.path.join(str(tmp_path), f'K{r}.npy'))
+        assert np.allclose(K, ref, rtol=1e-9)
+        assert np.count_nonzero(K - K.T) == 0

@@ -1,0 +1,243 @@
+"""Host-side object model against fixtures recorded from the reference
+(codegen grammar, theta structs, states, hyperparameter plumbing, degrees)."""
+import re
+import numpy as np
+import pytest
+from numpy import inf  # noqa: F401
+from _fixtures import load, graph_from_dict, graphs_from
+from graphdot_amd.codegen import Template
+from graphdot_amd.codegen.cpptool import cpptype, decltype
+from graphdot_amd.graph import Graph
+from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel, Backend
+from graphdot_amd.kernel.marginalized._devicegraph import (
+    DeviceGraph, GraphArena, HEADER_DTYPE)
+from graphdot_amd.kernel.marginalized.starting_probability import Uniform
+from graphdot_amd.microkernel import (  # noqa: F401
+    Constant, KroneckerDelta, SquareExponential, RationalQuadratic,
+    TensorProduct, Additive, Composite, Convolution, Normalize, Product,
+    DotProduct)
+from graphdot_amd.util.iterable import flatten, fold_like
+
+HOST = load('host_model.json')
+
+
+def squash(text):
+    return re.sub(r'\s+', '', text)
+
+
+def build(key):
+    return {
+        'constant': lambda: Constant(1.0),
+        'kdelta': lambda: KroneckerDelta(0.5),
+        'sqexp': lambda: SquareExponential(0.5),
+        'rq': lambda: RationalQuadratic(1.0, 2.0),
+        'tp': lambda: TensorProduct(radius=SquareExponential(0.5),
+                                    category=KroneckerDelta(0.5)),
+        'additive_norm': lambda: Additive(
+            order=KroneckerDelta(0.3),
+            length=SquareExponential(0.05)).normalized,
+        'tp_norm': lambda: TensorProduct(
+            hybridization=KroneckerDelta(0.3),
+            charge=SquareExponential(1.) + 0.01).normalized,
+        'conv': lambda: TensorProduct(rings=Convolution(KroneckerDelta(0.3))),
+        'weighted_wrap': lambda: TensorProduct(
+            weight=Product(),
+            label=TensorProduct(length=SquareExponential(1.0))),
+        'expr': lambda: KroneckerDelta(0.5) * 2 + 1,
+        'pow': lambda: KroneckerDelta(0.5)**2,
+        'dot': lambda: TensorProduct(v=DotProduct()),
+    }[key]()
+
+
+@pytest.mark.parametrize('key', sorted(HOST['kernels']))
+def test_microkernel_codegen_matches_reference(key):
+    ref = HOST['kernels'][key]
+    k = build(key)
+    expr, jac = k.gen_expr('x1', 'x2')
+    assert squash(expr) == squash(ref['expr'])
+    assert [squash(j) for j in jac] == [squash(j) for j in ref['jac']]
+    assert decltype(k) == ref['decltype']
+    assert repr(k) == ref['repr']
+    assert k.dtype.itemsize == ref['itemsize']
+    assert np.allclose(list(flatten(k.theta)), ref['theta'])
+    assert np.allclose(list(flatten(k.state)), list(flatten(ref['state'])))
+    if ref['minmax'] is not None:
+        assert [float(v) for v in k.minmax] == pytest.approx(ref['minmax'])
+    k2 = eval(repr(k))
+    assert repr(k2) == repr(k)
+
+
+def test_microkernel_values_and_jacobians():
+    k = TensorProduct(radius=SquareExponential(0.5),
+                      category=KroneckerDelta(0.5))
+    X, Y = dict(radius=1.0, category=1), dict(radius=1.5, category=2)
+    f, j = k(X, Y, jac=True)
+    assert f == pytest.approx(np.exp(-0.5) * 0.5)
+    h = 1e-6
+    for i in range(2):
+        t = np.array(list(flatten(k.theta)))
+        kp, km = eval(repr(k)), eval(repr(k))
+        tp, tm = t.copy(), t.copy()
+        tp[i] += h
+        tm[i] -= h
+        kp.theta = fold_like(tp, kp.theta)
+        km.theta = fold_like(tm, km.theta)
+        assert j[i] == pytest.approx((kp(X, Y) - km(X, Y)) / (2 * h),
+                                     rel=1e-6)
+    kn = k.normalized
+    assert kn(X, X) == pytest.approx(1.0)
+    assert kn.minmax[1] == 1
+    assert k(X, Y) == k(Y, X)
+
+
+def test_pack_state_diff_grid():
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    got = HIPBackend.pack_state(KroneckerDelta(0.5), diff_grid=True,
+                                diff_eps=1e-2)
+    assert np.allclose([list(flatten(s)) for s in got],
+                       [list(flatten(s)) for s in HOST['pack_state']])
+    assert list(Uniform(1.0).gen_expr()) == HOST['gencode_p']
+
+
+def test_theta_plumbing_matches_reference():
+    class Null(Backend):
+        def __call__(self, *a):
+            pass
+    mk = MarginalizedGraphKernel(
+        TensorProduct(f=KroneckerDelta(0.5)),
+        TensorProduct(a=SquareExponential(1.0, length_scale_bounds='fixed'),
+                      b=KroneckerDelta(0.25)),
+        q=0.05, backend=Null())
+    ref = HOST['theta_plumbing']
+    assert np.allclose(mk.flat_hyperparameters, ref['flat'])
+    assert mk.n_dims == ref['n_dims']
+    assert mk.active_theta_mask.tolist() == ref['mask']
+    assert np.allclose(mk.theta, ref['theta'])
+    assert np.allclose(mk.bounds, ref['bounds'])
+    mk.theta = np.log([2.0, 0.1, 0.25, 0.5])
+    assert np.allclose(mk.flat_hyperparameters, [2.0, 0.1, 0.25, 1.0, 0.5])
+    clone = mk.clone_with_theta(np.log([1.0, 0.2, 0.3, 0.4]))
+    assert np.allclose(clone.flat_hyperparameters, [1.0, 0.2, 0.3, 1.0, 0.4])
+    assert np.allclose(mk.flat_hyperparameters, [2.0, 0.1, 0.25, 1.0, 0.5])
+    assert 'stopping_probability' in repr(mk.hyperparameters)
+
+
+def test_range_check_warnings():
+    """test_kernel.py:572-605"""
+    class Null(Backend):
+        def __call__(self, *a):
+            pass
+    ok = TensorProduct(attribute=SquareExponential(1.0))
+    MarginalizedGraphKernel(KroneckerDelta(1e-7), ok, backend=Null())
+    for node, edge in [
+            (KroneckerDelta(0), ok),
+            (TensorProduct(feature=KroneckerDelta(0.5)) + 1,
+             SquareExponential(1.0)),
+            (TensorProduct(feature=KroneckerDelta(0.5)), ok + 1),
+            (KroneckerDelta(0.5) * 2, ok),
+            (TensorProduct(feature=KroneckerDelta(0.5)), ok * 2)]:
+        with pytest.warns(DeprecationWarning):
+            MarginalizedGraphKernel(node, edge, backend=Null())
+    with pytest.raises(ValueError):
+        MarginalizedGraphKernel(KroneckerDelta(0.5), ok, p=-1.0,
+                                backend=Null())
+    with pytest.raises(ValueError):
+        MarginalizedGraphKernel(KroneckerDelta(0.5), ok, backend='nope')
+
+
+@pytest.mark.parametrize('name', ['nlw3', 'rand12'])
+def test_device_graph_vs_reference_octilegraph(name):
+    """Same degrees, node/edge struct declarations and nonzero weights as the
+    reference's OctileGraph (layout differs by design, see graph.h)."""
+    ref = HOST['octilegraph'][name]
+    g = graph_from_dict(ref['graph'])
+    d = DeviceGraph(g)
+    assert d.weighted == ref['weighted']
+    assert decltype(d.node_t) == ref['node_t_decl']
+    assert decltype(d.edge_t) == ref['edge_t_decl']
+    # degrees are stored in the degree-sorted numbering: map back
+    deg = np.empty(d.n_node, np.float32)
+    deg[d.perm] = d.degree
+    assert deg.tolist() == ref['degree']
+    assert d.n_nz == len(ref['weights'])
+    edges = d.blob[d.offsets['edge']:d.offsets['edge']
+                   + d.n_nz * d.edge_t.itemsize].view(d.edge_t)
+    assert sorted(edges['weight'].tolist()) == sorted(ref['weights'])
+    # CSR consistency in the new numbering
+    assert d.rowptr[-1] == d.n_nz
+    assert np.all(np.diff(d.adjacency_count) <= 0)
+    A = np.zeros((d.n_node, d.n_node))
+    A[d.perm[d.nz['i']], d.perm[d.nz['j']]] = edges['weight']
+    assert np.allclose(A, g.adjacency_matrix.toarray())
+
+
+def test_arena_relocation_of_frozen_arrays():
+    G = graphs_from(load('mlgk_cases.json')['vario-features']['graphs'])
+    dgs = [DeviceGraph(g) for g in G]
+    arena = GraphArena(dgs)
+    base = 0x7f0000000000
+    img = arena.relocated(base)
+    hdr = img[:arena.n * HEADER_DTYPE.itemsize].view(HEADER_DTYPE)
+    assert hdr['n_node'].tolist() == [3, 2]
+    for k, d in enumerate(dgs):
+        nodes = img[hdr['node'][k]:hdr['node'][k]
+                    + d.n_node * d.node_t.itemsize].view(d.node_t)
+        fa = nodes[d.node_t.names[0]]
+        for row in range(d.n_node):
+            off = int(fa['ptr'][row]) - base
+            size = int(fa['size'][row])
+            payload = img[off:off + 2 * size].view(np.int16)
+            orig = d.perm[row]
+            rings = [r for i, r in zip(G[k].nodes['!i'], G[k].nodes['rings'])
+                     if i == orig][0]
+            assert payload.tolist() == list(rings)
+
+
+def test_graph_container_semantics():
+    import copy
+    import pickle
+    import networkx as nx
+    g = nx.Graph(title='t')
+    g.add_node('a', x=1)
+    g.add_node('b', x=300)
+    g.add_edge('a', 'b', w=0.5, y=1.5)
+    G = Graph.from_networkx(g, weight='w')
+    assert G.title == 't'
+    assert G.nodes['x'].dtype == np.int32          # uint16 -> signed int32
+    assert G.edges['!w'].dtype == np.float32
+    assert Graph.has_unified_types([G, G]) is True
+    G.cookie['k'] = 1
+    assert copy.deepcopy(G).cookie == {}
+    assert pickle.loads(pickle.dumps(G)).cookie == {}
+    P = G.permute([1, 0])
+    assert P.nodes['!i'].tolist() == [1, 0]
+    assert np.allclose(G.laplacian.toarray(), [[0.5, -0.5], [-0.5, 0.5]])
+    h = nx.Graph()
+    h.add_node(0, x=1.5)
+    h.add_node(1, x=2.5)
+    h.add_edge(0, 1, w=1.0, y=2.0)
+    H = Graph.from_networkx(h, weight='w')
+    assert Graph.has_unified_types([G, H]) is not True
+    U = Graph.unify_datatype([G, H])
+    assert Graph.has_unified_types(U) is True
+    with pytest.raises(RuntimeError):
+        Graph.from_networkx(nx.empty_graph(3))
+    back = G.to_networkx()
+    assert back.number_of_edges() == 1
+
+
+def test_template_and_cpptype():
+    assert Template('${a}(${b, })').render(a='f', b=[1, 2]) == 'f(1, 2)'
+    with Template('?{t.x is True}|?{t.x == 2}').context(
+            t=type('T', (), {'x': True})) as t:
+        assert t.render() == 'true|false'
+
+    @cpptype(h=np.float32, n=np.int32)
+    class K:
+        def __init__(self):
+            self.h, self.n = 0.5, 3
+    k = K()
+    assert k.state == (np.float32(0.5), np.int32(3))
+    assert decltype(k) == 'struct{float32 h;int32 n;}'
+    with pytest.raises(TypeError):
+        k.h = 'x'

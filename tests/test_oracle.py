@@ -1,0 +1,140 @@
+"""The CPU oracle (oracle/) pinned against the golden vectors generated from
+the reference's own Python oracles (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+from _fixtures import load, graphs_from, kernel_from_repr
+from graphdot_amd.microkernel import Constant
+from oracle import mgk
+
+MLGK = load('mlgk_cases.json')
+FAMILIES = ['unlabeled', 'labeled', 'weighted', 'vario-features']
+# dense/pcg64: fp64 restatements; pcg32: the reference's device arithmetic,
+# the reference's own tests accept 1e-5 for it (test_kernel.py:214)
+TOL = {'dense': 1e-11, 'pcg64': 1e-11, 'pcg32': 1e-5}
+
+
+@pytest.mark.parametrize('mode', ['dense', 'pcg64', 'pcg32'])
+@pytest.mark.parametrize('name', FAMILIES)
+def test_self_pairs_vs_reference_MLGK(name, mode):
+    case = MLGK[name]
+    G = graphs_from(case['graphs'])
+    knode = kernel_from_repr(case['knode'])
+    kedge = kernel_from_repr(case['kedge'])
+    for qi, q in enumerate(case['q']):
+        for gi, g in enumerate(G):
+            R = mgk.gram([g], knode, kedge, q=q, nodal=True, mode=mode)
+            ref = np.array(case['R_nodal'][qi][gi])
+            assert np.allclose(R, ref, rtol=TOL[mode], atol=0)
+            r = mgk.gram([g], knode, kedge, q=q, mode=mode)[0, 0]
+            assert r == pytest.approx(case['R'][qi][gi], rel=TOL[mode])
+
+
+def test_known_answers_from_survey():
+    """values quoted from the reference oracle."""
+    R = {name: MLGK[name]['R'] for name in FAMILIES}
+    assert R['unlabeled'][0][0] == pytest.approx(452.2613065, rel=1e-9)
+    assert R['unlabeled'][3] == pytest.approx([12.0, 12.0], rel=1e-12)
+    assert R['labeled'][1] == pytest.approx([9.376686034, 20.84356588],
+                                            rel=1e-9)
+    assert R['weighted'][1] == pytest.approx([11.71550219, 41.02564103],
+                                             rel=1e-9)
+    assert R['vario-features'][1] == pytest.approx(
+        [6.558041573, 4.741470873], rel=1e-9)
+
+
+@pytest.mark.parametrize('mode', ['dense', 'pcg32'])
+def test_self_loops_vs_reference_MLGK(mode):
+    for c in MLGK['self-loops']:
+        g = graphs_from([c['graph']])[0]
+        r = mgk.gram([g], Constant(1.0), Constant(1.0), q=c['q'],
+                     mode=mode)[0, 0]
+        assert r == pytest.approx(c['R'], rel=TOL[mode])
+
+
+@pytest.mark.parametrize('mode', ['dense', 'pcg32'])
+def test_cross_pairs_vs_reference_M3(mode):
+    """M3._mlgk builds part of its system in float32 (scipy CSC of float32
+    weights), so it pins cross pairs to about 1e-6 only."""
+    for case in load('m3_cross.json').values():
+        G = graphs_from(case['graphs'])
+        knode = kernel_from_repr(case['knode'])
+        kedge = kernel_from_repr(case['kedge'])
+        for a in range(len(G)):
+            for b in range(len(G)):
+                R = mgk.gram([G[a]], knode, kedge, Y=[G[b]], q=case['q'],
+                             nodal=True, mode=mode)
+                ref = np.array(case['R_nodal'][a][b])
+                assert np.allclose(R, ref, rtol=5e-6, atol=0)
+
+
+def test_closed_form_unlabeled():
+    """K = n1 n2 / (1 - (1-q)^2) for unlabeled graphs without isolated nodes
+    (SURVEY.md 8c(2))."""
+    import cases
+    G = cases.config1_graphs()
+    n = np.array([len(g.nodes) for g in G], dtype=float)
+    for q in (0.05, 0.5):
+        R = mgk.gram(G[:5], Constant(1.0), Constant(1.0), q=q)
+        assert np.allclose(R, np.outer(n[:5], n[:5]) / (1 - (1 - q)**2),
+                           rtol=1e-12)
+
+
+@pytest.mark.parametrize('name', ['labeled', 'weighted', 'vario-features'])
+def test_analytic_gradient_restatement_vs_finite_differences(name):
+    """mgk_derivative (marginalized_kernel.h:806-997 restated) against
+    central differences of the dense fp64 oracle in the raw hyperparameters."""
+    from graphdot_amd.util.iterable import flatten
+    case = MLGK[name]
+    G = graphs_from(case['graphs'])
+    knode = kernel_from_repr(case['knode'])
+    kedge = kernel_from_repr(case['kedge'])
+    p, q, h = 1.3, 0.05, 1e-6
+    K, dK = mgk.gram(G, knode, kedge, p=p, q=q, eval_gradient=True)
+
+    def val(p_, q_, kn, ke):
+        return mgk.gram(G, kn, ke, p=p_, q=q_)
+
+    cols = [(val(p + h, q, knode, kedge) - val(p - h, q, knode, kedge)),
+            (val(p, q + h, knode, kedge) - val(p, q - h, knode, kedge))]
+    for which, k in (('n', knode), ('e', kedge)):
+        t = np.array(list(flatten(k.theta)), float)
+        for j in range(len(t)):
+            tp, tm = t.copy(), t.copy()
+            tp[j] += h
+            tm[j] -= h
+            kp, km = mgk._with_theta(k, tp), mgk._with_theta(k, tm)
+            if which == 'n':
+                cols.append(val(p, q, kp, kedge) - val(p, q, km, kedge))
+            else:
+                cols.append(val(p, q, knode, kp) - val(p, q, knode, km))
+    fd = np.stack(cols, -1) / (2 * h)
+    assert dK.shape == fd.shape
+    assert np.allclose(dK, fd, rtol=1e-6, atol=1e-6 * np.abs(fd).max())
+
+
+def test_duo_solver_matches_two_single_solves():
+    case = MLGK['weighted']
+    G = graphs_from(case['graphs'])
+    knode = kernel_from_repr(case['knode'])
+    kedge = kernel_from_repr(case['kedge'])
+    s1, s2 = mgk._side(G[0]), mgk._side(G[1])
+    V = mgk.node_table(knode, s1, s2)
+    E = mgk.edge_table(kedge, s1, s2)
+    px = np.full((s1.n, s2.n), 1.7)
+    x, y, _ = mgk.solve_pair(s1, s2, V, E, 0.1, 'pcg64', rhs_extra=px)
+    xd, yd, _ = mgk.solve_pair(s1, s2, V, E, 0.1, 'dense', rhs_extra=px)
+    assert np.allclose(x, xd, rtol=1e-9) and np.allclose(y, yd, rtol=1e-9)
+
+
+def test_batched_tensorproduct_path_matches_generic():
+    import cases
+    G = cases.config3_graphs(12, seed=5)
+    knode, kedge, q = cases.config3_kernels()
+    batch = mgk.TensorProductBatch(G, knode, kedge)
+    i, j = np.triu_indices(len(G))
+    got, iters = batch.run(i, j, q=q, real='f64', tol=1e-13)
+    ref = mgk.gram(G, knode, kedge, q=q)
+    assert np.allclose(got, ref[i, j], rtol=1e-9)
+    got32, it32 = batch.run(i, j, q=q, real='f32')
+    assert np.allclose(got32, ref[i, j], rtol=1e-5)
+    assert it32.min() >= 1 and it32.max() < 100

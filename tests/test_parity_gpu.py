@@ -332,3 +332,31 @@ def test_qm7_like_sample(backend):
     mask = mlgk.active_theta_mask
     scale = np.abs(dRo[:, :, mask]).max(axis=(0, 1), keepdims=True)
     assert np.all(np.abs(dR - dRo[:, :, mask]) <= 2e-3 * scale)
+
+
+def test_fp64_build_vs_dense_oracle():
+    """Double-precision build (new capability, the reference is fp32 only):
+    rel 1e-9 on K against the dense fp64 oracle with ftol = 1e-13, on graphs
+    whose float attributes are stored as float64 columns."""
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    G = cases.config2_graphs(6, nmin=6, nmax=14, seed=4)
+    for g in G:
+        g.nodes['radius'] = np.asarray(g.nodes['radius'], dtype=np.float64)
+        g.edges['length'] = np.asarray(g.edges['length'], dtype=np.float64)
+        g.edges['!w'] = np.asarray(g.edges['!w'], dtype=np.float64)
+    G = Graph.unify_datatype(G)
+    knode = TensorProduct(radius=SquareExponential(0.5),
+                          category=KroneckerDelta(0.5))
+    kedge = TensorProduct(length=SquareExponential(1.0))
+    backend64 = HIPBackend(real=np.float64)
+    mlgk = MarginalizedGraphKernel(knode, kedge, q=0.05, ftol=1e-13,
+                                   backend=backend64)
+    R = mlgk(G)
+    ref = oracle.gram(G, knode, kedge, q=0.05)
+    assert R.dtype == np.float64
+    assert np.allclose(R, ref, rtol=1e-9, atol=0)
+    Rg, dR = mlgk(G[:3], eval_gradient=True)
+    Ro, dRo = oracle.gram(G[:3], knode, kedge, q=0.05, eval_gradient=True)
+    mask = mlgk.active_theta_mask
+    scale = np.abs(dRo[:, :, mask]).max(axis=(0, 1), keepdims=True)
+    assert np.all(np.abs(dR - dRo[:, :, mask]) <= 1e-7 * scale)
