@@ -219,6 +219,92 @@ struct pair_solver {
             for (int i = tid; i <= n2; i += T) lrp2[i] = g2.rowptr[i];
             job_sync<W>();
 
+            // ---- stage-1 nonzeros owned by this thread ------------------------
+            // batch kb = tasks [kb*T, kb*T + T); this lane's task is kb*T + tid.
+            // All lanes of a wave walk D = deg2(first task of the wave) slots
+            // per batch; the slot after which a batch ends is marked in `fm`.
+            // Pass 1 (index walk, needs only the CSR row pointers of G2 which
+            // were staged in LDS) records per slot the nonzero pair (a, b);
+            // pass 2 then issues all label loads back to back and evaluates
+            // the edge kernel.
+            real val[S];
+            unsigned adr[S];       // pass 1 scratch: (a << 16) | b, or ~0u
+            unsigned adr2[(S + 1) / 2];  // gather indices into p, two 16-bit per register
+            unsigned long long fm[NM];
+#pragma unroll
+            for (int w = 0; w < NM; ++w) fm[w] = 0;
+            int n_slots = 0;
+            {
+                // pass 0 (wave-uniform, rolled): depth of every batch of this
+                // wave -> flush mask and slot count
+                {
+                    divmod_walk tf(64 * wv, T, nnz1);      // first task of the wave
+#pragma nounroll
+                    for (int f = 64 * wv; f < ntask; f += T) {
+                        const int fi2 = uni(tf.hi);
+                        int D = uni(lrp2[fi2 + 1] - lrp2[fi2]);
+                        D = D < 1 ? 1 : D;
+                        n_slots += D;
+                        const int last = n_slots - 1;      // < S (host guarantees)
+#pragma unroll
+                        for (int w = 0; w < NM; ++w)
+                            if (last / 64 == w) fm[w] |= 1ull << (last % 64);
+                        tf.next();
+                    }
+                    n_slots = n_slots > S ? S : n_slots;
+                }
+                // pass 1 (unrolled, registers only + LDS row pointers): the
+                // nonzero pair of every slot of this lane
+                divmod_walk tk(tid, T, nnz1);          // per lane: (i2, a)
+                int kb = 0, d = 0;
+                auto open_task = [&]() -> task_t {
+                    task_t k;
+                    k.ok = kb * T + tid < ntask;
+                    k.i2 = k.ok ? tk.hi : 0;
+                    k.a = k.ok ? tk.lo : 0;
+                    k.rs2 = lrp2[k.i2];
+                    k.deg = k.ok ? lrp2[k.i2 + 1] - k.rs2 : 0;
+                    return k;
+                };
+                task_t cur = open_task();
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    adr[s] = (s < n_slots && cur.ok && d < cur.deg)
+                        ? ((unsigned)cur.a << 16) | (unsigned)(cur.rs2 + d) : ~0u;
+                    // materialise now: otherwise the select is sunk into pass 2
+                    // and a snapshot of the task state stays live per slot
+                    asm volatile("" : "+v"(adr[s]));
+                    ++d;
+                    if ((fm[s / 64] >> (s % 64)) & 1ull) {   // wave-uniform
+                        ++kb;
+                        tk.next();
+                        d = 0;
+                        cur = open_task();
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    // bound the loads in flight (and with them the live
+                    // registers) to SETUP_CHUNK slots
+                    if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
+                    const bool ok = adr[s] != ~0u;
+                    const int a = ok ? (int)(adr[s] >> 16) : 0, b = ok ? (int)(adr[s] & 0xFFFFu) : 0;
+                    const nz_t z1 = g1.nz[a], z2 = g2.nz[b];
+                    const edge_t e1 = g1.edge[a], e2 = g2.edge[b];
+                    const real e = prm.edge_kernel(e1, e2);
+                    val[s] = ok ? e : real(0);
+                    unsigned col = ok ? (unsigned)(z1.j * n2 + z2.j) : 0u;
+                    // pin the evaluation here: otherwise it is sunk below the
+                    // last chunk and every slot's raw labels stay live
+                    asm volatile("" : "+v"(val[s]), "+v"(col));
+                    if (s % 2 == 0) adr2[s / 2] = col;
+                    else adr2[s / 2] |= col << 16;
+                }
+            }
+            auto gather_index = [&](int s) -> unsigned {
+                return (s % 2 == 0) ? (adr2[s / 2] & 0xFFFFu) : (adr2[s / 2] >> 16);
+            };
+
             // ---- rows owned by this thread ------------------------------------
             // row i = k*T + tid = (i1, i2); Jacobi diagonal, start vectors, and
             // for stage 2 the first task index / trip count of the row.
@@ -259,82 +345,6 @@ struct pair_solver {
                     first.next();
                 }
             }
-
-            // ---- stage-1 nonzeros owned by this thread ------------------------
-            // batch kb = tasks [kb*T, kb*T + T); this lane's task is kb*T + tid.
-            // All lanes of a wave walk D = deg2(first task of the wave) slots
-            // per batch; the slot after which a batch ends is marked in `fm`.
-            // Pass 1 (index walk, needs only the CSR row pointers of G2 which
-            // were staged in LDS) records per slot the nonzero pair (a, b);
-            // pass 2 then issues all label loads back to back and evaluates
-            // the edge kernel.
-            real val[S];
-            unsigned adr[S];       // pass 1 scratch: (a << 16) | b, or ~0u
-            unsigned adr2[(S + 1) / 2];  // gather indices into p, two 16-bit per register
-            unsigned long long fm[NM];
-#pragma unroll
-            for (int w = 0; w < NM; ++w) fm[w] = 0;
-            int n_slots = 0;
-            {
-                divmod_walk tk(tid, T, nnz1);          // per lane: (i2, a)
-                divmod_walk tf(64 * wv, T, nnz1);      // first task of the wave (uniform)
-                int kb = 0;
-                auto batch_depth = [&]() -> int {
-                    if (kb * T + 64 * wv >= ntask) return 0;
-                    const int fi2 = uni(tf.hi);
-                    const int D = uni(lrp2[fi2 + 1] - lrp2[fi2]);
-                    return D < 1 ? 1 : D;
-                };
-                auto open_task = [&]() -> task_t {
-                    task_t k;
-                    k.ok = kb * T + tid < ntask;
-                    k.i2 = k.ok ? tk.hi : 0;
-                    k.a = k.ok ? tk.lo : 0;
-                    k.rs2 = lrp2[k.i2];
-                    k.deg = k.ok ? lrp2[k.i2 + 1] - k.rs2 : 0;
-                    return k;
-                };
-                int D = batch_depth(), d = 0;
-                task_t cur = open_task();
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    adr[s] = ~0u;
-                    if (D > 0) {   // wave-uniform
-                        if (cur.ok && d < cur.deg) adr[s] = ((unsigned)cur.a << 16) | (unsigned)(cur.rs2 + d);
-                        n_slots = s + 1;
-                        if (++d == D) {   // wave-uniform
-                            fm[s / 64] |= 1ull << (s % 64);
-                            ++kb;
-                            tk.next();
-                            tf.next();
-                            D = batch_depth();
-                            d = 0;
-                            cur = open_task();
-                        }
-                    }
-                }
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    // bound the loads in flight (and with them the live
-                    // registers) to SETUP_CHUNK slots
-                    if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
-                    const bool ok = adr[s] != ~0u;
-                    const int a = ok ? (int)(adr[s] >> 16) : 0, b = ok ? (int)(adr[s] & 0xFFFFu) : 0;
-                    const nz_t z1 = g1.nz[a], z2 = g2.nz[b];
-                    const edge_t e1 = g1.edge[a], e2 = g2.edge[b];
-                    const real e = prm.edge_kernel(e1, e2);
-                    val[s] = ok ? e : real(0);
-                    unsigned col = ok ? (unsigned)(z1.j * n2 + z2.j) : 0u;
-                    // pin the evaluation here: otherwise it is sunk below the
-                    // last chunk and every slot's raw labels stay live
-                    asm volatile("" : "+v"(val[s]), "+v"(col));
-                    if (s % 2 == 0) adr2[s / 2] = col;
-                    else adr2[s / 2] |= col << 16;
-                }
-            }
-            auto gather_index = [&](int s) -> unsigned {
-                return (s % 2 == 0) ? (adr2[s / 2] & 0xFFFFu) : (adr2[s / 2] >> 16);
-            };
 
             // ---- publish p ---------------------------------------------------
             job_sync<W>();  // everyone is done with the staged row pointers
