@@ -72,6 +72,7 @@ template<class real, class Graph, class NodeK, class EdgeK, class PStart> struct
     real *gramian;
     real *gradient;
     std::uint32_t *iters;        // optional per-job CG iteration counts
+    real *scratch;               // general solver only: per-workgroup CG scratch
     std::uint32_t n_launch_jobs;
     std::uint32_t nX, nY, nJ;
     std::uint32_t flags;
@@ -582,6 +583,268 @@ struct pair_solver {
                                 tk.next();
                                 cur = open_task();
                             }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < n_jac; ++j) {
+                    const real g = block_reduce<real, W>::sum(jac[j], red);
+                    if (tid == 0) {
+                        if (flags & F_PACKED) {
+                            prm.gradient[(size_t)(prm.order_offset + t) * n_jac + j] = g;
+                        } else if (flags & F_DIAGONAL) {
+                            prm.gradient[(size_t)I1 + (size_t)prm.nX * j] = g;
+                        } else {
+                            const size_t plane = (size_t)prm.nX * prm.nY;
+                            prm.gradient[(size_t)I1 + (size_t)prm.nX * I2 + plane * j] = g;
+                            if (mirror) prm.gradient[(size_t)I2 + (size_t)prm.nX * I1 + plane * j] = g;
+                        }
+                    }
+                }
+            }
+        }
+    }
+};
+
+
+// ---------------------------------------------------------------------------
+// General solver: any pair size.  One workgroup per pair; the CG vectors and
+// the stage-1 products U live in a per-workgroup global-memory scratch
+// (the role of the reference's PCGScratch, kernel/marginalized/_scratch.py:20-36,
+// marginalized_kernel.h:20-38) and the edge kernel is evaluated on the fly in
+// every iteration, like the reference does.  Same two-stage atomic-free
+// mat-vec, same iteration and stopping rules, same outputs as pair_solver;
+// used only for pairs that exceed the largest register-resident variant.
+// scratch layout per workgroup: [x | r | p | U] with x, r, p of N*C reals and
+// U of ntask*C reals (capacity passed in prm.u_capacity = reals per workgroup).
+// ---------------------------------------------------------------------------
+template<class real, int TPB, int C, class Graph, class NodeK, class EdgeK, class PStart>
+struct general_solver {
+    using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
+    using node_t = typename Graph::node_t;
+    using edge_t = typename Graph::edge_t;
+    constexpr static int W = TPB / 64;
+    constexpr static int n_jac = PStart::jac_dims + 1 + NodeK::jac_dims + EdgeK::jac_dims;
+    constexpr static int off_q = PStart::jac_dims;
+    constexpr static int off_v = off_q + 1;
+    constexpr static int off_e = off_v + NodeK::jac_dims;
+
+    struct lds_t {
+        real red[2 * W];
+    };
+
+    __device__ static __forceinline__ void run(P const &prm, lds_t &lds, real *scratch_all) {
+        const int tid = threadIdx.x;
+        real *const red = lds.red;
+        real *const scratch = scratch_all + (size_t)blockIdx.x * prm.u_capacity;
+        graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
+
+        for (unsigned t = blockIdx.x; t < prm.n_launch_jobs; t += gridDim.x) {
+            const unsigned job_id = prm.order[t];
+            const job_t job = prm.jobs[job_id];
+            const Graph g1(prm.arena, headers[job.i]);
+            const Graph g2(prm.arena, headers[job.j]);
+            const int n1 = g1.n_node, n2 = g2.n_node, N = n1 * n2;
+            const int nnz1 = g1.n_nz;
+            const long ntask = (long)nnz1 * n2;
+            const real q = prm.q, q0 = prm.q0;
+            const real inv1q2 = real(1) / ((real(1) - q) * (real(1) - q));
+            const real bscale = q * q / (q0 * q0);
+            real *const X = scratch;
+            real *const Rv = X + (size_t)N * C;
+            real *const Pv = Rv + (size_t)N * C;
+            real *const U = Pv + (size_t)N * C;
+
+            auto diag = [&](int i, real &dg, real &mi) {
+                const int i1 = i / n2, i2 = i - i1 * n2;
+                const real dx = real(g1.degree[i1]) * real(g2.degree[i2]) * inv1q2;
+                const real vx = prm.node_kernel(g1.node[i1], g2.node[i2]);
+                dg = dx / vx;
+                mi = vx / dx;
+            };
+
+            __syncthreads();   // previous pair is done with the scratch
+            real rTz = 0;
+            for (int i = tid; i < N; i += TPB) {
+                const int i1 = i / n2, i2 = i - i1 * n2;
+                real dg, mi;
+                diag(i, dg, mi);
+                const real dx = real(g1.degree[i1]) * real(g2.degree[i2]) * inv1q2;
+                real b[C];
+                b[0] = dx * bscale;
+                if constexpr (C == 2)
+                    b[1] = real(prm.p_start(g1.node[i1])) * real(prm.p_start(g2.node[i2]));
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    X[(size_t)i * C + c] = 0;
+                    Rv[(size_t)i * C + c] = b[c];
+                    Pv[(size_t)i * C + c] = b[c] * mi;
+                    rTz += b[c] * b[c] * mi;
+                }
+            }
+            rTz = block_reduce<real, W>::sum(rTz, red);
+
+            const real tol = (C == 2) ? real(1e-10) * real(2 * N) : prm.ftol * real(N);
+            const real tol2 = tol * tol;
+            unsigned it = 0;
+            for (; it < (unsigned)N && rTz != real(0); ++it) {
+                __syncthreads();
+                // stage 1
+                for (long tk = tid; tk < ntask; tk += TPB) {
+                    const int i2 = (int)(tk / nnz1), a = (int)(tk - (long)i2 * nnz1);
+                    const nz_t z1 = g1.nz[a];
+                    const edge_t e1 = g1.edge[a];
+                    real acc[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] = 0;
+                    for (int b = g2.rowptr[i2]; b < (int)g2.rowptr[i2 + 1]; ++b) {
+                        const real e = prm.edge_kernel(e1, g2.edge[b]);
+                        const size_t col = (size_t)z1.j * n2 + g2.nz[b].j;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] += e * Pv[col * C + c];
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) U[(size_t)tk * C + c] = acc[c];
+                }
+                __syncthreads();
+                // stage 2 + p.Ap ; Ap is kept in U's own rows? no: recomputed below
+                real pAp = 0;
+                for (int i = tid; i < N; i += TPB) {
+                    const int i1 = i / n2, i2 = i - i1 * n2;
+                    real dg, mi;
+                    diag(i, dg, mi);
+                    real acc[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] = 0;
+                    for (int a = g1.rowptr[i1]; a < (int)g1.rowptr[i1 + 1]; ++a)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] += U[((size_t)i2 * nnz1 + a) * C + c];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const real pv = Pv[(size_t)i * C + c];
+                        pAp += pv * (dg * pv - acc[c]);
+                    }
+                }
+                pAp = block_reduce<real, W>::sum(pAp, red);
+                if (pAp == real(0)) break;
+                const real alpha = rTz / pAp;
+                real rTr = 0, rTz_next = 0;
+                // x, r update (Ap recomputed from U: U is still valid)
+                for (int i = tid; i < N; i += TPB) {
+                    const int i1 = i / n2, i2 = i - i1 * n2;
+                    real dg, mi;
+                    diag(i, dg, mi);
+                    real acc[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] = 0;
+                    for (int a = g1.rowptr[i1]; a < (int)g1.rowptr[i1 + 1]; ++a)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] += U[((size_t)i2 * nnz1 + a) * C + c];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const size_t k = (size_t)i * C + c;
+                        const real pv = Pv[k];
+                        const real Ap = dg * pv - acc[c];
+                        X[k] += alpha * pv;
+                        const real rv = Rv[k] - alpha * Ap;
+                        Rv[k] = rv;
+                        rTr += rv * rv;
+                        rTz_next += rv * rv * mi;
+                    }
+                }
+                block_reduce<real, W>::sum2(rTr, rTz_next, red);
+                if (rTr < tol2) {
+                    ++it;
+                    break;
+                }
+                const real beta = rTz_next / rTz;
+                for (int i = tid; i < N; i += TPB) {
+                    real dg, mi;
+                    diag(i, dg, mi);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const size_t k = (size_t)i * C + c;
+                        Pv[k] = mi * Rv[k] + beta * Pv[k];
+                    }
+                }
+                rTz = rTz_next;
+            }
+            __syncthreads();
+            if (prm.iters != nullptr && tid == 0) prm.iters[job_id] = it;
+
+            // ---- output (same conventions as pair_solver) ----------------------
+            const unsigned flags = prm.flags;
+            const unsigned I1 = prm.starts[job.i], I2 = prm.starts[job.j];
+            const bool mirror = (flags & F_SYMMETRIC) && job.i != job.j;
+            real ksum = 0;
+            for (int i = tid; i < N; i += TPB) {
+                const int i1 = i / n2, i2 = i - i1 * n2;
+                const node_t v1 = g1.node[i1], v2 = g2.node[i2];
+                real xi = X[(size_t)i * C];
+                if (flags & F_LMIN1) xi -= real(prm.node_kernel(v1, v2)) * bscale;
+                const real rv = xi * real(prm.p_start(v1)) * real(prm.p_start(v2));
+                ksum += rv;
+                if (flags & F_NODAL) {
+                    const unsigned o1 = g1.perm[i1], o2 = g2.perm[i2];
+                    if (flags & F_BLOCK) {
+                        prm.gramian[I1 + o1 + o2 * n2] = rv;
+                    } else if (flags & F_DIAGONAL) {
+                        if (o1 == o2) prm.gramian[I1 + o1] = rv;
+                    } else {
+                        prm.gramian[(size_t)(I1 + o1) + (size_t)prm.nX * (I2 + o2)] = rv;
+                        if (mirror) prm.gramian[(size_t)(I2 + o2) + (size_t)prm.nX * (I1 + o1)] = rv;
+                    }
+                }
+            }
+            if (!(flags & F_NODAL)) {
+                ksum = block_reduce<real, W>::sum(ksum, red);
+                if (tid == 0) {
+                    if (flags & F_PACKED) {
+                        prm.gramian[prm.order_offset + t] = ksum;
+                    } else if (flags & F_DIAGONAL) {
+                        prm.gramian[I1] = ksum;
+                    } else {
+                        prm.gramian[(size_t)I1 + (size_t)prm.nX * I2] = ksum;
+                        if (mirror) prm.gramian[(size_t)I2 + (size_t)prm.nX * I1] = ksum;
+                    }
+                }
+            }
+
+            if constexpr (C == 2) {
+                real jac[n_jac];
+#pragma unroll
+                for (int j = 0; j < n_jac; ++j) jac[j] = 0;
+                const real Q = real(1) / (real(1) - q), Q3 = Q * Q * Q;
+                for (int i = tid; i < N; i += TPB) {
+                    const int i1 = i / n2, i2 = i - i1 * n2;
+                    const node_t v1 = g1.node[i1], v2 = g2.node[i2];
+                    const real p1 = prm.p_start(v1), p2 = prm.p_start(v2);
+                    const real dox = real(g1.degree[i1]) * real(g2.degree[i2]);
+                    const real dx = dox * inv1q2;
+                    const real v = prm.node_kernel(v1, v2);
+                    const real YDq = X[(size_t)i * 2], Yp = X[(size_t)i * 2 + 1];
+                    auto dp1 = prm.p_start._j_a_c_o_b_i_a_n_(v1);
+                    auto dp2 = prm.p_start._j_a_c_o_b_i_a_n_(v2);
+                    auto dv = prm.node_kernel._j_a_c_o_b_i_a_n_(v1, v2);
+#pragma unroll
+                    for (int j = 0; j < PStart::jac_dims; ++j)
+                        jac[j] += (real(dp1[j]) * p2 + p1 * real(dp2[j])) * YDq;
+                    jac[off_q] += real(2) * Q * p1 * p2 * YDq - real(2) * Q3 * Yp * dox / v * YDq;
+#pragma unroll
+                    for (int j = 0; j < NodeK::jac_dims; ++j)
+                        jac[off_v + j] += dx * Yp * YDq / (v * v) * real(dv[j]);
+                }
+                if constexpr (EdgeK::jac_dims > 0) {
+                    for (long tk = tid; tk < ntask; tk += TPB) {
+                        const int i2 = (int)(tk / nnz1), a = (int)(tk - (long)i2 * nnz1);
+                        const nz_t z1 = g1.nz[a];
+                        const edge_t e1 = g1.edge[a];
+                        const real Yp = X[((size_t)z1.i * n2 + i2) * 2 + 1];
+                        for (int b = g2.rowptr[i2]; b < (int)g2.rowptr[i2 + 1]; ++b) {
+                            auto de = prm.edge_kernel._j_a_c_o_b_i_a_n_(e1, g2.edge[b]);
+                            const real w = Yp * X[((size_t)z1.j * n2 + g2.nz[b].j) * 2];
+#pragma unroll
+                            for (int j = 0; j < EdgeK::jac_dims; ++j) jac[off_e + j] += w * real(de[j]);
                         }
                     }
                 }

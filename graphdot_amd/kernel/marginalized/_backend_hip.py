@@ -41,6 +41,9 @@ VARIANTS = [
     Variant(16, 16, 2), Variant(16, 32, 4), Variant(16, 64, 8),
     Variant(16, 128, 16),
 ]
+#: sentinel: the global-memory general solver (any pair size)
+GENERAL = Variant(0, 0, 0)
+GENERAL_THREADS = 1024
 LDS_LIMIT = 160 * 1024
 
 
@@ -169,7 +172,7 @@ class HIPBackend(Backend):
         self.real = np.dtype(kwargs.pop('real', np.float32)).type
         self.jobs_per_unit = kwargs.pop('jobs_per_unit', 8)
         self.hipcc_extra = list(kwargs.pop('hipcc_extra', []))
-        self.variants = list(kwargs.pop('variants', VARIANTS))
+        self.variants = list(kwargs.pop('variants', VARIANTS + [GENERAL]))
         self.record_iterations = kwargs.pop('record_iterations', False)
         self.occupancy = kwargs.pop('occupancy', None)
         if self.occupancy is None and os.environ.get('GD_OCCUPANCY'):
@@ -327,7 +330,7 @@ struct ${name}_t : ${name}_theta_t {
         P = np.uintp
         return np.dtype([
             ('arena', P), ('jobs', P), ('order', P), ('starts', P),
-            ('gramian', P), ('gradient', P), ('iters', P),
+            ('gramian', P), ('gradient', P), ('iters', P), ('scratch', P),
             ('n_launch_jobs', np.uint32), ('nX', np.uint32),
             ('nY', np.uint32), ('nJ', np.uint32), ('flags', np.uint32),
             ('order_offset', np.uint32), ('u_capacity', np.uint32),
@@ -340,6 +343,8 @@ struct ${name}_t : ${name}_theta_t {
 
     @staticmethod
     def kernel_name(v, C):
+        if v == GENERAL:
+            return f'mgk_general_T{GENERAL_THREADS}_C{C}'
         return f'mgk_W{v.W}_S{v.S}_R{v.R}_C{C}'
 
     def waves_per_eu(self, v, C):
@@ -359,6 +364,16 @@ struct ${name}_t : ${name}_theta_t {
         return max(1, floor)
 
     def _entry_point(self, v, C):
+        if v == GENERAL:
+            return Template(r'''
+extern "C" __global__ __launch_bounds__(${threads})
+void ${name}(params_t prm) {
+    using solver = graphdot::mgk::general_solver<real_t, ${threads}, ${C},
+        graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
+    __shared__ typename solver::lds_t lds;
+    solver::run(prm, lds, prm.scratch);
+}
+''').render(threads=GENERAL_THREADS, name=self.kernel_name(v, C), C=C)
         threads = 64 * v.W * (4 if v.W == 1 else 1)
         return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
@@ -452,6 +467,8 @@ void ${name}(params_t prm) {
             todo = choice < 0
             if not todo.any():
                 break
+            if v == GENERAL:
+                continue
             fits = (todo & (N <= 64 * v.W * v.R) & (N <= 0xFFFF)
                     & (self.lds_bytes(v, C, ntask) <= LDS_LIMIT))
             if not fits.any():
@@ -465,12 +482,15 @@ void ${name}(params_t prm) {
             fits &= slots[v.W] <= v.S
             choice[fits] = k
         if np.any(choice < 0):
-            bad = int(np.argmax(choice < 0))
-            raise NotImplementedError(
-                f'graph pair ({ji[bad]}, {jj[bad]}) with {n1[bad]}x{n2[bad]} '
-                f'nodes and {nnz1[bad]}x{n_nz[jj[bad]]} adjacency nonzeros '
-                'exceeds the largest register-resident solver variant; the '
-                'global-memory fallback is not built yet')
+            if GENERAL not in self.variants:
+                bad = int(np.argmax(choice < 0))
+                raise NotImplementedError(
+                    f'graph pair ({ji[bad]}, {jj[bad]}) with '
+                    f'{n1[bad]}x{n2[bad]} nodes and {nnz1[bad]}x'
+                    f'{n_nz[jj[bad]]} adjacency nonzeros exceeds the largest '
+                    'register-resident solver variant and the general '
+                    'solver is disabled')
+            choice[choice < 0] = self.variants.index(GENERAL)
         return choice, cost, ntask
 
     # -- the three phases -----------------------------------------------------------
@@ -491,8 +511,9 @@ void ${name}(params_t prm) {
 
         if traits.eval_gradient is True and traits.nodal is not False:
             raise NotImplementedError(
-                'nodal gradients (finite-difference path of the reference, '
-                'template.cu:226-418) are not built yet')
+                'nodal gradients are evaluated by finite differences over '
+                'value launches (HIPBackend._nodal_gradient), not by a '
+                'gradient plan')
         C = 2 if traits.eval_gradient is True else 1
 
         tic('code generation')
@@ -563,12 +584,27 @@ void ${name}(params_t prm) {
         plan.n_grad = n_out * plan.nJ if C == 2 else 0
 
         order_all = np.empty(len(jobs), dtype=np.uint32)
+        ji = jobs['i'].astype(np.int64)
+        jj = jobs['j'].astype(np.int64)
         launches, cursor = [], 0
         for k in used:
             v = self.variants[k]
             idx = np.flatnonzero(choice == k)
             idx = idx[np.argsort(-cost[idx], kind='stable')]
             order_all[cursor:cursor + len(idx)] = idx.astype(np.uint32)
+            fn = modules[k].function(self.kernel_name(v, C))
+            if v == GENERAL:
+                # one workgroup per pair, CG vectors + U in global scratch
+                N_ = (arena.n_node[ji[idx]] * arena.n_node[jj[idx]])
+                per_wg = int(((3 * N_ + ntask[idx]) * C).max())
+                grid = int(min(len(idx), 2 * self.props.compute_units))
+                launches.append(dict(
+                    variant=v, k=k, offset=cursor, ucap=per_wg, dynamic_lds=0,
+                    count=len(idx), grid=grid, threads=GENERAL_THREADS,
+                    fn=fn, module=modules[k],
+                    scratch_bytes=grid * per_wg * rsize))
+                cursor += len(idx)
+                continue
             wpb = 4 if v.W == 1 else 1
             threads = 64 * v.W * wpb
             # Many small workgroups (a few pairs per wave) rather than one
@@ -580,7 +616,6 @@ void ${name}(params_t prm) {
             grid = int(max(1, -(-len(idx) // (wpb * per_unit))))
             ucap = int(-(-ntask[idx].max() // 64) * 64)
             dyn = ucap * C * wpb * rsize
-            fn = modules[k].function(self.kernel_name(v, C))
             if dyn > 64 * 1024:
                 runtime.set_max_dynamic_lds(fn, dyn)
             launches.append(dict(variant=v, k=k, offset=cursor, ucap=ucap,
@@ -601,6 +636,10 @@ void ${name}(params_t prm) {
             if C == 2 else None
         b_iters = self._buffer('iters', 4 * len(jobs)) \
             if self.record_iterations else None
+        scratch_bytes = max([L.get('scratch_bytes', 0) for L in launches]
+                            + [0])
+        b_scratch = self._buffer('scratch', scratch_bytes) \
+            if scratch_bytes else None
         b_jobs.upload(jobs.view(np.uint32))
         b_order.upload(order_all)
         b_starts.upload(np.ascontiguousarray(starts, dtype=np.uint32))
@@ -616,6 +655,7 @@ void ${name}(params_t prm) {
         base['gramian'] = b_out.ptr
         base['gradient'] = b_grad.ptr if b_grad is not None else 0
         base['iters'] = b_iters.ptr if b_iters is not None else 0
+        base['scratch'] = b_scratch.ptr if b_scratch is not None else 0
         base['nX'], base['nY'], base['nJ'] = plan.nX, plan.nY, plan.nJ
         base['flags'] = flags
         base['q'] = q
@@ -680,10 +720,104 @@ void ${name}(params_t prm) {
         plan.buffers['iters'].download(it)
         return it
 
+    # -- nodal gradients: central finite differences in log-theta ----------------------
+    def _nodal_gradient(self, graphs, node_kernel, edge_kernel, p, q, eps,
+                        ftol, gtol, jobs, starts, gramian, gradient, nX, nY,
+                        nJ, traits, timer):
+        """Value + Jacobian of nodal outputs, as the reference defines them
+        (template.cu:226-418): d/dp analytic, d/dq, d/d(node theta),
+        d/d(edge theta) by central differences of re-solves at
+        exp(log(theta) +- eps).  The reference warm-starts those re-solves
+        in-kernel with tolerance gtol; here each perturbed system is a fresh
+        value launch (hyperparameters are kernel arguments, no recompilation),
+        which converges to the same differences."""
+        def solve(nk, ek, qq, lmin):
+            tr = traits._replace(eval_gradient=False, lmin=lmin)
+            plan = self.prepare(graphs, nk, ek, p, qq, eps, ftol, gtol, jobs,
+                                starts, nX, nY, nJ, tr, None)
+            self.launch(plan)
+            out, _ = self.collect(plan)
+            return out.astype(np.float64)
+
+        value = solve(node_kernel, edge_kernel, q, traits.lmin)
+        gramian[:] = value
+        shape = (nX, nJ) if traits.diagonal else (nX, nY, nJ)
+        J = np.zeros(shape, dtype=np.float64, order='F')
+        K = value.reshape(shape[:-1], order='F')
+
+        # d/dp (analytic): K_nodal * (dp1/p1 + dp2/p2)   (template.cu:258-284)
+        def node_p(gs):
+            pv, dpv = [], []
+            for g in gs:
+                order = np.argsort(np.asarray(g.nodes['!i']))
+                a, b = p(g.nodes)
+                a = np.asarray(a, dtype=float)[order]
+                b = np.asarray(b, dtype=float)
+                b = b[:, order] if b.size else np.zeros((0, len(order)))
+                pv.append(a)
+                dpv.append(b)
+            return np.concatenate(pv), np.concatenate(dpv, axis=1)
+        n_p = len(list(flatten(p.theta)))
+        if traits.diagonal or traits.symmetric:
+            px, dpx = node_p(graphs)
+            py, dpy = px, dpx
+        else:
+            sizes = np.array([len(g.nodes) for g in graphs])
+            split = int(np.searchsorted(np.cumsum(sizes), nX, side='left')) + 1
+            px, dpx = node_p(graphs[:split])
+            py, dpy = node_p(graphs[split:])
+        for j in range(n_p):
+            if traits.diagonal:
+                J[:, j] = K * 2 * dpx[j] / px
+            else:
+                J[:, :, j] = K * ((dpx[j] / px)[:, None]
+                                  + (dpy[j] / py)[None, :])
+        col = n_p
+
+        def central(plus, minus, denom):
+            nonlocal col
+            d = (solve(*plus, 0) - solve(*minus, 0)) / denom
+            J[..., col] = d.reshape(shape[:-1], order='F')
+            col += 1
+
+        central((node_kernel, edge_kernel, float(np.exp(np.log(q) + eps))),
+                (node_kernel, edge_kernel, float(np.exp(np.log(q) - eps))),
+                2 * eps * q)
+        for which, kern in (('node', node_kernel), ('edge', edge_kernel)):
+            theta = np.array(list(flatten(kern.theta)), dtype=float)
+            for j in range(len(theta)):
+                pair = []
+                for delta in (eps, -eps):
+                    k2 = copy.deepcopy(kern)
+                    t = np.log(theta)
+                    t[j] += delta
+                    k2.theta = fold_like(np.exp(t), k2.theta)
+                    pair.append(k2)
+                if which == 'node':
+                    central((pair[0], edge_kernel, q),
+                            (pair[1], edge_kernel, q), 2 * eps * theta[j])
+                else:
+                    central((node_kernel, pair[0], q),
+                            (node_kernel, pair[1], q), 2 * eps * theta[j])
+        assert col == nJ, (col, nJ)
+        gradient[:] = J.ravel(order='F')
+
     # -- the reference's backend call ---------------------------------------------------
     def __call__(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol,
                  gtol, jobs, starts, gramian, gradient, nX, nY, nJ, traits,
                  timer):
+        if traits.eval_gradient is True and traits.nodal is True:
+            timer.tic('GPU kernel execution')
+            self._nodal_gradient(graphs, node_kernel, edge_kernel, p, q, eps,
+                                 ftol, gtol, jobs, starts, gramian, gradient,
+                                 nX, nY, nJ, traits, timer)
+            timer.toc('GPU kernel execution')
+            return
+        if traits.eval_gradient is True and traits.nodal == 'block':
+            # the reference computes no gradient in this mode either
+            # (template.cu:226,422: neither branch is compiled for 'block')
+            traits = traits._replace(eval_gradient=False)
+            gradient = None
         plan = self.prepare(graphs, node_kernel, edge_kernel, p, q, eps, ftol,
                             gtol, jobs, starts, nX, nY, nJ, traits, timer)
         timer.tic('GPU kernel execution')

@@ -360,3 +360,80 @@ def test_fp64_build_vs_dense_oracle():
     mask = mlgk.active_theta_mask
     scale = np.abs(dRo[:, :, mask]).max(axis=(0, 1), keepdims=True)
     assert np.all(np.abs(dR - dRo[:, :, mask]) <= 1e-7 * scale)
+
+
+@pytest.mark.parametrize('name', FAMILIES)
+def test_nodal_gradient_finite_differences(backend, name):
+    """Nodal Jacobians (template.cu:226-418) against the oracle's restatement
+    of the same central differences with fp64 dense solves; tolerance of the
+    reference's own test (test_kernel.py:289): rtol = atol = 0.05, plus our
+    tighter bar of 1 % of the column scale."""
+    G, knode, kedge, case = family(name)
+    q = 0.05
+    mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    R, dR = mlgk(G, nodal=True, eval_gradient=True)
+    Ro, dRo = oracle.gram(G, knode, kedge, q=q, nodal=True,
+                          eval_gradient=True, eps=mlgk.eps)
+    mask = mlgk.active_theta_mask
+    assert np.allclose(R, Ro, rtol=1e-5)
+    ref = dRo[:, :, mask]
+    assert dR.shape == ref.shape
+    assert np.allclose(dR, ref, rtol=0.05, atol=0.05)
+    scale = np.abs(ref).max(axis=(0, 1), keepdims=True)
+    assert np.all(np.abs(dR - ref) <= 1e-2 * scale + 1e-4)
+    D, dD = mlgk.diag(G, nodal=True, eval_gradient=True)
+    assert np.allclose(D, np.diag(R), rtol=1e-6)
+    for k in range(dD.shape[1]):
+        assert np.allclose(dD[:, k], np.diag(dR[:, :, k]), rtol=1e-4,
+                           atol=1e-4 * float(scale[0, 0, k]))
+    Rx, dRx = mlgk(G[:1], G[1:], nodal=True, eval_gradient=True)
+    n0 = len(G[0].nodes)
+    assert np.allclose(Rx, R[:n0, n0:], rtol=1e-5)
+    assert np.allclose(dRx, dR[:n0, n0:, :], rtol=1e-3,
+                       atol=1e-3 * float(scale.max()))
+
+
+def test_general_solver_matches_register_solver():
+    """The global-scratch general solver (any pair size) on the reference
+    families, forced by removing every register-resident variant."""
+    from graphdot_amd.kernel.marginalized._backend_hip import (
+        HIPBackend, GENERAL)
+    general = HIPBackend(variants=[GENERAL], record_iterations=True)
+    for name in FAMILIES:
+        G, knode, kedge, case = family(name)
+        mlgk = MarginalizedGraphKernel(knode, kedge, q=0.05, backend=general)
+        R, dR = mlgk(G, eval_gradient=True)
+        Ro, dRo = oracle.gram(G, knode, kedge, q=0.05, eval_gradient=True)
+        assert np.allclose(R, Ro, rtol=1e-5)
+        mask = mlgk.active_theta_mask
+        scale = np.abs(dRo[:, :, mask]).max(axis=(0, 1), keepdims=True)
+        assert np.all(np.abs(dR - dRo[:, :, mask]) <= 2e-3 * scale + 1e-6)
+        Rn = mlgk(G, nodal=True, lmin=1)
+        assert np.allclose(Rn, oracle.gram(G, knode, kedge, q=0.05,
+                                           nodal=True, lmin=1),
+                           rtol=1e-5, atol=1e-5)
+
+
+def test_large_pair_goes_to_general_solver(backend):
+    """A 300 x 280 node pair (N = 84 000 product rows) exceeds every
+    register-resident variant; checked against the C restatement of the
+    reference PCG in fp64."""
+    G = cases.config2_graphs(2, nmin=280, nmax=300, seed=9)
+    knode, kedge, q = cases.config2b_kernels()
+    mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    R = mlgk(G)
+    names = {backend.kernel_name(L['variant'], 1)
+             for L in backend.last_plan.launches}
+    assert any('general' in n for n in names), names
+    ref = np.zeros((2, 2))
+    for a in range(2):
+        for b in range(a, 2):
+            s1, s2 = oracle._side(G[a]), oracle._side(G[b])
+            V = np.array([[knode(r1, r2) for r2 in s2.node_rows]
+                          for r1 in s1.node_rows])
+            L = np.array([r.length for r in s1.edge_rows])[:, None]
+            M = np.array([r.length for r in s2.edge_rows])[None, :]
+            E = np.exp(-0.5 * (L - M)**2) * s1.ew[:, None] * s2.ew[None, :]
+            x, _, _ = oracle.solve_pair(s1, s2, V, E, q, 'pcg64', tol=1e-13)
+            ref[a, b] = ref[b, a] = x.sum()
+    assert np.allclose(R, ref, rtol=2e-5)
