@@ -160,9 +160,10 @@ struct pair_solver {
     constexpr static int NV = R * T;   // capacity of p (rows)
     constexpr static int WPB = (W == 1) ? 4 : 1;  // independent pairs per workgroup
     constexpr static int threads = 64 * W * WPB;
-    constexpr static int NM = (S + 63) / 64;      // 64-bit flush-mask words
+    constexpr static int NM = (S + 31) / 32;      // 32-bit flush-mask words
     constexpr static int SETUP_CHUNK = 4;
     constexpr static int GCH = 8;                 // stage-1 gathers in flight
+    constexpr static int ZPAD = 64;               // zero entries at the end of U
     constexpr static int n_jac = PStart::jac_dims + 1 + NodeK::jac_dims + EdgeK::jac_dims;
     constexpr static int off_q = PStart::jac_dims;
     constexpr static int off_v = off_q + 1;
@@ -218,6 +219,13 @@ struct pair_solver {
             for (int i = tid; i <= n1; i += T) lrp1[i] = g1.rowptr[i];
 #pragma nounroll
             for (int i = tid; i <= n2; i += T) lrp2[i] = g2.rowptr[i];
+            // the last ZPAD entries of the U region stay zero: rows past N
+            // point there, so stage 2 can read without a per-lane mask
+            const int zbase = (int)prm.u_capacity - ZPAD;
+            if (tid < ZPAD) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) lU[(zbase + tid) * C + c] = 0;
+            }
             job_sync<W>();
 
             // ---- stage-1 nonzeros owned by this thread ------------------------
@@ -231,7 +239,7 @@ struct pair_solver {
             real val[S];
             unsigned adr[S];       // pass 1 scratch: (a << 16) | b, or ~0u
             unsigned adr2[(S + 1) / 2];  // gather indices into p, two 16-bit per register
-            unsigned long long fm[NM];
+            unsigned fm[NM];
 #pragma unroll
             for (int w = 0; w < NM; ++w) fm[w] = 0;
             int n_slots = 0;
@@ -249,7 +257,7 @@ struct pair_solver {
                         const int last = n_slots - 1;      // < S (host guarantees)
 #pragma unroll
                         for (int w = 0; w < NM; ++w)
-                            if (last / 64 == w) fm[w] |= 1ull << (last % 64);
+                            if (last / 32 == w) fm[w] |= 1u << (last % 32);
                         tf.next();
                     }
                     n_slots = n_slots > S ? S : n_slots;
@@ -276,7 +284,7 @@ struct pair_solver {
                     // and a snapshot of the task state stays live per slot
                     asm volatile("" : "+v"(adr[s]));
                     ++d;
-                    if ((fm[s / 64] >> (s % 64)) & 1ull) {   // wave-uniform
+                    if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
                         ++kb;
                         tk.next();
                         d = 0;
@@ -289,7 +297,7 @@ struct pair_solver {
                     // registers) to SETUP_CHUNK slots
                     if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
                     const bool ok = adr[s] != ~0u;
-                    const int a = ok ? (int)(adr[s] >> 16) : 0, b = ok ? (int)(adr[s] & 0xFFFFu) : 0;
+                    const unsigned a = ok ? (adr[s] >> 16) : 0u, b = ok ? (adr[s] & 0xFFFFu) : 0u;
                     const nz_t z1 = g1.nz[a], z2 = g2.nz[b];
                     const edge_t e1 = g1.edge[a], e2 = g2.edge[b];
                     const real e = prm.edge_kernel(e1, e2);
@@ -325,7 +333,7 @@ struct pair_solver {
                     dg[k] = ok ? dx / vx : real(0);
                     mi[k] = ok ? vx / dx : real(0);
                     const int rs = lrp1[i1];
-                    ubase[k] = i2 * nnz1 + rs;
+                    ubase[k] = ok ? i2 * nnz1 + rs : zbase;
                     udeg[k] = ok ? lrp1[i1 + 1] - rs : 0;
                     // rows of one wave are consecutive: the first has the largest degree
                     const int f1 = uni(first.hi);
@@ -345,6 +353,19 @@ struct pair_solver {
                     row.next();
                     first.next();
                 }
+            }
+
+            // smallest degree among this wave's live rows = degree of its last
+            // live row (rows are dealt in descending-degree order)
+            int Dmin = 0;
+            if (64 * wv < N) {
+                const int kl = (N - 1 - 64 * wv) / T;
+                int il = kl * T + 64 * wv + 63;
+                il = il < N ? il : N - 1;
+                divmod_walk last(il, 0, n2);
+                const int i1l = uni(last.hi);
+                Dmin = uni(lrp1[i1l + 1] - lrp1[i1l]);
+                Dmin = Dmin < ZPAD ? Dmin : ZPAD;
             }
 
             // ---- publish p ---------------------------------------------------
@@ -371,7 +392,7 @@ struct pair_solver {
                     int kb = 0;
                     // keep the flush mask as data (s_bitcmp per slot) instead of
                     // letting LICM expand it into S precomputed SGPR pairs
-                    unsigned long long fmv[NM];
+                    unsigned fmv[NM];
 #pragma unroll
                     for (int w = 0; w < NM; ++w) {
                         fmv[w] = fm[w];
@@ -391,7 +412,7 @@ struct pair_solver {
                             if (s < S) {
 #pragma unroll
                                 for (int c = 0; c < C; ++c) acc[c] += val[s] * g[c][j];
-                                if ((fmv[s / 64] >> (s % 64)) & 1ull) {   // wave-uniform
+                                if ((fmv[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
 #pragma unroll
                                     for (int c = 0; c < C; ++c) {
                                         lU[(kb * T + tid) * C + c] = acc[c];
@@ -413,8 +434,25 @@ struct pair_solver {
                     for (int k = 0; k < R; ++k)
 #pragma unroll
                         for (int c = 0; c < C; ++c) acc[c][k] = 0;
-                    // D1[0] >= D1[k]: rows are dealt in descending-degree order
-                    for (int d = 0; d < D1[0]; ++d) {   // wave-uniform trip count
+                    // D1[0] >= D1[k]: rows are dealt in descending-degree order;
+                    // below Dmin every live row of the wave has an entry, so
+                    // those reads need no per-lane mask (rows past N read
+                    // in-range garbage that is multiplied by dg = 0 ... never
+                    // used: their Ap is discarded through p = 0)
+                    int d = 0;
+                    for (; d < Dmin; ++d) {   // wave-uniform trip count
+                        real u[C][R];
+#pragma unroll
+                        for (int k = 0; k < R; ++k)
+#pragma unroll
+                            for (int c = 0; c < C; ++c)
+                                u[c][k] = lU[(ubase[k] + d) * C + c];
+#pragma unroll
+                        for (int k = 0; k < R; ++k)
+#pragma unroll
+                            for (int c = 0; c < C; ++c) acc[c][k] += u[c][k];
+                    }
+                    for (; d < D1[0]; ++d) {   // wave-uniform trip count
                         real u[C][R];
 #pragma unroll
                         for (int k = 0; k < R; ++k)
@@ -577,7 +615,7 @@ struct pair_solver {
 #pragma unroll
                             for (int j = 0; j < EdgeK::jac_dims; ++j) jac[off_e + j] += w * real(de[j]);
                             ++d;
-                            if ((fm[s / 64] >> (s % 64)) & 1ull) {   // wave-uniform
+                            if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
                                 ++kb;
                                 d = 0;
                                 tk.next();

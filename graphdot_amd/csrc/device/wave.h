@@ -20,17 +20,32 @@ template<int CTRL> __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(t);
 }
 
+template<int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_add_masked(float v) {
+    // lanes outside ROW_MASK keep v (old = v, bound_ctrl off)
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true);
+    return v + __int_as_float(t);
+}
+
 // Sum over the 64 lanes; every lane gets the same (bitwise identical) total.
+// 4 DPP steps give every lane its 16-lane row sum; row_bcast15 / row_bcast31
+// (gfx9 wave-level DPP) then chain the four rows into lane 63, which is read
+// back through an SGPR: 6 VALU + 1 v_readlane.
 __device__ __forceinline__ float sum(float v) {
     v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
     v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
     v = dpp_add<0x141>(v);  // row_half_mirror : 8-lane sums
-    v = dpp_add<0x140>(v);  // row_mirror      : 16-lane sums
-    float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    float s2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    float s3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return (s0 + s1) + (s2 + s3);
+    v = dpp_add<0x140>(v);  // row_mirror      : 16-lane sums in every lane
+    // row_bcast:15 -> rows 1 and 3 add the total of the previous row
+    {
+        int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false);
+        v += __int_as_float(t);
+    }
+    // row_bcast:31 -> rows 2 and 3 add lane 31 (= rows 0 + 1)
+    {
+        int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false);
+        v += __int_as_float(t);
+    }
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ double sum(double v) {

@@ -420,7 +420,7 @@ void ${name}(params_t prm) {
         """LDS bytes of one workgroup: static p + scratch, dynamic U."""
         wpb = 4 if v.W == 1 else 1
         T = 64 * v.W
-        ucap = -(-np.asarray(ntask) // 64) * 64
+        ucap = -(-np.asarray(ntask) // 64) * 64 + 64
         return ((v.R * T + ucap) * C * wpb + wpb * 2 * v.W) \
             * np.dtype(self.real).itemsize
 
@@ -462,7 +462,9 @@ void ${name}(params_t prm) {
         cost = n_nz[ji] * n_nz[jj] + 4 * N
         choice = np.full(len(ji), -1, dtype=np.int64)
         slots = {}
-        ntask = nnz1 * n2
+        # U entries per pair: one per stage-1 task; the region also stages the
+        # CSR row pointers of both graphs during setup
+        ntask = np.maximum(nnz1 * n2, n1 + n2 + 2)
         for k, v in enumerate(self.variants):
             todo = choice < 0
             if not todo.any():
@@ -614,7 +616,7 @@ void ${name}(params_t prm) {
             # blocks_per_cu - 1 workgroups fitted a CU).
             per_unit = self.jobs_per_unit
             grid = int(max(1, -(-len(idx) // (wpb * per_unit))))
-            ucap = int(-(-ntask[idx].max() // 64) * 64)
+            ucap = int(-(-ntask[idx].max() // 64) * 64) + 64   # + zero pad
             dyn = ucap * C * wpb * rsize
             if dyn > 64 * 1024:
                 runtime.set_max_dynamic_lds(fn, dyn)

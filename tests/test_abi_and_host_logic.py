@@ -114,14 +114,14 @@ def test_job_classification_respects_variant_capacity():
     for k, (a, b) in enumerate(zip(i, j)):
         v = backend.variants[choice[k]]
         assert n[a] * n[b] <= 64 * v.W * v.R
-        assert ntask[k] == nz[a] * n[b]
+        assert ntask[k] == max(nz[a] * n[b], n[a] + n[b] + 2)
         # brute-force the stage-1 walk of mgk_solver.h for this job
         T = 64 * v.W
         deg = dgs[b].adjacency_count
         worst = 0
         for w in range(v.W):
             total, kb = 0, 0
-            while kb * T + 64 * w < ntask[k]:
+            while kb * T + 64 * w < nz[a] * n[b]:
                 total += max(1, deg[(kb * T + 64 * w) // nz[a]])
                 kb += 1
             worst = max(worst, total)
