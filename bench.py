@@ -39,6 +39,10 @@ def parse():
     ap.add_argument('--gradient', action='store_true',
                     help='also evaluate dK/dtheta (config 5 kernel part)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--serial', action='store_true',
+                    help='all solver variants on one stream (default: one '
+                         'HIP stream per variant so short launches fill the '
+                         'tails of long ones)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     return ap.parse_args()
 
@@ -116,14 +120,33 @@ def main():
     events = [runtime.Event() for _ in range(len(plan.launches) + 1)]
     kernel_ms = np.zeros(len(plan.launches))
 
+    streams = [runtime.Stream() for _ in plan.launches] \
+        if not args.serial else None
+    ev2 = [(runtime.Event(), runtime.Event()) for _ in plan.launches]
+
     def step(timed):
-        if timed:
-            events[0].record()
-        for k, L in enumerate(plan.launches):
-            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                           dynamic_lds=L['dynamic_lds'])
+        if streams is not None:
+            # one stream per solver variant: events bracket each kernel on
+            # the stream it runs on
+            for k, L in enumerate(plan.launches):
+                if timed:
+                    ev2[k][0].record(streams[k].h)
+                runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                               stream=streams[k].h,
+                               dynamic_lds=L['dynamic_lds'])
+                if timed:
+                    ev2[k][1].record(streams[k].h)
+            if world > 1:
+                for st in streams:
+                    st.sync()
+        else:
             if timed:
-                events[k + 1].record()
+                events[0].record()
+            for k, L in enumerate(plan.launches):
+                runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                               dynamic_lds=L['dynamic_lds'])
+                if timed:
+                    events[k + 1].record()
         if world > 1:
             # packed slab -> torch tensor (device-to-device), then all-gather
             rs = np.dtype(real).itemsize
@@ -154,9 +177,14 @@ def main():
     for _ in range(args.steps):
         step(True)
         # per-kernel durations from the events of this step
-        events[-1].sync()
-        for k in range(len(plan.launches)):
-            kernel_ms[k] += events[k].elapsed_ms(events[k + 1])
+        if streams is not None:
+            for k in range(len(plan.launches)):
+                ev2[k][1].sync()
+                kernel_ms[k] += ev2[k][0].elapsed_ms(ev2[k][1])
+        else:
+            events[-1].sync()
+            for k in range(len(plan.launches)):
+                kernel_ms[k] += events[k].elapsed_ms(events[k + 1])
     sync()
     barrier()
     sync()
@@ -196,6 +224,8 @@ def main():
         'algorithmic_bytes_per_launch': abytes,
         'pairs_per_launch': int(L['count']),
         'avg_launch_ms': float(kernel_ms[dom]),
+        'launch_streams': 'one per solver variant (durations overlap)'
+                          if not args.serial else 'single stream',
         'note': 'the solver is LDS/VALU-bound by design (CG vectors and the '
                 'product-graph operator live in LDS/registers); see compute',
     }

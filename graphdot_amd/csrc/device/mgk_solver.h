@@ -400,6 +400,7 @@ struct pair_solver {
                     }
 #pragma unroll
                     for (int s0 = 0; s0 < S; s0 += GCH) {
+                        if (s0 >= n_slots) break;   // wave-uniform: no slots left
                         real g[C][GCH];
 #pragma unroll
                         for (int j = 0; j < GCH; ++j)

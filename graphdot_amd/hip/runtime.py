@@ -201,6 +201,27 @@ class Event:
             self.h = None
 
 
+class Stream:
+    """A non-blocking HIP stream."""
+
+    def __init__(self):
+        ensure_device()
+        p = ctypes.c_void_p()
+        check(lib().gd_stream_create(ctypes.byref(p)))
+        self.h = p.value
+
+    def sync(self):
+        check(lib().gd_stream_sync(self.h))
+
+    def __del__(self):
+        if getattr(self, 'h', None) and _lib is not None:
+            try:
+                _lib.gd_stream_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+
 class Module:
     """A loaded gfx950 code object and its kernels."""
 

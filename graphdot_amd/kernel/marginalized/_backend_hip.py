@@ -35,8 +35,9 @@ Variant = namedtuple('Variant', 'W S R')
 #: register-resident solver menu, cheapest first.  A pair fits a variant if
 #: its stage-1 walk needs <= S slots per lane and N = n1*n2 <= 64*W*R.
 VARIANTS = [
-    Variant(1, 8, 2), Variant(1, 16, 4), Variant(1, 24, 6),
-    Variant(1, 32, 9), Variant(1, 48, 9), Variant(1, 64, 16),
+    Variant(1, 8, 2), Variant(1, 12, 3), Variant(1, 16, 4), Variant(1, 20, 5),
+    Variant(1, 24, 6), Variant(1, 28, 7), Variant(1, 32, 9), Variant(1, 48, 9),
+    Variant(1, 64, 16),
     Variant(4, 16, 4), Variant(4, 32, 8), Variant(4, 64, 16),
     Variant(16, 16, 2), Variant(16, 32, 4), Variant(16, 64, 8),
     Variant(16, 128, 16),
@@ -175,6 +176,8 @@ class HIPBackend(Backend):
         self.variants = list(kwargs.pop('variants', VARIANTS + [GENERAL]))
         self.record_iterations = kwargs.pop('record_iterations', False)
         self.occupancy = kwargs.pop('occupancy', None)
+        self.concurrent = kwargs.pop('concurrent', True)
+        self._streams = []
         if self.occupancy is None and os.environ.get('GD_OCCUPANCY'):
             # e.g. GD_OCCUPANCY="1:16:5,1:24:4"  (W:S:waves)
             self.occupancy = {
@@ -676,15 +679,38 @@ void ${name}(params_t prm) {
             a['u_capacity'] = L['ucap']
             L['args'] = a.tobytes()
         plan.params_dtype = pd
+        # uploads were issued on the null stream; solver launches may go to
+        # non-blocking streams, which do not wait for it
+        runtime.synchronize()
         toc('calculating launch configuration')
         self.last_plan = plan
         return plan
 
-    def launch(self, plan, stream=None):
-        """Enqueue every solver launch of `plan` (asynchronous)."""
-        for L in plan.launches:
+    def launch(self, plan, stream=None, concurrent=None):
+        """Enqueue every solver launch of `plan` (asynchronous).  With
+        `concurrent` (default: the backend's setting) each solver variant
+        goes to its own HIP stream so that the short launches fill the tails
+        of the long ones; `synchronize()` / `collect()` wait for all of them."""
+        concurrent = self.concurrent if concurrent is None else concurrent
+        if not concurrent or len(plan.launches) < 2:
+            for L in plan.launches:
+                runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                               stream=stream, dynamic_lds=L['dynamic_lds'])
+            return
+        while len(self._streams) < len(plan.launches):
+            self._streams.append(runtime.Stream())
+        # longest first
+        order = sorted(range(len(plan.launches)),
+                       key=lambda k: -plan.launches[k]['count']
+                       * (plan.launches[k]['variant'].S + 8))
+        for slot, k in enumerate(order):
+            L = plan.launches[k]
             runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                           stream=stream, dynamic_lds=L['dynamic_lds'])
+                           stream=self._streams[slot].h,
+                           dynamic_lds=L['dynamic_lds'])
+
+    def synchronize(self):
+        runtime.synchronize()
 
     def collect(self, plan, gramian=None, gradient=None):
         """Copy results back.  With a packed plan the per-job values come
