@@ -123,6 +123,13 @@ template<class real> __device__ __forceinline__ void lds_add(real *p, real v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// base[idx] with the byte offset formed in 32 bits: lets the compiler address
+// with a scalar base + 32-bit vector offset (no 64-bit multiply-add per load)
+template<class T> __device__ __forceinline__ T const &at32(T const *base, unsigned idx) {
+    return *reinterpret_cast<T const *>(reinterpret_cast<char const *>(base) +
+                                        idx * (unsigned)sizeof(T));
+}
+
 // Walks (hi, lo) = divmod(index, n) for index = start, start + step, ...
 // without a division per step.
 struct divmod_walk {
@@ -298,11 +305,11 @@ struct pair_solver {
                     if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
                     const bool ok = adr[s] != ~0u;
                     const unsigned a = ok ? (adr[s] >> 16) : 0u, b = ok ? (adr[s] & 0xFFFFu) : 0u;
-                    const nz_t z1 = g1.nz[a], z2 = g2.nz[b];
-                    const edge_t e1 = g1.edge[a], e2 = g2.edge[b];
+                    const nz_t z1 = at32(g1.nz, a), z2 = at32(g2.nz, b);
+                    const edge_t e1 = at32(g1.edge, a), e2 = at32(g2.edge, b);
                     const real e = prm.edge_kernel(e1, e2);
                     val[s] = ok ? e : real(0);
-                    unsigned col = ok ? (unsigned)(z1.j * n2 + z2.j) : 0u;
+                    unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)n2) + (unsigned)z2.j : 0u;
                     // pin the evaluation here: otherwise it is sunk below the
                     // last chunk and every slot's raw labels stay live
                     asm volatile("" : "+v"(val[s]), "+v"(col));
@@ -327,13 +334,14 @@ struct pair_solver {
                 for (int k = 0; k < R; ++k) {
                     const bool ok = k * T + tid < N;
                     const int i1 = ok ? row.hi : 0, i2 = ok ? row.lo : 0;
-                    const node_t v1 = g1.node[i1], v2 = g2.node[i2];
-                    const real dx = real(g1.degree[i1]) * real(g2.degree[i2]) * inv1q2;
+                    const node_t v1 = at32(g1.node, (unsigned)i1), v2 = at32(g2.node, (unsigned)i2);
+                    const real dx = real(at32(g1.degree, (unsigned)i1)) *
+                                    real(at32(g2.degree, (unsigned)i2)) * inv1q2;
                     const real vx = prm.node_kernel(v1, v2);
                     dg[k] = ok ? dx / vx : real(0);
                     mi[k] = ok ? vx / dx : real(0);
                     const int rs = lrp1[i1];
-                    ubase[k] = ok ? i2 * nnz1 + rs : zbase;
+                    ubase[k] = ok ? (int)__umul24((unsigned)i2, (unsigned)nnz1) + rs : zbase;
                     udeg[k] = ok ? lrp1[i1 + 1] - rs : 0;
                     // rows of one wave are consecutive: the first has the largest degree
                     const int f1 = uni(first.hi);
