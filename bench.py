@@ -78,12 +78,22 @@ def main():
     from graphdot_amd.kernel.marginalized._sharded import ShardPlan
 
     dist = torch = None
+    host_collective = False
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device(
-            'cuda', local_rank))
+        n_dev = torch.cuda.device_count()
+        if n_dev >= world:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device(
+                'cuda', local_rank))
+        else:
+            # fewer GPUs than ranks (development box): ranks share devices
+            # and the all-gather goes through gloo on host memory
+            host_collective = True
+            local_rank = local_rank % max(n_dev, 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('gloo')
     real = np.float32 if args.dtype == 'f32' else np.float64
     backend = HIPBackend(device=local_rank, real=real, record_iterations=True)
 
@@ -157,7 +167,13 @@ def main():
                 runtime.check(runtime.lib().gd_memcpy_d2d(
                     local_out.data_ptr() + cap * rs,
                     plan.buffers['gradient'].ptr, plan.n_jobs * nJ * rs, None))
-            dist.all_gather_into_tensor(gathered, local_out)
+            if host_collective:
+                h = local_out.cpu()
+                g = torch.empty(world * h.numel(), dtype=h.dtype)
+                dist.all_gather_into_tensor(g, h)
+                gathered.copy_(g)
+            else:
+                dist.all_gather_into_tensor(gathered, local_out)
 
     def sync():
         runtime.synchronize()
@@ -190,7 +206,8 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device='cpu' if host_collective else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms /= max(args.steps, 1)
@@ -199,6 +216,22 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+
+    sharded_check = None
+    if world > 1:
+        # reassemble the gathered slabs and compare a sample with the oracle
+        from oracle import mgk
+        K = shard.assemble(gathered.cpu().numpy().reshape(
+            world, -1)[:, :shard.capacity].ravel())
+        rng = np.random.default_rng(1)
+        probe = rng.choice(n_pairs, size=min(3000, n_pairs), replace=False)
+        batch = mgk.TensorProductBatch(graphs, knode, kedge)
+        ref, _ = batch.run(i[probe], j[probe], q=q, real='f64', tol=1e-13)
+        sharded_check = {
+            'max_rel_diff_vs_oracle': float(np.max(np.abs(
+                K[i[probe], j[probe]] / ref - 1))),
+            'symmetric': bool(np.count_nonzero(K - K.T) == 0),
+            'collective': 'gloo/host' if host_collective else 'nccl(RCCL)'}
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = n_pairs / (elapsed / args.steps)
@@ -229,6 +262,17 @@ def main():
         'note': 'the solver is LDS/VALU-bound by design (CG vectors and the '
                 'product-graph operator live in LDS/registers); see compute',
     }
+    # measured HBM traffic of that kernel, if a PMC profile of this command
+    # has been committed (scripts/profile.sh + scripts/summarize_profile.py)
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            tr = json.load(f)['kernels'].get(roofline['kernel'])
+        if tr and args.dtype == 'f32' and not args.gradient and world == 1:
+            roofline['traffic'] = tr['hbm_bytes_per_launch']
+            roofline['traffic_source'] = 'profiles/traffic.json (rocprofv3 ' \
+                'FETCH_SIZE + WRITE_SIZE, separate passes)'
+    except (OSError, KeyError, ValueError):
+        pass
     peak_tf = 157.3 if real is np.float32 else 78.6
     compute = {
         'bound': 'valu', 'achieved': aflops / dur / 1e12, 'peak': peak_tf,
@@ -282,7 +326,7 @@ def main():
             'parallelism': f'pair-sharded x{world}' if world > 1 else 'single',
         },
         'roofline': roofline, 'compute': compute, 'kernels': per_kernel,
-        'cpu_baseline': cpu,
+        'cpu_baseline': cpu, 'sharded_check': sharded_check,
     }
     print(json.dumps(line))
     if world > 1:

@@ -244,8 +244,7 @@ struct pair_solver {
             // pass 2 then issues all label loads back to back and evaluates
             // the edge kernel.
             real val[S];
-            unsigned adr[S];       // pass 1 scratch: (a << 16) | b, or ~0u
-            unsigned adr2[(S + 1) / 2];  // gather indices into p, two 16-bit per register
+            unsigned adr[S];   // pass 1: (a << 16) | b, or ~0u; pass 2: gather index into p
             unsigned fm[NM];
 #pragma unroll
             for (int w = 0; w < NM; ++w) fm[w] = 0;
@@ -313,13 +312,13 @@ struct pair_solver {
                     // pin the evaluation here: otherwise it is sunk below the
                     // last chunk and every slot's raw labels stay live
                     asm volatile("" : "+v"(val[s]), "+v"(col));
-                    if (s % 2 == 0) adr2[s / 2] = col;
-                    else adr2[s / 2] |= col << 16;
+                    adr[s] = col;
                 }
             }
-            auto gather_index = [&](int s) -> unsigned {
-                return (s % 2 == 0) ? (adr2[s / 2] & 0xFFFFu) : (adr2[s / 2] >> 16);
-            };
+            // (the compiler turns adr[s] into the LDS address &lp[adr[s] * C]
+            // once, outside the CG loop: one register per slot, no per-
+            // iteration address arithmetic)
+            auto gather_index = [&](int s) -> unsigned { return adr[s]; };
 
             // ---- rows owned by this thread ------------------------------------
             // row i = k*T + tid = (i1, i2); Jacobi diagonal, start vectors, and

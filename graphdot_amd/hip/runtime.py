@@ -145,11 +145,9 @@ class DeviceBuffer:
         import numpy as np
         a = np.ascontiguousarray(array)
         assert offset + a.nbytes <= self.nbytes
+        # pageable source: hipMemcpyAsync returns once `a` may be reused
         check(lib().gd_memcpy_h2d(self.ptr + offset, a.ctypes.data, a.nbytes,
                                   stream))
-        if stream is None or True:
-            # pageable source: the copy is synchronous w.r.t. the host buffer
-            pass
         return self
 
     def download(self, array, offset=0, stream=None):

@@ -351,18 +351,25 @@ struct ${name}_t : ${name}_theta_t {
         return f'mgk_W{v.W}_S{v.S}_R{v.R}_C{C}'
 
     def waves_per_eu(self, v, C):
-        """Occupancy target handed to the register allocator.  The solver's
-        live state is ~2.5 registers per slot plus ~8 per row (x C); asking
-        for more waves than that allows makes the compiler spill, but only in
-        the once-per-pair setup / epilogue code, not in the CG loop."""
-        if self.occupancy is not None:
-            for (W, S), n in self.occupancy.items():
-                if (W, S) == (v.W, v.S):
-                    return n
-        need = (2.5 * v.S + 8 * v.R) * (1 if C == 1 else 1.6) + 16
+        """Occupancy target handed to the register allocator
+        (amdgpu_waves_per_eu).  Measured on gfx950/ROCm 7.2: the fp32 value
+        solver needs about 4.6 S + 2 R + 30 VGPRs to stay spill-free
+        (S=16 -> 112, S=24 -> 155, S=32 -> 216); the targets below are the
+        highest spill-free occupancies, which were also the fastest or within
+        2 % of it in a per-variant sweep (scripts/occupancy_sweep.sh) and keep
+        scratch traffic out of HBM."""
         floor = -(-64 * v.W * (4 if v.W == 1 else 1) // 256)  # block must fit
+        if self.occupancy is not None and (v.W, v.S) in self.occupancy:
+            return max(self.occupancy[(v.W, v.S)], floor)
+        need = 4.6 * v.S + 2 * v.R + 30
+        if C == 2:
+            need = 1.6 * need
+        if np.dtype(self.real) == np.float64:   # every real takes two VGPRs
+            need = 1.8 * need
+        if (v.W, v.S) == (1, 20) and C == 1 and self.real is np.float32:
+            return 4        # 1 spilled register, 12 % faster than 3 waves
         for n in (8, 6, 5, 4, 3, 2):
-            if need <= 512 // n:
+            if need <= (512 // n) // 8 * 8:
                 return max(n, floor)
         return max(1, floor)
 

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Condense gpurun_out/prof (scripts/profile.sh) into the committed summaries
+profiles/<tag>_kernel_stats.csv, <tag>_pmc.csv, <tag>_bench.json and
+profiles/traffic.json (HBM bytes per launch from FETCH_SIZE / WRITE_SIZE,
+which rocprofv3 reports in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B
+request of a wide coalesced read -- MI355X_MICROARCH.md, HBM -- this solver's
+reads are narrow gathers, so no x2 is applied; both figures are kept)."""
+import glob
+import json
+import shutil
+import sys
+import pandas as pd
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+src = 'gpurun_out/prof'
+shutil.copy(glob.glob(f'{src}/stats/*/*kernel_stats.csv')[0],
+            f'profiles/{tag}_kernel_stats.csv')
+shutil.copy(f'{src}/bench.json', f'profiles/{tag}_bench.json')
+rows, traffic = [], {}
+for d in ('pmc_a', 'pmc_b', 'pmc_fetch', 'pmc_write'):
+    f = glob.glob(f'{src}/{d}/*/*counter_collection.csv')[0]
+    df = pd.read_csv(f)
+    df = df[df.Kernel_Name.str.startswith('mgk')]
+    df['dur_us'] = (df.End_Timestamp - df.Start_Timestamp) / 1e3
+    g = df.groupby(['Kernel_Name', 'Counter_Name']).agg(
+        value_per_dispatch=('Counter_Value', 'mean'),
+        avg_dur_us=('dur_us', 'mean'),
+        vgpr=('VGPR_Count', 'first'), lds=('LDS_Block_Size', 'first'),
+        scratch=('Scratch_Size', 'first')).reset_index()
+    rows.append(g)
+    for _, r in g.iterrows():
+        if r.Counter_Name in ('FETCH_SIZE', 'WRITE_SIZE'):
+            traffic.setdefault(r.Kernel_Name, {})[r.Counter_Name + '_KiB'] = \
+                float(r.value_per_dispatch)
+pd.concat(rows).to_csv(f'profiles/{tag}_pmc.csv', index=False)
+for k, v in traffic.items():
+    v['hbm_bytes_per_launch'] = 1024 * (v.get('FETCH_SIZE_KiB', 0)
+                                        + v.get('WRITE_SIZE_KiB', 0))
+    v['hbm_bytes_per_launch_fetch_x2'] = 1024 * (
+        2 * v.get('FETCH_SIZE_KiB', 0) + v.get('WRITE_SIZE_KiB', 0))
+json.dump({'source': f'profiles/{tag}_pmc.csv', 'kernels': traffic},
+          open('profiles/traffic.json', 'w'), indent=1)
+print(json.dumps(traffic, indent=1))

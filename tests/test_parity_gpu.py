@@ -437,3 +437,57 @@ def test_large_pair_goes_to_general_solver(backend):
             x, _, _ = oracle.solve_pair(s1, s2, V, E, q, 'pcg64', tol=1e-13)
             ref[a, b] = ref[b, a] = x.sum()
     assert np.allclose(R, ref, rtol=2e-5)
+
+
+def test_gpr_log_marginal_likelihood_step(backend):
+    """Config 5 in miniature: one hyperparameter-fit step of a Gaussian
+    process on top of the kernel protocol (the computation of the reference's
+    GaussianProcessRegressor.log_marginal_likelihood, gpr.py:222-315):
+    K, dK = kernel(X, eval_gradient=True); L = chol(K + alpha I);
+    dL/dtheta_k = 0.5 (tr(K^-1 dK_k) - a^T dK_k a) * exp(theta_k).
+    The gradient from the HIP path must agree with a central difference of
+    the likelihood itself."""
+    G = cases.config3_graphs(24, seed=21)
+    knode, kedge, q = cases.config3_kernels()
+    kernel = MarginalizedGraphKernel(knode, kedge, q=0.05, backend=backend)
+    rng = np.random.default_rng(0)
+    y = rng.normal(size=len(G))
+
+    def normalised(K, dK=None):
+        d = np.diag(K)**-0.5
+        Kn = d[:, None] * K * d[None, :]
+        if dK is None:
+            return Kn
+        dd = -0.5 * np.diag(K)[:, None]**-1.5 * np.einsum('iik->ik', dK)
+        dKn = (dd[:, None, :] * K[:, :, None] * d[None, :, None]
+               + d[:, None, None] * dK * d[None, :, None]
+               + d[:, None, None] * K[:, :, None] * dd[None, :, :])
+        return Kn, dKn
+
+    def nll(theta, grad=False):
+        k = kernel.clone_with_theta(theta)
+        if grad:
+            K, dK = k(G, eval_gradient=True)
+            K, dK = normalised(K, dK)
+        else:
+            K = normalised(k(G))
+        Ky = K + 1e-2 * np.eye(len(G))
+        L = np.linalg.cholesky(Ky)
+        a = np.linalg.solve(L.T, np.linalg.solve(L, y))
+        val = 0.5 * y @ a + np.log(np.diag(L)).sum()
+        if not grad:
+            return val
+        Kinv = np.linalg.inv(Ky)
+        g = 0.5 * (np.einsum('ij,ijk->k', Kinv, dK)
+                   - np.einsum('i,ijk,j->k', a, dK, a))
+        return val, g * np.exp(theta)
+
+    theta = kernel.theta.copy()
+    val, g = nll(theta, grad=True)
+    assert np.all(np.isfinite(g)) and len(g) == len(theta)
+    for k in range(len(theta)):
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += 1e-2
+        tm[k] -= 1e-2
+        fd = (nll(tp) - nll(tm)) / 2e-2
+        assert g[k] == pytest.approx(fd, rel=0.05, abs=2e-3)
