@@ -8,6 +8,8 @@
 // consecutive rows (tasks) handled by one wave instruction has near-equal
 // trip counts and the wave-uniform maximum is known from its first row.
 //
+// The solver copies the packed image of each graph of a pair into LDS (the
+// image [degree .. perm] is contiguous) and builds its view on that copy.
 // All graphs of a call live in one arena allocation; a header stores byte
 // offsets from the arena base (which is a kernel argument, so the compiler
 // knows every derived pointer is in global memory and emits global_load /

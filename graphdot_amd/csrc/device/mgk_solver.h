@@ -78,6 +78,7 @@ template<class real, class Graph, class NodeK, class EdgeK, class PStart> struct
     std::uint32_t flags;
     std::uint32_t order_offset;  // slot of order[0] in the packed output
     std::uint32_t u_capacity;    // tasks per pair slot in the dynamic LDS region
+    std::uint32_t g_capacity;    // bytes per staged graph image in dynamic LDS
     real q, q0, eps, ftol, gtol;
     NodeK node_kernel;
     EdgeK edge_kernel;
@@ -113,6 +114,14 @@ template<class real, int W> struct block_reduce {
         return a;
     }
 };
+
+// Diagnostic build (-DGD_STAMPS): per-phase cycle totals are accumulated into
+// prm.iters[n_jobs_total .. +4) -- never compiled into the product kernels.
+#ifdef GD_STAMPS
+#define GD_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define GD_STAMP(var)
+#endif
 
 template<int W> __device__ __forceinline__ void job_sync() {
     if constexpr (W > 1) __syncthreads();
@@ -199,33 +208,66 @@ struct pair_solver {
         const int tid = (W == 1) ? lane : (int)threadIdx.x;             // thread within pair
         const int wv = (W == 1) ? 0 : uni((int)(threadIdx.x / 64));     // wave within pair
         real *const lp = lds.p[slot];
-        real *const lU = dyn + (size_t)slot * prm.u_capacity * C;
+        // dynamic LDS per pair slot: [U: u_capacity*C reals][G1 image][G2 image]
+        const unsigned slot_bytes = prm.u_capacity * C * (unsigned)sizeof(real) + 2 * prm.g_capacity;
+        char *const dyn_slot = reinterpret_cast<char *>(dyn) + (size_t)slot * slot_bytes;
+        real *const lU = reinterpret_cast<real *>(dyn_slot);
+        char *const lG1 = dyn_slot + prm.u_capacity * C * sizeof(real);
+        char *const lG2 = lG1 + prm.g_capacity;
         real *const red = lds.red[slot];
         graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
 
+#ifdef GD_STAMPS
+        unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
         const unsigned n_units = gridDim.x * WPB;
         for (unsigned t = blockIdx.x * WPB + slot; t < prm.n_launch_jobs; t += n_units) {
-            const unsigned job_id = prm.order[t];
-            const job_t job = prm.jobs[job_id];
-            const Graph g1(prm.arena, headers[job.i]);
-            const Graph g2(prm.arena, headers[job.j]);
-            const int n1 = g1.n_node, n2 = g2.n_node, N = n1 * n2;
-            const int nnz1 = g1.n_nz;
+            GD_STAMP(t_begin);
+            const job_t job = prm.jobs[t];     // jobs of this launch, in launch order
+            const graph_header_t h1 = headers[job.i], h2 = headers[job.j];
+            const int n1 = h1.n_node, n2 = h2.n_node, N = n1 * n2;
+            const int nnz1 = h1.n_nz;
             const int ntask = nnz1 * n2;       // stage-1 tasks (a, i2), i2-major
             const real q = prm.q, q0 = prm.q0;
             const real inv1q2 = real(1) / ((real(1) - q) * (real(1) - q));
             const real bscale = q * q / (q0 * q0);
 
-            // ---- stage the CSR row pointers of both graphs in LDS (as ints) ----
-            // lrp1[0..n1], lrp2[0..n2] live at the head of the U region, which
-            // is idle until the first mat-vec.
-            int *const lrp1 = reinterpret_cast<int *>(lU);
-            int *const lrp2 = lrp1 + n1 + 1;
-            job_sync<W>();  // previous pair is done with lU
+            // ---- stage both graph images in LDS: one global round trip --------
+            // A packed image is contiguous ([degree .. perm], graph.h); every
+            // later label / CSR access is an LDS read.  (Variable-length
+            // attribute payloads stay in global memory behind their pointers.)
+            job_sync<W>();  // previous pair is done with lU / lG
+            {
+                const unsigned w1 = (h1.perm + 2u * n1 - h1.degree + 3u) / 4u;
+                const unsigned w2 = (h2.perm + 2u * n2 - h2.degree + 3u) / 4u;
+                const unsigned *const s1 = reinterpret_cast<const unsigned *>(prm.arena + h1.degree);
+                const unsigned *const s2 = reinterpret_cast<const unsigned *>(prm.arena + h2.degree);
+                unsigned *const d1 = reinterpret_cast<unsigned *>(lG1);
+                unsigned *const d2 = reinterpret_cast<unsigned *>(lG2);
+                constexpr int K = 4;   // loads in flight per graph and lane
+                const unsigned wmax = w1 > w2 ? w1 : w2;
 #pragma nounroll
-            for (int i = tid; i <= n1; i += T) lrp1[i] = g1.rowptr[i];
-#pragma nounroll
-            for (int i = tid; i <= n2; i += T) lrp2[i] = g2.rowptr[i];
+                for (unsigned base = 0; base < wmax; base += K * T) {
+                    unsigned v1[K], v2[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const unsigned w = base + k * T + tid;
+                        v1[k] = w < w1 ? s1[w] : 0u;
+                        v2[k] = w < w2 ? s2[w] : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const unsigned w = base + k * T + tid;
+                        if (w < w1) d1[w] = v1[k];
+                        if (w < w2) d2[w] = v2[k];
+                    }
+                }
+            }
+            // graph views whose section pointers land in the LDS images
+            const Graph g1(lG1 - h1.degree, h1);
+            const Graph g2(lG2 - h2.degree, h2);
+            std::uint16_t const *const lrp1 = g1.rowptr;
+            std::uint16_t const *const lrp2 = g2.rowptr;
             // the last ZPAD entries of the U region stay zero: rows past N
             // point there, so stage 2 can read without a per-lane mask
             const int zbase = (int)prm.u_capacity - ZPAD;
@@ -234,6 +276,7 @@ struct pair_solver {
                 for (int c = 0; c < C; ++c) lU[(zbase + tid) * C + c] = 0;
             }
             job_sync<W>();
+            GD_STAMP(t_stage);
 
             // ---- stage-1 nonzeros owned by this thread ------------------------
             // batch kb = tasks [kb*T, kb*T + T); this lane's task is kb*T + tid.
@@ -320,15 +363,18 @@ struct pair_solver {
             // iteration address arithmetic)
             auto gather_index = [&](int s) -> unsigned { return adr[s]; };
 
+            GD_STAMP(t_slots);
             // ---- rows owned by this thread ------------------------------------
             // row i = k*T + tid = (i1, i2); Jacobi diagonal, start vectors, and
             // for stage 2 the first task index / trip count of the row.
             real dg[R], mi[R], x[C][R], r[C][R], p[C][R];
-            int ubase[R], udeg[R], D1[R];
+            int ubase[R], udeg[R];
+            int D1[R], D0[R];   // wave-uniform max / min degree of the rows of batch k
             real rTz = 0;
             {
                 divmod_walk row(tid, T, n2);         // per lane
                 divmod_walk first(64 * wv, T, n2);   // first row of this wave (uniform)
+                divmod_walk lastw(64 * wv + 63, T, n2);   // its last row (uniform)
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     const bool ok = k * T + tid < N;
@@ -342,9 +388,12 @@ struct pair_solver {
                     const int rs = lrp1[i1];
                     ubase[k] = ok ? (int)__umul24((unsigned)i2, (unsigned)nnz1) + rs : zbase;
                     udeg[k] = ok ? lrp1[i1 + 1] - rs : 0;
-                    // rows of one wave are consecutive: the first has the largest degree
+                    // rows of one wave are consecutive: the first has the largest
+                    // degree, the last the smallest (0 if the batch has dead rows)
                     const int f1 = uni(first.hi);
                     D1[k] = (k * T + 64 * wv < N) ? uni(lrp1[f1 + 1] - lrp1[f1]) : 0;
+                    const int l1 = uni(lastw.hi);
+                    D0[k] = (k * T + 64 * wv + 63 < N) ? uni(lrp1[l1 + 1] - lrp1[l1]) : 0;
                     const real b = ok ? dx * bscale : real(0);
                     x[0][k] = 0;
                     r[0][k] = b;
@@ -359,22 +408,11 @@ struct pair_solver {
                     }
                     row.next();
                     first.next();
+                    lastw.next();
                 }
             }
 
-            // smallest degree among this wave's live rows = degree of its last
-            // live row (rows are dealt in descending-degree order)
-            int Dmin = 0;
-            if (64 * wv < N) {
-                const int kl = (N - 1 - 64 * wv) / T;
-                int il = kl * T + 64 * wv + 63;
-                il = il < N ? il : N - 1;
-                divmod_walk last(il, 0, n2);
-                const int i1l = uni(last.hi);
-                Dmin = uni(lrp1[i1l + 1] - lrp1[i1l]);
-                Dmin = Dmin < ZPAD ? Dmin : ZPAD;
-            }
-
+            GD_STAMP(t_setup);
             // ---- publish p ---------------------------------------------------
             job_sync<W>();  // everyone is done with the staged row pointers
 #pragma unroll
@@ -442,35 +480,34 @@ struct pair_solver {
                     for (int k = 0; k < R; ++k)
 #pragma unroll
                         for (int c = 0; c < C; ++c) acc[c][k] = 0;
-                    // D1[0] >= D1[k]: rows are dealt in descending-degree order;
-                    // below Dmin every live row of the wave has an entry, so
-                    // those reads need no per-lane mask (rows past N read
-                    // in-range garbage that is multiplied by dg = 0 ... never
-                    // used: their Ap is discarded through p = 0)
-                    int d = 0;
-                    for (; d < Dmin; ++d) {   // wave-uniform trip count
-                        real u[C][R];
+                    // Rows are dealt in descending-degree order, so within batch k
+                    // all 64 rows have D0[k] <= degree <= D1[k] (wave-uniform
+                    // bounds, usually equal or one apart).  Entries below D0 are
+                    // read unmasked with immediate offsets; the few between D0
+                    // and D1 select the zero pad for rows that are shorter.
 #pragma unroll
-                        for (int k = 0; k < R; ++k)
+                    for (int k = 0; k < R; ++k) {
+                        real const *const u0 = lU + ubase[k] * C;
+                        int d = 0;
+                        for (; d + 4 <= D0[k]; d += 4) {
+                            real u[C][4];
 #pragma unroll
-                            for (int c = 0; c < C; ++c)
-                                u[c][k] = lU[(ubase[k] + d) * C + c];
+                            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int k = 0; k < R; ++k)
+                                for (int c = 0; c < C; ++c) u[c][j] = u0[(d + j) * C + c];
 #pragma unroll
-                            for (int c = 0; c < C; ++c) acc[c][k] += u[c][k];
-                    }
-                    for (; d < D1[0]; ++d) {   // wave-uniform trip count
-                        real u[C][R];
+                            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                        for (int k = 0; k < R; ++k)
+                                for (int c = 0; c < C; ++c) acc[c][k] += u[c][j];
+                        }
+                        for (; d < D0[k]; ++d)
 #pragma unroll
-                            for (int c = 0; c < C; ++c)
-                                u[c][k] = (d < udeg[k]) ? lU[(ubase[k] + d) * C + c] : real(0);
+                            for (int c = 0; c < C; ++c) acc[c][k] += u0[d * C + c];
+                        for (; d < D1[k]; ++d) {
+                            real const *const src = (d < udeg[k]) ? u0 + d * C : lU + zbase * C;
 #pragma unroll
-                        for (int k = 0; k < R; ++k)
-#pragma unroll
-                            for (int c = 0; c < C; ++c) acc[c][k] += u[c][k];
+                            for (int c = 0; c < C; ++c) acc[c][k] += src[c];
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < R; ++k)
@@ -510,7 +547,8 @@ struct pair_solver {
                     }
                 rTz = rTz_next;
             }
-            if (prm.iters != nullptr && tid == 0) prm.iters[job_id] = it;
+            if (prm.iters != nullptr && tid == 0) prm.iters[prm.order[t]] = it;
+            GD_STAMP(t_loop);
 
             // ---- output ------------------------------------------------------
             const unsigned flags = prm.flags;
@@ -648,7 +686,26 @@ struct pair_solver {
                     }
                 }
             }
+#ifdef GD_STAMPS
+            {
+                const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+                st_acc[0] += t_setup - t_begin;
+                st_acc[1] += t_loop - t_setup;
+                st_acc[2] += t_end - t_loop;
+                st_acc[3] += 1;
+                st_acc[4] += t_stage - t_begin;
+                st_acc[5] += t_slots - t_stage;
+                st_acc[6] += t_setup - t_slots;
+            }
+#endif
         }
+#ifdef GD_STAMPS
+        if (tid == 0 && prm.iters != nullptr) {
+            unsigned long long *acc = reinterpret_cast<unsigned long long *>(
+                prm.iters + ((prm.nJ + 1) & ~1u));   // host passes nJ := n_jobs
+            for (int k = 0; k < 7; ++k) atomicAdd(acc + k, st_acc[k]);
+        }
+#endif
     }
 };
 
@@ -686,8 +743,7 @@ struct general_solver {
         graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
 
         for (unsigned t = blockIdx.x; t < prm.n_launch_jobs; t += gridDim.x) {
-            const unsigned job_id = prm.order[t];
-            const job_t job = prm.jobs[job_id];
+            const job_t job = prm.jobs[t];     // jobs of this launch, in launch order
             const Graph g1(prm.arena, headers[job.i]);
             const Graph g2(prm.arena, headers[job.j]);
             const int n1 = g1.n_node, n2 = g2.n_node, N = n1 * n2;
@@ -816,7 +872,7 @@ struct general_solver {
                 rTz = rTz_next;
             }
             __syncthreads();
-            if (prm.iters != nullptr && tid == 0) prm.iters[job_id] = it;
+            if (prm.iters != nullptr && tid == 0) prm.iters[prm.order[t]] = it;
 
             // ---- output (same conventions as pair_solver) ----------------------
             const unsigned flags = prm.flags;

@@ -35,16 +35,14 @@ __device__ __forceinline__ float sum(float v) {
     v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
     v = dpp_add<0x141>(v);  // row_half_mirror : 8-lane sums
     v = dpp_add<0x140>(v);  // row_mirror      : 16-lane sums in every lane
-    // row_bcast:15 -> rows 1 and 3 add the total of the previous row
-    {
-        int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false);
-        v += __int_as_float(t);
-    }
-    // row_bcast:31 -> rows 2 and 3 add lane 31 (= rows 0 + 1)
-    {
-        int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false);
-        v += __int_as_float(t);
-    }
+    // row_bcast:15 -> rows 1 and 3 add the total of the previous row;
+    // row_bcast:31 -> rows 2 and 3 add lane 31 (= rows 0 + 1).  Written as
+    // asm: the builtin form costs an extra v_mov (old value) + v_add each.
+    // (s_nop 1: two wait states between a VALU write and a DPP read of it.)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\t"
+                 "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc\n\t"
+                 "s_nop 0"
+                 : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 

@@ -337,6 +337,7 @@ struct ${name}_t : ${name}_theta_t {
             ('n_launch_jobs', np.uint32), ('nX', np.uint32),
             ('nY', np.uint32), ('nJ', np.uint32), ('flags', np.uint32),
             ('order_offset', np.uint32), ('u_capacity', np.uint32),
+            ('g_capacity', np.uint32),
             ('q', self.real), ('q0', self.real), ('eps', self.real),
             ('ftol', self.real), ('gtol', self.real),
             ('node_kernel', theta(node_kernel)),
@@ -426,13 +427,14 @@ void ${name}(params_t prm) {
         return mod
 
     # -- job partitioning ---------------------------------------------------------
-    def lds_bytes(self, v, C, ntask=0):
-        """LDS bytes of one workgroup: static p + scratch, dynamic U."""
+    def lds_bytes(self, v, C, ntask=0, gbytes=0):
+        """LDS bytes of one workgroup: static p + scratch, dynamic U and the
+        two staged graph images."""
         wpb = 4 if v.W == 1 else 1
         T = 64 * v.W
         ucap = -(-np.asarray(ntask) // 64) * 64 + 64
         return ((v.R * T + ucap) * C * wpb + wpb * 2 * v.W) \
-            * np.dtype(self.real).itemsize
+            * np.dtype(self.real).itemsize + wpb * 2 * np.asarray(gbytes)
 
     @staticmethod
     def slots_needed(nnz1, n2, jj, deg_sorted, W):
@@ -475,6 +477,8 @@ void ${name}(params_t prm) {
         # U entries per pair: one per stage-1 task; the region also stages the
         # CSR row pointers of both graphs during setup
         ntask = np.maximum(nnz1 * n2, n1 + n2 + 2)
+        image = np.array([g.image_bytes for g in dgraphs], dtype=np.int64)
+        gbytes = np.maximum(image[ji], image[jj])
         for k, v in enumerate(self.variants):
             todo = choice < 0
             if not todo.any():
@@ -482,7 +486,7 @@ void ${name}(params_t prm) {
             if v == GENERAL:
                 continue
             fits = (todo & (N <= 64 * v.W * v.R) & (N <= 0xFFFF)
-                    & (self.lds_bytes(v, C, ntask) <= LDS_LIMIT))
+                    & (self.lds_bytes(v, C, ntask, gbytes) <= LDS_LIMIT))
             if not fits.any():
                 continue
             if v.W not in slots:
@@ -503,7 +507,7 @@ void ${name}(params_t prm) {
                     'register-resident solver variant and the general '
                     'solver is disabled')
             choice[choice < 0] = self.variants.index(GENERAL)
-        return choice, cost, ntask
+        return choice, cost, ntask, gbytes
 
     # -- the three phases -----------------------------------------------------------
     def _frontend(self, graphs, node_kernel, edge_kernel, p, jobs, traits,
@@ -534,15 +538,15 @@ void ${name}(params_t prm) {
         jobs = np.ascontiguousarray(jobs)
         ji = jobs['i'].astype(np.int64)
         jj = jobs['j'].astype(np.int64)
-        choice, cost, ntask = self.classify(ji, jj, dgraphs, C)
+        choice, cost, ntask, gbytes = self.classify(ji, jj, dgraphs, C)
         used = sorted(set(choice.tolist()))
         sources = {k: self.render_source(node_kernel, edge_kernel, p,
                                          dgraphs[0].node_t, dgraphs[0].edge_t,
                                          [self.variants[k]], C)
                    for k in used}
         toc('code generation')
-        return dgraphs, edge_kernel, jobs, C, choice, cost, ntask, used, \
-            sources
+        return dgraphs, edge_kernel, jobs, C, choice, cost, ntask, gbytes, \
+            used, sources
 
     def precompile(self, graphs, node_kernel, edge_kernel, p, jobs, traits):
         """Compile (into the on-disk JIT cache) every code object that
@@ -558,7 +562,7 @@ void ${name}(params_t prm) {
         tic = timer.tic if timer else (lambda *_: None)
         toc = timer.toc if timer else (lambda *_: None)
         runtime.ensure_device(self.device)
-        (dgraphs, edge_kernel, jobs, C, choice, cost, ntask, used,
+        (dgraphs, edge_kernel, jobs, C, choice, cost, ntask, gbytes, used,
          sources) = self._frontend(graphs, node_kernel, edge_kernel, p, jobs,
                                    traits, timer)
         arena, arena_buf, _ = self._arena(dgraphs)
@@ -611,7 +615,8 @@ void ${name}(params_t prm) {
                 per_wg = int(((3 * N_ + ntask[idx]) * C).max())
                 grid = int(min(len(idx), 2 * self.props.compute_units))
                 launches.append(dict(
-                    variant=v, k=k, offset=cursor, ucap=per_wg, dynamic_lds=0,
+                    variant=v, k=k, offset=cursor, ucap=per_wg, gcap=0,
+                    dynamic_lds=0,
                     count=len(idx), grid=grid, threads=GENERAL_THREADS,
                     fn=fn, module=modules[k],
                     scratch_bytes=grid * per_wg * rsize))
@@ -627,11 +632,12 @@ void ${name}(params_t prm) {
             per_unit = self.jobs_per_unit
             grid = int(max(1, -(-len(idx) // (wpb * per_unit))))
             ucap = int(-(-ntask[idx].max() // 64) * 64) + 64   # + zero pad
-            dyn = ucap * C * wpb * rsize
+            gcap = int(-(-gbytes[idx].max() // 16) * 16)
+            dyn = (ucap * C * rsize + 2 * gcap) * wpb
             if dyn > 64 * 1024:
                 runtime.set_max_dynamic_lds(fn, dyn)
             launches.append(dict(variant=v, k=k, offset=cursor, ucap=ucap,
-                                 dynamic_lds=dyn,
+                                 gcap=gcap, dynamic_lds=dyn,
                                  count=len(idx), grid=grid, threads=threads,
                                  fn=fn,
                                  module=modules[k]))
@@ -652,7 +658,8 @@ void ${name}(params_t prm) {
                             + [0])
         b_scratch = self._buffer('scratch', scratch_bytes) \
             if scratch_bytes else None
-        b_jobs.upload(jobs.view(np.uint32))
+        # jobs travel in launch order: the kernel reads jobs[t] directly
+        b_jobs.upload(np.ascontiguousarray(jobs[order_all]).view(np.uint32))
         b_order.upload(order_all)
         b_starts.upload(np.ascontiguousarray(starts, dtype=np.uint32))
         plan.buffers = dict(jobs=b_jobs, order=b_order, starts=b_starts,
@@ -681,6 +688,8 @@ void ${name}(params_t prm) {
         for L in launches:
             a = base.copy()
             a['order'] = b_order.ptr + 4 * L['offset']
+            a['jobs'] = b_jobs.ptr + 8 * L['offset']
+            a['g_capacity'] = L['gcap']
             a['n_launch_jobs'] = L['count']
             a['order_offset'] = L['offset']
             a['u_capacity'] = L['ucap']

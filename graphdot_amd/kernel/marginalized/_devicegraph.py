@@ -229,6 +229,9 @@ class DeviceGraph:
             blob[off:off + arr.nbytes] = arr.view(np.uint8).ravel() \
                 if arr.nbytes else []
         self.offsets = {k: v[0] for k, v in sections.items()}
+        #: bytes of the contiguous image [degree .. perm] that the solver
+        #: stages in LDS (payloads of variable-length attributes excluded)
+        self.image_bytes = _pad(self.offsets['perm'] + 2 * n)
 
         relocs = []
         for base_name, base_t, fa_list in (('node', node_t, node_fa),

@@ -107,7 +107,7 @@ def test_job_classification_respects_variant_capacity():
     backend = HIPBackend()
     dgs = [backend._register_graph(g) for g in G]
     i, j = np.triu_indices(len(G))
-    choice, cost, ntask = backend.classify(i, j, dgs, 1)
+    choice, cost, ntask, gbytes = backend.classify(i, j, dgs, 1)
     n = np.array([d.n_node for d in dgs])
     nz = np.array([d.n_nz for d in dgs])
     assert np.all(choice >= 0)
@@ -126,7 +126,7 @@ def test_job_classification_respects_variant_capacity():
                 kb += 1
             worst = max(worst, total)
         assert worst <= v.S
-        assert backend.lds_bytes(v, 1, ntask[k]) <= 160 * 1024
+        assert backend.lds_bytes(v, 1, ntask[k], gbytes[k]) <= 160 * 1024
     # with only the smallest variant available, large pairs must be refused
     small = HIPBackend(variants=[Variant(1, 8, 2)])
     with pytest.raises(NotImplementedError):
