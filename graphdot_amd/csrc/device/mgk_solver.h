@@ -166,8 +166,9 @@ struct divmod_walk {
 };
 
 // S: register slots per lane for stage-1 nonzeros, R: rows per lane,
-// W: waves per pair, C: right-hand sides (1 = value, 2 = value + gradient).
-template<class real, int S, int R, int W, int C, class Graph, class NodeK, class EdgeK, class PStart>
+// W: waves per pair, C: right-hand sides (1 = value, 2 = value + gradient),
+// NODAL: compile the node-wise output modes (F_NODAL / F_BLOCK) in.
+template<class real, int S, int R, int W, int C, bool NODAL, class Graph, class NodeK, class EdgeK, class PStart>
 struct pair_solver {
     using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
     using node_t = typename Graph::node_t;
@@ -568,7 +569,7 @@ struct pair_solver {
                     const real pp = real(prm.p_start(v1)) * real(prm.p_start(v2));
                     const real rv = ok ? xi * pp : real(0);
                     ksum += rv;
-                    if ((flags & F_NODAL) && ok) {
+                    if constexpr (NODAL) if ((flags & F_NODAL) && ok) {
                         // back to the caller's node numbering
                         const unsigned o1 = g1.perm[i1], o2 = g2.perm[i2];
                         if (flags & F_BLOCK) {
@@ -582,7 +583,7 @@ struct pair_solver {
                     }
                 }
             }
-            if (!(flags & F_NODAL)) {
+            if (!NODAL || !(flags & F_NODAL)) {
                 ksum = block_reduce<real, W>::sum(ksum, red);
                 if (tid == 0) {
                     if (flags & F_PACKED) {

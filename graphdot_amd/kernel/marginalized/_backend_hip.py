@@ -346,35 +346,40 @@ struct ${name}_t : ${name}_theta_t {
         ], align=True)
 
     @staticmethod
-    def kernel_name(v, C):
+    def kernel_name(v, C, nodal=False):
         if v == GENERAL:
             return f'mgk_general_T{GENERAL_THREADS}_C{C}'
-        return f'mgk_W{v.W}_S{v.S}_R{v.R}_C{C}'
+        return f'mgk_W{v.W}_S{v.S}_R{v.R}_C{C}' + ('_nodal' if nodal else '')
+
+    #: measured highest (near) spill-free occupancy of the fp32 value solver,
+    #: W = 1 (hipcc 7.2, gfx950): S -> waves per SIMD
+    _WAVES_F32_VALUE = {8: 6, 12: 6, 16: 5, 20: 4, 24: 3, 28: 3, 32: 2}
 
     def waves_per_eu(self, v, C):
         """Occupancy target handed to the register allocator
-        (amdgpu_waves_per_eu).  Measured on gfx950/ROCm 7.2: the fp32 value
-        solver needs about 4.6 S + 2 R + 30 VGPRs to stay spill-free
-        (S=16 -> 112, S=24 -> 155, S=32 -> 216); the targets below are the
-        highest spill-free occupancies, which were also the fastest or within
-        2 % of it in a per-variant sweep (scripts/occupancy_sweep.sh) and keep
-        scratch traffic out of HBM."""
+        (amdgpu_waves_per_eu).  The fp32 value solver needs about
+        5.3 S + 4 R + 6 VGPRs to stay spill-free (measured: S=12 -> 81,
+        S=16 -> 106, S=24 -> 150, S=32 -> 211); the targets are the highest
+        occupancies with at most a handful of spilled registers, which were
+        also the fastest or within 2 % of it in a per-variant sweep
+        (scripts/occupancy_sweep.sh) and keep scratch traffic out of HBM."""
         floor = -(-64 * v.W * (4 if v.W == 1 else 1) // 256)  # block must fit
         if self.occupancy is not None and (v.W, v.S) in self.occupancy:
             return max(self.occupancy[(v.W, v.S)], floor)
-        need = 4.6 * v.S + 2 * v.R + 30
+        if (v.W == 1 and C == 1 and self.real is np.float32
+                and v.S in self._WAVES_F32_VALUE):
+            return self._WAVES_F32_VALUE[v.S]
+        need = 5.3 * v.S + 4 * v.R + 6
         if C == 2:
             need = 1.6 * need
         if np.dtype(self.real) == np.float64:   # every real takes two VGPRs
             need = 1.8 * need
-        if (v.W, v.S) == (1, 20) and C == 1 and self.real is np.float32:
-            return 4        # 1 spilled register, 12 % faster than 3 waves
         for n in (8, 6, 5, 4, 3, 2):
-            if need <= (512 // n) // 8 * 8:
+            if need <= (512 // n) // 8 * 8 + 4:
                 return max(n, floor)
         return max(1, floor)
 
-    def _entry_point(self, v, C):
+    def _entry_point(self, v, C, nodal=False):
         if v == GENERAL:
             return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
@@ -391,16 +396,17 @@ extern "C" __global__ __launch_bounds__(${threads})
 __attribute__((amdgpu_waves_per_eu(${waves})))
 void ${name}(params_t prm) {
     using solver = graphdot::mgk::pair_solver<real_t, ${S}, ${R}, ${W}, ${C},
-        graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
+        ${nodal}, graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
     __shared__ typename solver::lds_t lds;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     solver::run(prm, lds, reinterpret_cast<real_t *>(dyn_lds));
 }
-''').render(threads=threads, name=self.kernel_name(v, C), S=v.S, R=v.R,
-            W=v.W, C=C, waves=self.waves_per_eu(v, C))
+''').render(threads=threads, name=self.kernel_name(v, C, nodal), S=v.S,
+            R=v.R, W=v.W, C=C, waves=self.waves_per_eu(v, C),
+            nodal='true' if nodal else 'false')
 
     def render_source(self, node_kernel, edge_kernel, p, node_t, edge_t,
-                      variants, C):
+                      variants, C, nodal=False):
         """Full translation unit for the given solver variants."""
         pd = self._params_dtype(node_kernel, edge_kernel, p)
         return Template(_TEMPLATE).render(
@@ -415,7 +421,8 @@ void ${name}(params_t prm) {
             node_size=np.dtype(node_t).itemsize,
             edge_size=max(np.dtype(edge_t).itemsize, 1),
             params_size=pd.itemsize,
-            entry_points=[self._entry_point(v, C) for v in variants] + [''],
+            entry_points=[self._entry_point(v, C, nodal)
+                          for v in variants] + [''],
         )
 
     def _module(self, source):
@@ -540,9 +547,10 @@ void ${name}(params_t prm) {
         jj = jobs['j'].astype(np.int64)
         choice, cost, ntask, gbytes = self.classify(ji, jj, dgraphs, C)
         used = sorted(set(choice.tolist()))
+        nodal = traits.nodal is not False
         sources = {k: self.render_source(node_kernel, edge_kernel, p,
                                          dgraphs[0].node_t, dgraphs[0].edge_t,
-                                         [self.variants[k]], C)
+                                         [self.variants[k]], C, nodal)
                    for k in used}
         toc('code generation')
         return dgraphs, edge_kernel, jobs, C, choice, cost, ntask, gbytes, \
@@ -608,7 +616,8 @@ void ${name}(params_t prm) {
             idx = np.flatnonzero(choice == k)
             idx = idx[np.argsort(-cost[idx], kind='stable')]
             order_all[cursor:cursor + len(idx)] = idx.astype(np.uint32)
-            fn = modules[k].function(self.kernel_name(v, C))
+            fn = modules[k].function(self.kernel_name(
+                v, C, traits.nodal is not False))
             if v == GENERAL:
                 # one workgroup per pair, CG vectors + U in global scratch
                 N_ = (arena.n_node[ji[idx]] * arena.n_node[jj[idx]])
