@@ -116,16 +116,24 @@ def main():
     n_nz = np.array([g.n_nz for g in dgs], dtype=np.int64)
     shard = ShardPlan(i, j, n_node, n_nz, n, n, True, rank, world)
     local_jobs = all_jobs[shard.local] if world > 1 else all_jobs
+    local_out = gathered = None
+    out_ptrs = {}
+    if world > 1:
+        # every rank's packed slab [cap values | cap*nJ gradient entries] is
+        # written by the kernels straight into the all-gather input
+        cap = shard.capacity
+        tdtype = torch.float32 if real is np.float32 else torch.float64
+        local_out = torch.zeros(cap * n_cols, dtype=tdtype, device='cuda')
+        gathered = torch.empty(world * cap * n_cols, dtype=tdtype,
+                               device='cuda')
+        rs_ = np.dtype(real).itemsize
+        out_ptrs = dict(gramian_ptr=local_out.data_ptr(),
+                        gradient_ptr=local_out.data_ptr() + cap * rs_)
+        torch.cuda.synchronize()
     plan = backend.prepare(graphs, knode, kedge, kernel.p, kernel.q,
                            kernel.eps, kernel.ftol, kernel.gtol, local_jobs,
-                           starts, n, n, nJ, traits, packed=(world > 1))
-    if world > 1:
-        cap = shard.capacity
-        local_out = torch.zeros(cap * n_cols, dtype=torch.float32
-                                if real is np.float32 else torch.float64,
-                                device='cuda')
-        gathered = torch.empty(world * cap * n_cols, dtype=local_out.dtype,
-                               device='cuda')
+                           starts, n, n, nJ, traits, packed=(world > 1),
+                           **out_ptrs)
 
     events = [runtime.Event() for _ in range(len(plan.launches) + 1)]
     kernel_ms = np.zeros(len(plan.launches))
@@ -133,22 +141,26 @@ def main():
     streams = [runtime.Stream() for _ in plan.launches] \
         if not args.serial else None
     ev2 = [(runtime.Event(), runtime.Event()) for _ in plan.launches]
+    ev_gathered = runtime.Event()      # previous all-gather has read the slab
 
-    def step(timed):
+    def step(timed, first=False):
         if streams is not None:
-            # one stream per solver variant: events bracket each kernel on
-            # the stream it runs on
+            # one stream per solver variant; events bracket each kernel on
+            # the stream it runs on.  No host synchronisation inside a step:
+            # the solver streams wait (device-side) for the previous
+            # all-gather, the collective's stream waits for the solvers.
             for k, L in enumerate(plan.launches):
+                if world > 1 and not first:
+                    streams[k].wait_event(ev_gathered)
                 if timed:
                     ev2[k][0].record(streams[k].h)
                 runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
                                stream=streams[k].h,
                                dynamic_lds=L['dynamic_lds'])
-                if timed:
-                    ev2[k][1].record(streams[k].h)
+                ev2[k][1].record(streams[k].h)
             if world > 1:
-                for st in streams:
-                    st.sync()
+                for k in range(len(plan.launches)):
+                    runtime.null_stream_wait_event(ev2[k][1])
         else:
             if timed:
                 events[0].record()
@@ -158,15 +170,6 @@ def main():
                 if timed:
                     events[k + 1].record()
         if world > 1:
-            # packed slab -> torch tensor (device-to-device), then all-gather
-            rs = np.dtype(real).itemsize
-            runtime.check(runtime.lib().gd_memcpy_d2d(
-                local_out.data_ptr(), plan.buffers['gramian'].ptr,
-                plan.n_jobs * rs, None))
-            if args.gradient:
-                runtime.check(runtime.lib().gd_memcpy_d2d(
-                    local_out.data_ptr() + cap * rs,
-                    plan.buffers['gradient'].ptr, plan.n_jobs * nJ * rs, None))
             if host_collective:
                 h = local_out.cpu()
                 g = torch.empty(world * h.numel(), dtype=h.dtype)
@@ -174,6 +177,7 @@ def main():
                 gathered.copy_(g)
             else:
                 dist.all_gather_into_tensor(gathered, local_out)
+            ev_gathered.record()
 
     def sync():
         runtime.synchronize()
@@ -184,8 +188,10 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step(False)
+    for w in range(args.warmup):
+        step(False, first=(w == 0))
+    if args.warmup == 0 and world > 1:
+        ev_gathered.record()
     sync()
     barrier()
     sync()

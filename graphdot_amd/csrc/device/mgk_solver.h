@@ -53,7 +53,7 @@ enum : unsigned {
     F_SYMMETRIC = 4u,  // mirror K(I2, I1)
     F_LMIN1 = 8u,      // subtract the zero-step term kappa_v q^2/q0^2
     F_BLOCK = 16u,     // diag(nodal='block'): n x n block per graph
-    F_PACKED = 32u,    // graph-level: out[job slot] instead of K(I1, I2)
+    F_PACKED = 32u,    // graph-level: out[job id] instead of K(I1, I2)
 };
 
 struct job_t {
@@ -587,7 +587,7 @@ struct pair_solver {
                 ksum = block_reduce<real, W>::sum(ksum, red);
                 if (tid == 0) {
                     if (flags & F_PACKED) {
-                        prm.gramian[prm.order_offset + t] = ksum;
+                        prm.gramian[prm.order[t]] = ksum;   // slab in job order
                     } else if (flags & F_DIAGONAL) {
                         prm.gramian[I1] = ksum;
                     } else {
@@ -676,7 +676,7 @@ struct pair_solver {
                     const real g = block_reduce<real, W>::sum(jac[j], red);
                     if (tid == 0) {
                         if (flags & F_PACKED) {
-                            prm.gradient[(size_t)(prm.order_offset + t) * n_jac + j] = g;
+                            prm.gradient[(size_t)prm.order[t] * n_jac + j] = g;
                         } else if (flags & F_DIAGONAL) {
                             prm.gradient[(size_t)I1 + (size_t)prm.nX * j] = g;
                         } else {
@@ -903,7 +903,7 @@ struct general_solver {
                 ksum = block_reduce<real, W>::sum(ksum, red);
                 if (tid == 0) {
                     if (flags & F_PACKED) {
-                        prm.gramian[prm.order_offset + t] = ksum;
+                        prm.gramian[prm.order[t]] = ksum;   // slab in job order
                     } else if (flags & F_DIAGONAL) {
                         prm.gramian[I1] = ksum;
                     } else {
@@ -956,7 +956,7 @@ struct general_solver {
                     const real g = block_reduce<real, W>::sum(jac[j], red);
                     if (tid == 0) {
                         if (flags & F_PACKED) {
-                            prm.gradient[(size_t)(prm.order_offset + t) * n_jac + j] = g;
+                            prm.gradient[(size_t)prm.order[t] * n_jac + j] = g;
                         } else if (flags & F_DIAGONAL) {
                             prm.gradient[(size_t)I1 + (size_t)prm.nX * j] = g;
                         } else {

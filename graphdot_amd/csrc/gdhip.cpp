@@ -213,6 +213,10 @@ int gd_event_sync(gd_event_t e) {
     GD_TRY(hipEventSynchronize(E(e)));
     return 0;
 }
+int gd_stream_wait_event(gd_stream_t s, gd_event_t e) {
+    GD_TRY(hipStreamWaitEvent(S(s), E(e), 0));
+    return 0;
+}
 int gd_event_elapsed_ms(gd_event_t start, gd_event_t stop, float *ms) {
     if (!ms) return fail("gd_event_elapsed_ms: null argument");
     GD_TRY(hipEventElapsedTime(ms, E(start), E(stop)));

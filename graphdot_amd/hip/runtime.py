@@ -63,6 +63,7 @@ SIGNATURES = {
     'gd_event_destroy': [_vp],
     'gd_event_record': [_vp, _vp],
     'gd_event_sync': [_vp],
+    'gd_stream_wait_event': [_vp, _vp],
     'gd_event_elapsed_ms': [_vp, _vp, _P(ctypes.c_float)],
 }
 
@@ -211,6 +212,10 @@ class Stream:
     def sync(self):
         check(lib().gd_stream_sync(self.h))
 
+    def wait_event(self, event):
+        """Device-side: later work on this stream waits for `event`."""
+        check(lib().gd_stream_wait_event(self.h, event.h))
+
     def __del__(self):
         if getattr(self, 'h', None) and _lib is not None:
             try:
@@ -253,6 +258,10 @@ def launch(function, grid, block, args: bytes, stream=None, dynamic_lds=0):
     buf = ctypes.create_string_buffer(args, len(args))
     check(lib().gd_launch(function, grid, block, dynamic_lds, stream, buf,
                           len(args)))
+
+
+def null_stream_wait_event(event):
+    check(lib().gd_stream_wait_event(None, event.h))
 
 
 def set_max_dynamic_lds(function, nbytes):

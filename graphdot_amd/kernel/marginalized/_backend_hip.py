@@ -564,9 +564,12 @@ void ${name}(params_t prm) {
         return jit.compile_many(list(sources.values()), self.hipcc_extra)
 
     def prepare(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
-                jobs, starts, nX, nY, nJ, traits, timer=None, packed=False):
+                jobs, starts, nX, nY, nJ, traits, timer=None, packed=False,
+                gramian_ptr=None, gradient_ptr=None):
         """Upload graphs / jobs, generate + compile code, partition the jobs.
-        Returns a Plan whose launches can be replayed."""
+        Returns a Plan whose launches can be replayed.  `gramian_ptr` /
+        `gradient_ptr` (device addresses) make the kernels write into
+        caller-owned memory, e.g. the tensor handed to the all-gather."""
         tic = timer.tic if timer else (lambda *_: None)
         toc = timer.toc if timer else (lambda *_: None)
         runtime.ensure_device(self.device)
@@ -680,8 +683,9 @@ void ${name}(params_t prm) {
         base['arena'] = arena_buf.ptr
         base['jobs'] = b_jobs.ptr
         base['starts'] = b_starts.ptr
-        base['gramian'] = b_out.ptr
-        base['gradient'] = b_grad.ptr if b_grad is not None else 0
+        base['gramian'] = gramian_ptr if gramian_ptr else b_out.ptr
+        base['gradient'] = gradient_ptr if gradient_ptr else (
+            b_grad.ptr if b_grad is not None else 0)
         base['iters'] = b_iters.ptr if b_iters is not None else 0
         base['scratch'] = b_scratch.ptr if b_scratch is not None else 0
         base['nX'], base['nY'], base['nJ'] = plan.nX, plan.nY, plan.nJ
@@ -738,8 +742,8 @@ void ${name}(params_t prm) {
         runtime.synchronize()
 
     def collect(self, plan, gramian=None, gradient=None):
-        """Copy results back.  With a packed plan the per-job values come
-        back in *job order* (not launch order)."""
+        """Copy results back.  A packed plan returns one value (and nJ
+        gradient entries) per job, in job order."""
         runtime.synchronize()
         rs = np.dtype(self.real)
         out = np.empty(plan.n_out, dtype=rs)
@@ -748,16 +752,6 @@ void ${name}(params_t prm) {
         if plan.C == 2:
             grad = np.empty(plan.n_grad, dtype=rs)
             plan.buffers['gradient'].download(grad)
-        if plan.packed:
-            ids = plan.order_host
-            unsorted = np.empty_like(out)
-            unsorted[ids] = out
-            out = unsorted
-            if grad is not None:
-                g = grad.reshape(plan.n_jobs, -1)
-                gu = np.empty_like(g)
-                gu[ids] = g
-                grad = gu
         if gramian is not None:
             gramian[:] = out
         if gradient is not None and grad is not None:

@@ -92,6 +92,10 @@ int gd_event_create(gd_event_t *out);
 int gd_event_destroy(gd_event_t e);
 int gd_event_record(gd_event_t e, gd_stream_t s);
 int gd_event_sync(gd_event_t e);
+/* make all later work on `s` wait for `e` (device-side dependency, no host
+ * synchronisation); orders the per-variant solver streams against the
+ * stream that runs the collective */
+int gd_stream_wait_event(gd_stream_t s, gd_event_t e);
 int gd_event_elapsed_ms(gd_event_t start, gd_event_t stop, float *ms);
 
 #ifdef __cplusplus
