@@ -109,8 +109,17 @@ template<class real, int W> struct block_reduce {
         }
     }
     __device__ static __forceinline__ real sum(real a, real *scratch) {
-        real b = 0;
-        sum2(a, b, scratch);
+        a = wave::sum(a);
+        if constexpr (W > 1) {
+            const int w = threadIdx.x / 64;
+            __syncthreads();
+            if (wave::laneid() == 0) scratch[2 * w] = a;
+            __syncthreads();
+            real sa = 0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) sa += scratch[2 * k];
+            a = sa;
+        }
         return a;
     }
 };
@@ -165,6 +174,49 @@ struct divmod_walk {
     }
 };
 
+// sum_{j < n, j < deg} t[j] per lane, n <= 4: the entries past a lane's own
+// degree hold other rows' data and are kept out by the EXEC mask, which only
+// shrinks as j grows (v_cmpx writes it): two VALU per entry.
+template<int n> __device__ __forceinline__ float masked_sum(float const (&t)[4], int deg) {
+    float a;
+    unsigned long long saved;
+    if constexpr (n == 1)
+        asm volatile("v_cmp_lt_i32 vcc, 0, %[dg]\n\tv_cndmask_b32 %[a], 0, %[t0], vcc"
+                     : [a] "=&v"(a) : [dg] "v"(deg), [t0] "v"(t[0]) : "vcc");
+    else if constexpr (n == 2)
+        asm volatile("v_cmp_lt_i32 vcc, 0, %[dg]\n\tv_cndmask_b32 %[a], 0, %[t0], vcc\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_lt_i32 vcc, 1, %[dg]\n\tv_add_f32 %[a], %[a], %[t1]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "=&v"(a), [sv] "=&s"(saved)
+                     : [dg] "v"(deg), [t0] "v"(t[0]), [t1] "v"(t[1]) : "vcc");
+    else if constexpr (n == 3)
+        asm volatile("v_cmp_lt_i32 vcc, 0, %[dg]\n\tv_cndmask_b32 %[a], 0, %[t0], vcc\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_lt_i32 vcc, 1, %[dg]\n\tv_add_f32 %[a], %[a], %[t1]\n\t"
+                     "v_cmpx_lt_i32 vcc, 2, %[dg]\n\tv_add_f32 %[a], %[a], %[t2]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "=&v"(a), [sv] "=&s"(saved)
+                     : [dg] "v"(deg), [t0] "v"(t[0]), [t1] "v"(t[1]), [t2] "v"(t[2]) : "vcc");
+    else
+        asm volatile("v_cmp_lt_i32 vcc, 0, %[dg]\n\tv_cndmask_b32 %[a], 0, %[t0], vcc\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "v_cmpx_lt_i32 vcc, 1, %[dg]\n\tv_add_f32 %[a], %[a], %[t1]\n\t"
+                     "v_cmpx_lt_i32 vcc, 2, %[dg]\n\tv_add_f32 %[a], %[a], %[t2]\n\t"
+                     "v_cmpx_lt_i32 vcc, 3, %[dg]\n\tv_add_f32 %[a], %[a], %[t3]\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [a] "=&v"(a), [sv] "=&s"(saved)
+                     : [dg] "v"(deg), [t0] "v"(t[0]), [t1] "v"(t[1]), [t2] "v"(t[2]), [t3] "v"(t[3])
+                     : "vcc");
+    return a;
+}
+template<int n> __device__ __forceinline__ double masked_sum(double const (&t)[4], int deg) {
+    double a = 0;
+#pragma unroll
+    for (int j = 0; j < n; ++j) a += (j < deg) ? t[j] : 0.0;
+    return a;
+}
+
 // S: register slots per lane for stage-1 nonzeros, R: rows per lane,
 // W: waves per pair, C: right-hand sides (1 = value, 2 = value + gradient),
 // NODAL: compile the node-wise output modes (F_NODAL / F_BLOCK) in.
@@ -181,6 +233,8 @@ struct pair_solver {
     constexpr static int SETUP_CHUNK = 4;
     constexpr static int GCH = 8;                 // stage-1 gathers in flight
     constexpr static int ZPAD = 64;               // zero entries at the end of U
+    constexpr static int DU = 4;                  // stage-2 degree bound of the unrolled path
+    constexpr static int RCH = 2;                 // rows whose stage-2 reads are in flight together
     constexpr static int n_jac = PStart::jac_dims + 1 + NodeK::jac_dims + EdgeK::jac_dims;
     constexpr static int off_q = PStart::jac_dims;
     constexpr static int off_v = off_q + 1;
@@ -197,7 +251,7 @@ struct pair_solver {
     // wave-uniform integer (kept in an SGPR)
     __device__ static __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-    // stage-1 task of lane `tid` in batch kb: task index kb*T + tid = i2*nnz1 + a
+    // stage-1 task of lane `tid` in batch kb: task index kb*T + tid = i2*ldu + a
     struct task_t {
         bool ok;
         int a, i2, rs2, deg;
@@ -228,7 +282,17 @@ struct pair_solver {
             const graph_header_t h1 = headers[job.i], h2 = headers[job.j];
             const int n1 = h1.n_node, n2 = h2.n_node, N = n1 * n2;
             const int nnz1 = h1.n_nz;
-            const int ntask = nnz1 * n2;       // stage-1 tasks (a, i2), i2-major
+            // LDS strides are odd so that the per-lane addresses of one access
+            // spread over the 32 banks (n2 and nnz1 are even more often than
+            // not: 16 x 16 nodes put all rows on 2 banks, 32 nonzeros all rows'
+            // U entries on one).  p: row i1 starts at i1*ldp; U: the tasks of
+            // i2 start at i2*ldu.  Both index spaces are dealt to lanes padded
+            // -- the pad row (i1, n2) and pad task (nnz1, i2) are dead lanes
+            // (+3..6 % lanes) -- so that every store stays lane-contiguous.
+            const int ldp = n2 | 1;
+            const int ldu = nnz1 + 1;          // nnz1 = 2 * edges
+            const int NP = n1 * ldp;           // padded row space
+            const int ntask = ldu * n2;        // stage-1 tasks (a, i2), i2-major, padded
             const real q = prm.q, q0 = prm.q0;
             const real inv1q2 = real(1) / ((real(1) - q) * (real(1) - q));
             const real bscale = q * q / (q0 * q0);
@@ -297,7 +361,7 @@ struct pair_solver {
                 // pass 0 (wave-uniform, rolled): depth of every batch of this
                 // wave -> flush mask and slot count
                 {
-                    divmod_walk tf(64 * wv, T, nnz1);      // first task of the wave
+                    divmod_walk tf(64 * wv, T, ldu);       // first task of the wave
 #pragma nounroll
                     for (int f = 64 * wv; f < ntask; f += T) {
                         const int fi2 = uni(tf.hi);
@@ -314,11 +378,11 @@ struct pair_solver {
                 }
                 // pass 1 (unrolled, registers only + LDS row pointers): the
                 // nonzero pair of every slot of this lane
-                divmod_walk tk(tid, T, nnz1);          // per lane: (i2, a)
+                divmod_walk tk(tid, T, ldu);           // per lane: (i2, a)
                 int kb = 0, d = 0;
                 auto open_task = [&]() -> task_t {
                     task_t k;
-                    k.ok = kb * T + tid < ntask;
+                    k.ok = kb * T + tid < ntask && tk.lo < nnz1;
                     k.i2 = k.ok ? tk.hi : 0;
                     k.a = k.ok ? tk.lo : 0;
                     k.rs2 = lrp2[k.i2];
@@ -352,7 +416,7 @@ struct pair_solver {
                     const edge_t e1 = at32(g1.edge, a), e2 = at32(g2.edge, b);
                     const real e = prm.edge_kernel(e1, e2);
                     val[s] = ok ? e : real(0);
-                    unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)n2) + (unsigned)z2.j : 0u;
+                    unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
                     // pin the evaluation here: otherwise it is sunk below the
                     // last chunk and every slot's raw labels stay live
                     asm volatile("" : "+v"(val[s]), "+v"(col));
@@ -371,14 +435,15 @@ struct pair_solver {
             real dg[R], mi[R], x[C][R], r[C][R], p[C][R];
             int ubase[R], udeg[R];
             int D1[R], D0[R];   // wave-uniform max / min degree of the rows of batch k
+            int plain1[R];
             real rTz = 0;
             {
-                divmod_walk row(tid, T, n2);         // per lane
-                divmod_walk first(64 * wv, T, n2);   // first row of this wave (uniform)
-                divmod_walk lastw(64 * wv + 63, T, n2);   // its last row (uniform)
+                divmod_walk row(tid, T, ldp);         // per lane
+                divmod_walk first(64 * wv, T, ldp);   // first row of this wave (uniform)
+                divmod_walk lastw(64 * wv + 63, T, ldp);   // its last row (uniform)
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const bool ok = k * T + tid < N;
+                    const bool ok = k * T + tid < NP && row.lo < n2;
                     const int i1 = ok ? row.hi : 0, i2 = ok ? row.lo : 0;
                     const node_t v1 = at32(g1.node, (unsigned)i1), v2 = at32(g2.node, (unsigned)i2);
                     const real dx = real(at32(g1.degree, (unsigned)i1)) *
@@ -387,14 +452,20 @@ struct pair_solver {
                     dg[k] = ok ? dx / vx : real(0);
                     mi[k] = ok ? vx / dx : real(0);
                     const int rs = lrp1[i1];
-                    ubase[k] = ok ? (int)__umul24((unsigned)i2, (unsigned)nnz1) + rs : zbase;
+                    ubase[k] = ok ? (int)__umul24((unsigned)i2, (unsigned)ldu) + rs : zbase;
                     udeg[k] = ok ? lrp1[i1 + 1] - rs : 0;
                     // rows of one wave are consecutive: the first has the largest
                     // degree, the last the smallest (0 if the batch has dead rows)
                     const int f1 = uni(first.hi);
-                    D1[k] = (k * T + 64 * wv < N) ? uni(lrp1[f1 + 1] - lrp1[f1]) : 0;
+                    D1[k] = (k * T + 64 * wv < NP) ? uni(lrp1[f1 + 1] - lrp1[f1]) : 0;
                     const int l1 = uni(lastw.hi);
-                    D0[k] = (k * T + 64 * wv + 63 < N) ? uni(lrp1[l1 + 1] - lrp1[l1]) : 0;
+                    D0[k] = (k * T + 64 * wv + 63 < NP) ? uni(lrp1[l1 + 1] - lrp1[l1]) : 0;
+                    // (pad rows inside a batch read the zero pad unmasked)
+                    D0[k] = D0[k] < ZPAD ? D0[k] : ZPAD;
+                    // a batch of degree-1 rows (hydrogens; its dead lanes and pad
+                    // rows read the zero pad) needs no mask in stage 2
+                    plain1[k] = uni(D1[k] <= 1 && D0[k] == D1[k]);
+                    asm volatile("" : "+s"(plain1[k]));   // an SGPR now, not a sunk readfirstlane
                     const real b = ok ? dx * bscale : real(0);
                     x[0][k] = 0;
                     r[0][k] = b;
@@ -483,31 +554,66 @@ struct pair_solver {
                         for (int c = 0; c < C; ++c) acc[c][k] = 0;
                     // Rows are dealt in descending-degree order, so within batch k
                     // all 64 rows have D0[k] <= degree <= D1[k] (wave-uniform
-                    // bounds, usually equal or one apart).  Entries below D0 are
-                    // read unmasked with immediate offsets; the few between D0
-                    // and D1 select the zero pad for rows that are shorter.
+                    // bounds).
+                    int fast = uni(D1[0] <= DU);   // D1[0] bounds every degree this wave sees
+                    asm volatile("" : "+s"(fast));   // one CG loop, not two unswitched copies
+                    if (fast) {
+                        // Degrees up to DU (every molecular graph): read DU entries
+                        // of every row, back to back with immediate offsets and no
+                        // branch -- what lies past a row's degree is some other
+                        // row's entry or the zero pad -- then sum them under the
+                        // lane's own degree as EXEC mask (masked_sum), or take the
+                        // single entry as it is in a batch of degree-1 rows.  One
+                        // LDS round trip per RCH rows instead of one per entry.
+                        // (RCH rows at a time bounds the registers in flight)
 #pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        real const *const u0 = lU + ubase[k] * C;
-                        int d = 0;
-                        for (; d + 4 <= D0[k]; d += 4) {
-                            real u[C][4];
+                        for (int kc = 0; kc < R; kc += RCH) {
+                            real u[RCH][C][DU];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                            for (int k = kc; k < kc + RCH && k < R; ++k) {
+                                real const *const u0 = lU + ubase[k] * C;
 #pragma unroll
-                                for (int c = 0; c < C; ++c) u[c][j] = u0[(d + j) * C + c];
+                                for (int j = 0; j < DU; ++j)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                                    for (int c = 0; c < C; ++c) u[k - kc][c][j] = u0[j * C + c];
+                            }
 #pragma unroll
-                                for (int c = 0; c < C; ++c) acc[c][k] += u[c][j];
+                            for (int k = kc; k < kc + RCH && k < R; ++k) {
+                                // (kept as data: hoisted out of the CG loop the test
+                                // would pin an SGPR pair per row)
+                                int plain = plain1[k];   // wave-uniform
+                                asm volatile("" : "+s"(plain));
+#pragma unroll
+                                for (int c = 0; c < C; ++c) {
+                                    real (&t)[DU] = u[k - kc][c];
+                                    acc[c][k] = plain ? t[0] : masked_sum<4>(t, udeg[k]);
+                                }
+                            }
                         }
-                        for (; d < D0[k]; ++d)
+                    } else {
 #pragma unroll
-                            for (int c = 0; c < C; ++c) acc[c][k] += u0[d * C + c];
-                        for (; d < D1[k]; ++d) {
-                            real const *const src = (d < udeg[k]) ? u0 + d * C : lU + zbase * C;
+                        for (int k = 0; k < R; ++k) {
+                            real const *const u0 = lU + ubase[k] * C;
+                            int d = 0;
+                            for (; d + 4 <= D0[k]; d += 4) {
+                                real u[C][4];
 #pragma unroll
-                            for (int c = 0; c < C; ++c) acc[c][k] += src[c];
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int c = 0; c < C; ++c) u[c][j] = u0[(d + j) * C + c];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                    for (int c = 0; c < C; ++c) acc[c][k] += u[c][j];
+                            }
+                            for (; d < D0[k]; ++d)
+#pragma unroll
+                                for (int c = 0; c < C; ++c) acc[c][k] += u0[d * C + c];
+                            for (; d < D1[k]; ++d) {
+                                real const *const src = (d < udeg[k]) ? u0 + d * C : lU + zbase * C;
+#pragma unroll
+                                for (int c = 0; c < C; ++c) acc[c][k] += src[c];
+                            }
                         }
                     }
 #pragma unroll
@@ -557,10 +663,10 @@ struct pair_solver {
             const bool mirror = (flags & F_SYMMETRIC) && job.i != job.j;
             real ksum = 0;
             {
-                divmod_walk row(tid, T, n2);
+                divmod_walk row(tid, T, ldp);
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const bool ok = k * T + tid < N;
+                    const bool ok = k * T + tid < NP && row.lo < n2;
                     const int i1 = ok ? row.hi : 0, i2 = ok ? row.lo : 0;
                     row.next();
                     const node_t v1 = g1.node[i1], v2 = g2.node[i2];
@@ -611,10 +717,10 @@ struct pair_solver {
                 for (int j = 0; j < n_jac; ++j) jac[j] = 0;
                 const real Q = real(1) / (real(1) - q), Q3 = Q * Q * Q;
                 {
-                    divmod_walk row(tid, T, n2);
+                    divmod_walk row(tid, T, ldp);
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        const bool ok = k * T + tid < N;
+                        const bool ok = k * T + tid < NP && row.lo < n2;
                         const int i1 = ok ? row.hi : 0, i2 = ok ? row.lo : 0;
                         row.next();
                         const node_t v1 = g1.node[i1], v2 = g2.node[i2];
@@ -638,11 +744,11 @@ struct pair_solver {
                 job_sync<W>();
                 if constexpr (EdgeK::jac_dims > 0) {
                     // walk the stage-1 nonzeros again: row = (i1(a), i2), col = adr
-                    divmod_walk tk(tid, T, nnz1);
+                    divmod_walk tk(tid, T, ldu);
                     int kb = 0, d = 0;
                     auto open_task = [&]() -> task_t {
                         task_t k;
-                        k.ok = kb * T + tid < ntask;
+                        k.ok = kb * T + tid < ntask && tk.lo < nnz1;
                         k.i2 = k.ok ? tk.hi : 0;
                         k.a = k.ok ? tk.lo : 0;
                         k.rs2 = g2.rowptr[k.i2];
@@ -657,7 +763,7 @@ struct pair_solver {
                             const int b = ok ? cur.rs2 + d : 0;
                             const edge_t e1 = g1.edge[cur.a], e2 = g2.edge[b];
                             auto de = prm.edge_kernel._j_a_c_o_b_i_a_n_(e1, e2);
-                            const int row = g1.nz[cur.a].i * n2 + cur.i2;
+                            const int row = g1.nz[cur.a].i * ldp + cur.i2;
                             const real w = ok ? lp[row * 2 + 1] * lp[gather_index(s) * 2 + 0] : real(0);
 #pragma unroll
                             for (int j = 0; j < EdgeK::jac_dims; ++j) jac[off_e + j] += w * real(de[j]);

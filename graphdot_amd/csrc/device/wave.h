@@ -39,7 +39,8 @@ __device__ __forceinline__ float sum(float v) {
     // row_bcast:31 -> rows 2 and 3 add lane 31 (= rows 0 + 1).  Written as
     // asm: the builtin form costs an extra v_mov (old value) + v_add each.
     // (s_nop 1: two wait states between a VALU write and a DPP read of it.)
-    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\t"
+    // (not volatile: a sum nobody reads must stay removable)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\t"
                  "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc\n\t"
                  "s_nop 0"
                  : "+v"(v));

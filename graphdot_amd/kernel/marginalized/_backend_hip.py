@@ -172,7 +172,8 @@ class HIPBackend(Backend):
         self.device = kwargs.pop('device', None)
         self.real = np.dtype(kwargs.pop('real', np.float32)).type
         self.jobs_per_unit = kwargs.pop('jobs_per_unit', 8)
-        self.hipcc_extra = list(kwargs.pop('hipcc_extra', []))
+        self.hipcc_extra = list(kwargs.pop('hipcc_extra', [])) + \
+            os.environ.get('GD_HIPCC_EXTRA', '').split()
         self.variants = list(kwargs.pop('variants', VARIANTS + [GENERAL]))
         self.record_iterations = kwargs.pop('record_iterations', False)
         self.occupancy = kwargs.pop('occupancy', None)
@@ -450,7 +451,8 @@ void ${name}(params_t prm) {
         and wave w of batch k walks max(1, deg2(i2 of its first task)) slots.
         Returns the maximum over the W waves."""
         T = 64 * W
-        ntask = nnz1 * n2
+        ldu = nnz1 + 1                     # padded task stride (mgk_solver.h)
+        ntask = ldu * n2
         worst = np.zeros(len(nnz1), dtype=np.int64)
         nb = int(-(-ntask.max() // T)) if len(ntask) else 0
         for w in range(W):
@@ -460,7 +462,7 @@ void ${name}(params_t prm) {
                 live = first < ntask
                 if not live.any():
                     break
-                i2 = np.where(live, first // np.maximum(nnz1, 1), 0)
+                i2 = np.where(live, first // ldu, 0)
                 d = np.maximum(deg_sorted[jj, i2], 1)
                 total += np.where(live, d, 0)
             worst = np.maximum(worst, total)
@@ -478,12 +480,13 @@ void ${name}(params_t prm) {
         n1, n2 = n_node[ji], n_node[jj]
         nnz1 = n_nz[ji]
         N = n1 * n2
+        NP = n1 * (n2 | 1)                 # row space with the odd LDS stride
         cost = n_nz[ji] * n_nz[jj] + 4 * N
         choice = np.full(len(ji), -1, dtype=np.int64)
         slots = {}
         # U entries per pair: one per stage-1 task; the region also stages the
         # CSR row pointers of both graphs during setup
-        ntask = np.maximum(nnz1 * n2, n1 + n2 + 2)
+        ntask = np.maximum((nnz1 + 1) * n2, n1 + n2 + 2)
         image = np.array([g.image_bytes for g in dgraphs], dtype=np.int64)
         gbytes = np.maximum(image[ji], image[jj])
         for k, v in enumerate(self.variants):
@@ -492,7 +495,7 @@ void ${name}(params_t prm) {
                 break
             if v == GENERAL:
                 continue
-            fits = (todo & (N <= 64 * v.W * v.R) & (N <= 0xFFFF)
+            fits = (todo & (NP <= 64 * v.W * v.R) & (NP <= 0xFFFF)
                     & (self.lds_bytes(v, C, ntask, gbytes) <= LDS_LIMIT))
             if not fits.any():
                 continue

@@ -113,16 +113,19 @@ def test_job_classification_respects_variant_capacity():
     assert np.all(choice >= 0)
     for k, (a, b) in enumerate(zip(i, j)):
         v = backend.variants[choice[k]]
-        assert n[a] * n[b] <= 64 * v.W * v.R
-        assert ntask[k] == max(nz[a] * n[b], n[a] + n[b] + 2)
+        # rows and stage-1 tasks live in index spaces with odd strides
+        # (ldp = n2 | 1, ldu = nnz1 + 1: LDS bank spreading, mgk_solver.h)
+        assert n[a] * (n[b] | 1) <= 64 * v.W * v.R
+        ldu = nz[a] + 1
+        assert ntask[k] == max(ldu * n[b], n[a] + n[b] + 2)
         # brute-force the stage-1 walk of mgk_solver.h for this job
         T = 64 * v.W
         deg = dgs[b].adjacency_count
         worst = 0
         for w in range(v.W):
             total, kb = 0, 0
-            while kb * T + 64 * w < nz[a] * n[b]:
-                total += max(1, deg[(kb * T + 64 * w) // nz[a]])
+            while kb * T + 64 * w < ldu * n[b]:
+                total += max(1, deg[(kb * T + 64 * w) // ldu])
                 kb += 1
             worst = max(worst, total)
         assert worst <= v.S
