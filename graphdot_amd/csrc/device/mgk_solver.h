@@ -174,6 +174,23 @@ struct divmod_walk {
     }
 };
 
+// LDS byte offset of a pointer into __shared__ memory
+template<class T> __device__ __forceinline__ unsigned lds_offset(T *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) T *)p;
+}
+
+// base[lane] = v for the 64 lanes of a wave, `base` wave-uniform: the store
+// takes its address from M0 + 4 lane (ds_write_addtid_b32), i.e. no address
+// VGPR and half the LDS cycles of ds_write_b32 (MI355X_MICROARCH.md, LDS).
+// The compiler does not count this store in lgkmcnt, which can only make its
+// own waits stricter; it is used where only the issuing wave reads the data
+// back (LDS operations of one wave execute in order).
+template<int BYTE_OFFSET> __device__ __forceinline__ void store_lane_contiguous(unsigned base, float v) {
+    // (s_nop: one wait state between an SALU write of M0 and the add-TID store)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%2"
+                 :: "s"(base), "v"(v), "n"(BYTE_OFFSET) : "memory", "m0");
+}
+
 // sum_{j < n, j < deg} t[j] per lane, n <= 4: the entries past a lane's own
 // degree hold other rows' data and are kept out by the EXEC mask, which only
 // shrinks as j grows (v_cmpx writes it): two VALU per entry.
@@ -234,7 +251,12 @@ struct pair_solver {
     constexpr static int GCH = 8;                 // stage-1 gathers in flight
     constexpr static int ZPAD = 64;               // zero entries at the end of U
     constexpr static int DU = 4;                  // stage-2 degree bound of the unrolled path
-    constexpr static int RCH = 2;                 // rows whose stage-2 reads are in flight together
+#ifndef GD_RCH
+#define GD_RCH 2
+#endif
+    constexpr static int RCH = GD_RCH;            // rows whose stage-2 reads are in flight together
+    // one wave per pair, one float per entry: stores of U and p go through M0
+    constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4;
     constexpr static int n_jac = PStart::jac_dims + 1 + NodeK::jac_dims + EdgeK::jac_dims;
     constexpr static int off_q = PStart::jac_dims;
     constexpr static int off_v = off_q + 1;
@@ -257,6 +279,22 @@ struct pair_solver {
         int a, i2, rs2, deg;
     };
 
+    // lp[row * C + c] = p[c][k] for the rows k*T + tid of this thread
+    template<int k = 0>
+    __device__ static __forceinline__ void publish_p(real *lp, int tid, real const (&p)[C][R]) {
+        if constexpr (ADDTID) {
+            if constexpr (k < R) {
+                store_lane_contiguous<k * T * 4>(lds_offset(lp), (float)p[0][k]);
+                publish_p<k + 1>(lp, tid, p);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < R; ++kk)
+#pragma unroll
+                for (int c = 0; c < C; ++c) lp[(kk * T + tid) * C + c] = p[c][kk];
+        }
+    }
+
     __device__ static __forceinline__ void run(P const &prm, lds_t &lds, real *dyn) {
         const int lane = wave::laneid();
         const int slot = (W == 1) ? uni((int)(threadIdx.x / 64)) : 0;  // pair slot in workgroup
@@ -270,6 +308,7 @@ struct pair_solver {
         char *const lG1 = dyn_slot + prm.u_capacity * C * sizeof(real);
         char *const lG2 = lG1 + prm.g_capacity;
         real *const red = lds.red[slot];
+        const unsigned lU_off = uni((int)lds_offset(lU));
         graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
 
 #ifdef GD_STAMPS
@@ -487,10 +526,7 @@ struct pair_solver {
             GD_STAMP(t_setup);
             // ---- publish p ---------------------------------------------------
             job_sync<W>();  // everyone is done with the staged row pointers
-#pragma unroll
-            for (int k = 0; k < R; ++k)
-#pragma unroll
-                for (int c = 0; c < C; ++c) lp[(k * T + tid) * C + c] = p[c][k];
+            publish_p(lp, tid, p);
             rTz = block_reduce<real, W>::sum(rTz, red);
 
             const real tol = (C == 2) ? real(1e-10) * real(2 * N) : prm.ftol * real(N);
@@ -531,10 +567,15 @@ struct pair_solver {
 #pragma unroll
                                 for (int c = 0; c < C; ++c) acc[c] += val[s] * g[c][j];
                                 if ((fmv[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
+                                    if constexpr (ADDTID) {
+                                        store_lane_contiguous<0>(lU_off + kb * (T * 4), (float)acc[0]);
+                                        acc[0] = 0;
+                                    } else {
 #pragma unroll
-                                    for (int c = 0; c < C; ++c) {
-                                        lU[(kb * T + tid) * C + c] = acc[c];
-                                        acc[c] = 0;
+                                        for (int c = 0; c < C; ++c) {
+                                            lU[(kb * T + tid) * C + c] = acc[c];
+                                            acc[c] = 0;
+                                        }
                                     }
                                     ++kb;
                                 }
@@ -648,10 +689,8 @@ struct pair_solver {
 #pragma unroll
                 for (int k = 0; k < R; ++k)
 #pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        p[c][k] = z[c][k] + beta * p[c][k];
-                        lp[(k * T + tid) * C + c] = p[c][k];
-                    }
+                    for (int c = 0; c < C; ++c) p[c][k] = z[c][k] + beta * p[c][k];
+                publish_p(lp, tid, p);
                 rTz = rTz_next;
             }
             if (prm.iters != nullptr && tid == 0) prm.iters[prm.order[t]] = it;
