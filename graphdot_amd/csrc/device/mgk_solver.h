@@ -228,9 +228,18 @@ template<int n> __device__ __forceinline__ float masked_sum(float const (&t)[4],
     return a;
 }
 template<int n> __device__ __forceinline__ double masked_sum(double const (&t)[4], int deg) {
+    static_assert(n == 4, "the double build only instantiates the 4-entry sum");
     double a = 0;
-#pragma unroll
-    for (int j = 0; j < n; ++j) a += (j < deg) ? t[j] : 0.0;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_lt_i32 vcc, 0, %[dg]\n\tv_add_f64 %[a], %[a], %[t0]\n\t"
+                 "v_cmpx_lt_i32 vcc, 1, %[dg]\n\tv_add_f64 %[a], %[a], %[t1]\n\t"
+                 "v_cmpx_lt_i32 vcc, 2, %[dg]\n\tv_add_f64 %[a], %[a], %[t2]\n\t"
+                 "v_cmpx_lt_i32 vcc, 3, %[dg]\n\tv_add_f64 %[a], %[a], %[t3]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [a] "+v"(a), [sv] "=&s"(saved)
+                 : [dg] "v"(deg), [t0] "v"(t[0]), [t1] "v"(t[1]), [t2] "v"(t[2]), [t3] "v"(t[3])
+                 : "vcc");
     return a;
 }
 

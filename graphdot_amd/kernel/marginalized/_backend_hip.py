@@ -352,9 +352,17 @@ struct ${name}_t : ${name}_theta_t {
             return f'mgk_general_T{GENERAL_THREADS}_C{C}'
         return f'mgk_W{v.W}_S{v.S}_R{v.R}_C{C}' + ('_nodal' if nodal else '')
 
-    #: measured highest (near) spill-free occupancy of the fp32 value solver,
-    #: W = 1 (hipcc 7.2, gfx950): S -> waves per SIMD
-    _WAVES_F32_VALUE = {8: 6, 12: 6, 16: 5, 20: 4, 24: 3, 28: 3, 32: 2}
+    #: occupancy targets of the fp32 value solver, W = 1 (hipcc 7.2, gfx950):
+    #: S -> waves per SIMD.  Spill-free or nearly so, except S = 24 where 16
+    #: VGPRs spilled around (never inside) the CG loop buy 4 instead of 3
+    #: waves: +7 % on the whole Gram matrix for 2 KB of scratch traffic per
+    #: pair.  S = 16 at 6 waves and S = 28 at 4 are another +3 % but write
+    #: 5-10 KB of scratch per pair to HBM (profiles/README.md) -- not taken.
+    _WAVES_F32_VALUE = {8: 6, 12: 6, 16: 5, 20: 4, 24: 4, 28: 3, 32: 2}
+    #: same for the value + gradient solver (C = 2) and the fp64 value solver:
+    #: the fastest of a per-variant sweep (scripts/occupancy_sweep2.sh)
+    _WAVES_F32_GRADIENT = {8: 5, 12: 4, 16: 3, 20: 2, 24: 2, 28: 2, 32: 1}
+    _WAVES_F64_VALUE = {8: 4, 12: 4, 16: 3, 20: 3, 24: 2, 28: 2, 32: 1}
 
     def waves_per_eu(self, v, C):
         """Occupancy target handed to the register allocator
@@ -367,9 +375,13 @@ struct ${name}_t : ${name}_theta_t {
         floor = -(-64 * v.W * (4 if v.W == 1 else 1) // 256)  # block must fit
         if self.occupancy is not None and (v.W, v.S) in self.occupancy:
             return max(self.occupancy[(v.W, v.S)], floor)
-        if (v.W == 1 and C == 1 and self.real is np.float32
-                and v.S in self._WAVES_F32_VALUE):
-            return self._WAVES_F32_VALUE[v.S]
+        if v.W == 1:
+            f64 = np.dtype(self.real) == np.float64
+            table = {(1, False): self._WAVES_F32_VALUE,
+                     (2, False): self._WAVES_F32_GRADIENT,
+                     (1, True): self._WAVES_F64_VALUE}.get((C, f64), {})
+            if v.S in table:
+                return max(table[v.S], floor)
         need = 5.3 * v.S + 4 * v.R + 6
         if C == 2:
             need = 1.6 * need
