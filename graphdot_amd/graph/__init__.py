@@ -100,13 +100,22 @@ class Graph:
     def has_unified_types(graphs):
         """True, or ``(component, first, offender)`` on the first mismatch of
         node/edge row types."""
+        def rowtypes(g):
+            # cached in the cookie, which every mutation of a graph clears
+            try:
+                return g.cookie['rowtypes']
+            except KeyError:
+                t = g.cookie['rowtypes'] = (g.nodes.rowtype(),
+                                            g.edges.rowtype())
+                return t
+
         first = next(iter(graphs))
-        node_t = first.nodes.rowtype()
-        edge_t = first.edges.rowtype()
+        node_t, edge_t = rowtypes(first)
         for other in graphs:
-            if other.nodes.rowtype() != node_t:
+            nt, et = rowtypes(other)
+            if nt is not node_t and nt != node_t:
                 return ('nodes', first, other)
-            if other.edges.rowtype() != edge_t:
+            if et is not edge_t and et != edge_t:
                 return ('edges', first, other)
         return True
 

@@ -12,6 +12,7 @@ There is no CPU path: a missing ``libgdhip.so`` / hipcc / device raises.
 import copy
 import os
 import uuid
+import zlib
 import warnings
 from collections import OrderedDict, namedtuple
 import numpy as np
@@ -140,6 +141,11 @@ class Plan:
     pass
 
 
+class Layout:
+    """The hyperparameter-independent part of a Plan (HIPBackend._layout)."""
+    pass
+
+
 class HIPBackend(Backend):
     """MI355X backend.
 
@@ -191,6 +197,8 @@ class HIPBackend(Backend):
         self._modules = {}                 # (tu key) -> runtime.Module
         self._arenas = OrderedDict()       # tuple(id(DeviceGraph)) -> (arena, buf)
         self._pool = {}                    # name -> DeviceBuffer (grow-only)
+        self._layouts = OrderedDict()      # job-list key -> Layout (LRU)
+        self.layout_cache_size = 8
         self._props = None
         self.last_plan = None
 
@@ -245,9 +253,10 @@ class HIPBackend(Backend):
         buf.upload(arena.relocated(buf.ptr))
         runtime.synchronize()
         self._arenas[key] = (arena, buf, list(dgraphs))
+        # evicted arenas are released when the last layout / plan that points
+        # into them is gone (DeviceBuffer frees on destruction)
         while len(self._arenas) > 4:
-            _, (_, old, _) = self._arenas.popitem(last=False)
-            old.free()
+            self._arenas.popitem(last=False)
         return self._arenas[key]
 
     # -- code generation --------------------------------------------------------
@@ -532,121 +541,54 @@ void ${name}(params_t prm) {
         return choice, cost, ntask, gbytes
 
     # -- the three phases -----------------------------------------------------------
-    def _frontend(self, graphs, node_kernel, edge_kernel, p, jobs, traits,
-                  timer=None):
-        """Host-only half of `prepare`: pack graphs, partition the jobs and
-        render one translation unit per solver variant in use."""
+    def _graphs_and_kernels(self, graphs, edge_kernel, traits, timer=None):
+        """Pack (or fetch the cached packing of) every graph; wrap the edge
+        kernel for weighted graphs; pick the solver flavour C."""
         tic = timer.tic if timer else (lambda *_: None)
         toc = timer.toc if timer else (lambda *_: None)
         tic('transferring graphs to GPU')
         dgraphs = []
         for i, g in enumerate(graphs):
             dg = self._register_graph(g)
-            if i > 0:
+            if i > 0 and dg.signature != dgraphs[0].signature:
                 self._assert_homogeneous(dgraphs[0], dg)
             dgraphs.append(dg)
         toc('transferring graphs to GPU')
-
         if traits.eval_gradient is True and traits.nodal is not False:
             raise NotImplementedError(
                 'nodal gradients are evaluated by finite differences over '
                 'value launches (HIPBackend._nodal_gradient), not by a '
                 'gradient plan')
         C = 2 if traits.eval_gradient is True else 1
-
-        tic('code generation')
         if dgraphs[0].weighted:
             edge_kernel = TensorProduct(weight=Product(), label=edge_kernel)
+        return dgraphs, edge_kernel, C
+
+    def _partition(self, dgraphs, jobs, C):
+        """Host half of a layout: solver variant per job, launch order (by
+        variant, then descending cost) and launch geometry.  No device."""
         jobs = np.ascontiguousarray(jobs)
         ji = jobs['i'].astype(np.int64)
         jj = jobs['j'].astype(np.int64)
         choice, cost, ntask, gbytes = self.classify(ji, jj, dgraphs, C)
         used = sorted(set(choice.tolist()))
-        nodal = traits.nodal is not False
-        sources = {k: self.render_source(node_kernel, edge_kernel, p,
-                                         dgraphs[0].node_t, dgraphs[0].edge_t,
-                                         [self.variants[k]], C, nodal)
-                   for k in used}
-        toc('code generation')
-        return dgraphs, edge_kernel, jobs, C, choice, cost, ntask, gbytes, \
-            used, sources
-
-    def precompile(self, graphs, node_kernel, edge_kernel, p, jobs, traits):
-        """Compile (into the on-disk JIT cache) every code object that
-        `prepare` would need for this call.  Needs hipcc but no device."""
-        *_, sources = self._frontend(graphs, node_kernel, edge_kernel, p,
-                                     jobs, traits)
-        return jit.compile_many(list(sources.values()), self.hipcc_extra)
-
-    def prepare(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
-                jobs, starts, nX, nY, nJ, traits, timer=None, packed=False,
-                gramian_ptr=None, gradient_ptr=None):
-        """Upload graphs / jobs, generate + compile code, partition the jobs.
-        Returns a Plan whose launches can be replayed.  `gramian_ptr` /
-        `gradient_ptr` (device addresses) make the kernels write into
-        caller-owned memory, e.g. the tensor handed to the all-gather."""
-        tic = timer.tic if timer else (lambda *_: None)
-        toc = timer.toc if timer else (lambda *_: None)
-        runtime.ensure_device(self.device)
-        (dgraphs, edge_kernel, jobs, C, choice, cost, ntask, gbytes, used,
-         sources) = self._frontend(graphs, node_kernel, edge_kernel, p, jobs,
-                                   traits, timer)
-        arena, arena_buf, _ = self._arena(dgraphs)
-
-        tic('JIT')
-        missing = [s for s in sources.values()
-                   if jit.cache_key(s, self.hipcc_extra) not in self._modules]
-        if len(missing) > 1:
-            jit.compile_many(missing, self.hipcc_extra)
-        modules = {k: self._module(s) for k, s in sources.items()}
-        toc('JIT')
-
-        tic('calculating launch configuration')
-        plan = Plan()
-        plan.traits, plan.C, plan.n_jobs = traits, C, len(jobs)
-        plan.nX, plan.nY, plan.nJ = int(nX), int(nY), int(nJ)
-        plan.packed = packed
-        plan.keep = (arena, arena_buf, dgraphs)
-        flags = 0
-        if traits.nodal is True or traits.nodal == 'block':
-            flags |= F_NODAL
-        if traits.nodal == 'block':
-            flags |= F_BLOCK
-        if traits.diagonal:
-            flags |= F_DIAGONAL
-        if traits.symmetric:
-            flags |= F_SYMMETRIC
-        if traits.lmin == 1:
-            flags |= F_LMIN1
-        if packed:
-            flags |= F_PACKED
         rsize = np.dtype(self.real).itemsize
-        n_out = len(jobs) if packed else plan.nX * plan.nY
-        plan.n_out = n_out
-        plan.n_grad = n_out * plan.nJ if C == 2 else 0
-
+        n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
         order_all = np.empty(len(jobs), dtype=np.uint32)
-        ji = jobs['i'].astype(np.int64)
-        jj = jobs['j'].astype(np.int64)
         launches, cursor = [], 0
         for k in used:
             v = self.variants[k]
             idx = np.flatnonzero(choice == k)
             idx = idx[np.argsort(-cost[idx], kind='stable')]
             order_all[cursor:cursor + len(idx)] = idx.astype(np.uint32)
-            fn = modules[k].function(self.kernel_name(
-                v, C, traits.nodal is not False))
             if v == GENERAL:
                 # one workgroup per pair, CG vectors + U in global scratch
-                N_ = (arena.n_node[ji[idx]] * arena.n_node[jj[idx]])
+                N_ = n_node[ji[idx]] * n_node[jj[idx]]
                 per_wg = int(((3 * N_ + ntask[idx]) * C).max())
-                grid = int(min(len(idx), 2 * self.props.compute_units))
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=per_wg, gcap=0,
-                    dynamic_lds=0,
-                    count=len(idx), grid=grid, threads=GENERAL_THREADS,
-                    fn=fn, module=modules[k],
-                    scratch_bytes=grid * per_wg * rsize))
+                    dynamic_lds=0, count=len(idx), grid=None,
+                    threads=GENERAL_THREADS, per_wg=per_wg))
                 cursor += len(idx)
                 continue
             wpb = 4 if v.W == 1 else 1
@@ -661,43 +603,176 @@ void ${name}(params_t prm) {
             ucap = int(-(-ntask[idx].max() // 64) * 64) + 64   # + zero pad
             gcap = int(-(-gbytes[idx].max() // 16) * 16)
             dyn = (ucap * C * rsize + 2 * gcap) * wpb
-            if dyn > 64 * 1024:
-                runtime.set_max_dynamic_lds(fn, dyn)
             launches.append(dict(variant=v, k=k, offset=cursor, ucap=ucap,
-                                 gcap=gcap, dynamic_lds=dyn,
-                                 count=len(idx), grid=grid, threads=threads,
-                                 fn=fn,
-                                 module=modules[k]))
+                                 gcap=gcap, dynamic_lds=dyn, count=len(idx),
+                                 grid=grid, threads=threads))
             cursor += len(idx)
-        plan.order_host = order_all
+        return jobs, used, order_all, launches
+
+    def _sources(self, used, node_kernel, edge_kernel, p, dgraphs, C, nodal):
+        """One translation unit per solver variant in use.  The node / edge /
+        start-probability code is shared text; only the entry point differs."""
+        out = {}
+        for k in used:
+            out[k] = self.render_source(node_kernel, edge_kernel, p,
+                                        dgraphs[0].node_t, dgraphs[0].edge_t,
+                                        [self.variants[k]], C, nodal)
+        return out
+
+    def _frontend(self, graphs, node_kernel, edge_kernel, p, jobs, traits,
+                  timer=None):
+        """Host-only half of `prepare` (used by `precompile`): pack graphs,
+        partition the jobs and render one translation unit per solver variant
+        in use."""
+        dgraphs, edge_kernel, C = self._graphs_and_kernels(
+            graphs, edge_kernel, traits, timer)
+        jobs, used, order_all, launches = self._partition(dgraphs, jobs, C)
+        sources = self._sources(used, node_kernel, edge_kernel, p, dgraphs, C,
+                                traits.nodal is not False)
+        return dgraphs, edge_kernel, jobs, C, used, order_all, launches, \
+            sources
+
+    def precompile(self, graphs, node_kernel, edge_kernel, p, jobs, traits):
+        """Compile (into the on-disk JIT cache) every code object that
+        `prepare` would need for this call.  Needs hipcc but no device."""
+        *_, sources = self._frontend(graphs, node_kernel, edge_kernel, p,
+                                     jobs, traits)
+        return jit.compile_many(list(sources.values()), self.hipcc_extra)
+
+    def _layout(self, dgraphs, jobs, starts, C, timer=None):
+        """Everything of a plan that depends only on WHICH pairs of WHICH
+        graphs are evaluated: variant per job, launch order and geometry, and
+        the device copies of the job list, the order and `starts`.  Cached
+        (LRU) on the identity of the packed graphs and a checksum of the job
+        list, so that repeated evaluations with new hyperparameters -- the
+        training loop of a Gaussian process -- skip the host-side work and
+        the uploads."""
+        jobs = np.ascontiguousarray(jobs)
+        starts = np.ascontiguousarray(starts, dtype=np.uint32)
+        # a read-only job list is recognised by identity (the kernel object
+        # keeps its lists that way), anything else by checksum
+        jobs_id = ('id', id(jobs)) if not jobs.flags.writeable else \
+            ('crc', zlib.crc32(jobs.view(np.uint8)))
+        key = (tuple(map(id, dgraphs)), len(jobs), jobs_id,
+               zlib.crc32(starts.view(np.uint8)), C)
+        hit = self._layouts.get(key)
+        if hit is not None:
+            self._layouts.move_to_end(key)
+            return hit
+        tic = timer.tic if timer else (lambda *_: None)
+        toc = timer.toc if timer else (lambda *_: None)
+        tic('calculating launch configuration')
+        lay = Layout()
+        lay.dgraphs = list(dgraphs)          # keeps the ids in `key` alive
+        lay.jobs_host = jobs
+        lay.arena, lay.arena_buf, _ = self._arena(dgraphs)
+        jobs, lay.used, lay.order_host, lay.launches = self._partition(
+            dgraphs, jobs, C)
+        lay.n_jobs = len(jobs)
+        lay.b_jobs = runtime.DeviceBuffer(max(jobs.nbytes, 8))
+        lay.b_order = runtime.DeviceBuffer(max(lay.order_host.nbytes, 4))
+        lay.b_starts = runtime.DeviceBuffer(max(starts.nbytes, 4))
+        # jobs travel in launch order: the kernel reads jobs[t] directly
+        lay.b_jobs.upload(np.ascontiguousarray(
+            jobs[lay.order_host]).view(np.uint32))
+        lay.b_order.upload(lay.order_host)
+        lay.b_starts.upload(starts)
+        # uploads were issued on the null stream; solver launches may go to
+        # non-blocking streams, which do not wait for it
+        runtime.synchronize()
+        self._layouts[key] = lay
+        while len(self._layouts) > self.layout_cache_size:
+            self._layouts.popitem(last=False)    # freed with its last plan
+        toc('calculating launch configuration')
+        return lay
+
+    def prepare(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
+                jobs, starts, nX, nY, nJ, traits, timer=None, packed=False,
+                gramian_ptr=None, gradient_ptr=None):
+        """Upload graphs / jobs, generate + compile code, partition the jobs.
+        Returns a Plan whose launches can be replayed.  `gramian_ptr` /
+        `gradient_ptr` (device addresses) make the kernels write into
+        caller-owned memory, e.g. the tensor handed to the all-gather."""
+        tic = timer.tic if timer else (lambda *_: None)
+        toc = timer.toc if timer else (lambda *_: None)
+        runtime.ensure_device(self.device)
+        dgraphs, edge_kernel, C = self._graphs_and_kernels(
+            graphs, edge_kernel, traits, timer)
+        lay = self._layout(dgraphs, jobs, starts, C, timer)
+
+        tic('code generation')
+        nodal = traits.nodal is not False
+        sources = self._sources(lay.used, node_kernel, edge_kernel, p,
+                                dgraphs, C, nodal)
+        toc('code generation')
+        tic('JIT')
+        missing = [s for s in sources.values()
+                   if jit.cache_key(s, self.hipcc_extra) not in self._modules]
+        if len(missing) > 1:
+            jit.compile_many(missing, self.hipcc_extra)
+        modules = {k: self._module(s) for k, s in sources.items()}
+        toc('JIT')
+
+        plan = Plan()
+        plan.layout = lay
+        plan.traits, plan.C, plan.n_jobs = traits, C, lay.n_jobs
+        plan.nX, plan.nY, plan.nJ = int(nX), int(nY), int(nJ)
+        plan.packed = packed
+        plan.keep = (lay.arena, lay.arena_buf, dgraphs)
+        plan.order_host = lay.order_host
+        flags = 0
+        if traits.nodal is True or traits.nodal == 'block':
+            flags |= F_NODAL
+        if traits.nodal == 'block':
+            flags |= F_BLOCK
+        if traits.diagonal:
+            flags |= F_DIAGONAL
+        if traits.symmetric:
+            flags |= F_SYMMETRIC
+        if traits.lmin == 1:
+            flags |= F_LMIN1
+        if packed:
+            flags |= F_PACKED
+        rsize = np.dtype(self.real).itemsize
+        n_out = lay.n_jobs if packed else plan.nX * plan.nY
+        plan.n_out = n_out
+        plan.n_grad = n_out * plan.nJ if C == 2 else 0
+
+        launches = []
+        for G in lay.launches:
+            L = dict(G)
+            L['module'] = modules[L['k']]
+            L['fn'] = fn = L['module'].function(
+                self.kernel_name(L['variant'], C, nodal))
+            if L['variant'] == GENERAL:
+                L['grid'] = int(min(L['count'],
+                                    2 * self.props.compute_units))
+                L['scratch_bytes'] = L['grid'] * L['per_wg'] * rsize
+            elif L['dynamic_lds'] > 64 * 1024:
+                runtime.set_max_dynamic_lds(fn, L['dynamic_lds'])
+            launches.append(L)
         plan.launches = launches
 
-        # device buffers
-        b_jobs = self._buffer('jobs', jobs.nbytes)
-        b_order = self._buffer('order', order_all.nbytes)
-        b_starts = self._buffer('starts', np.asarray(starts).nbytes)
+        # per-call device buffers (outputs, scratch) from the grow-only pool
         b_out = self._buffer('gramian', n_out * rsize)
         b_grad = self._buffer('gradient', plan.n_grad * rsize) \
             if C == 2 else None
-        b_iters = self._buffer('iters', 4 * len(jobs)) \
+        b_iters = self._buffer('iters', 4 * lay.n_jobs) \
             if self.record_iterations else None
         scratch_bytes = max([L.get('scratch_bytes', 0) for L in launches]
                             + [0])
         b_scratch = self._buffer('scratch', scratch_bytes) \
             if scratch_bytes else None
-        # jobs travel in launch order: the kernel reads jobs[t] directly
-        b_jobs.upload(np.ascontiguousarray(jobs[order_all]).view(np.uint32))
-        b_order.upload(order_all)
-        b_starts.upload(np.ascontiguousarray(starts, dtype=np.uint32))
-        plan.buffers = dict(jobs=b_jobs, order=b_order, starts=b_starts,
-                            gramian=b_out, gradient=b_grad, iters=b_iters)
+        plan.buffers = dict(jobs=lay.b_jobs, order=lay.b_order,
+                            starts=lay.b_starts, gramian=b_out,
+                            gradient=b_grad, iters=b_iters)
 
         # kernel argument blocks
         pd = self._params_dtype(node_kernel, edge_kernel, p)
         base = np.zeros((), dtype=pd)
-        base['arena'] = arena_buf.ptr
-        base['jobs'] = b_jobs.ptr
-        base['starts'] = b_starts.ptr
+        base['arena'] = lay.arena_buf.ptr
+        base['jobs'] = lay.b_jobs.ptr
+        base['starts'] = lay.b_starts.ptr
         base['gramian'] = gramian_ptr if gramian_ptr else b_out.ptr
         base['gradient'] = gradient_ptr if gradient_ptr else (
             b_grad.ptr if b_grad is not None else 0)
@@ -715,18 +790,14 @@ void ${name}(params_t prm) {
                 base[field] = val
         for L in launches:
             a = base.copy()
-            a['order'] = b_order.ptr + 4 * L['offset']
-            a['jobs'] = b_jobs.ptr + 8 * L['offset']
+            a['order'] = lay.b_order.ptr + 4 * L['offset']
+            a['jobs'] = lay.b_jobs.ptr + 8 * L['offset']
             a['g_capacity'] = L['gcap']
             a['n_launch_jobs'] = L['count']
             a['order_offset'] = L['offset']
             a['u_capacity'] = L['ucap']
             L['args'] = a.tobytes()
         plan.params_dtype = pd
-        # uploads were issued on the null stream; solver launches may go to
-        # non-blocking streams, which do not wait for it
-        runtime.synchronize()
-        toc('calculating launch configuration')
         self.last_plan = plan
         return plan
 
@@ -761,17 +832,24 @@ void ${name}(params_t prm) {
         gradient entries) per job, in job order."""
         runtime.synchronize()
         rs = np.dtype(self.real)
-        out = np.empty(plan.n_out, dtype=rs)
-        plan.buffers['gramian'].download(out)
+
+        def fetch(buf, n, dest):
+            # straight into the caller's array when it can take the bytes
+            if (isinstance(dest, np.ndarray) and dest.dtype == rs
+                    and dest.size == n and dest.flags.c_contiguous
+                    and dest.flags.writeable):
+                buf.download(dest.reshape(-1))
+                return dest.reshape(-1)
+            out = np.empty(n, dtype=rs)
+            buf.download(out)
+            if dest is not None:
+                dest[:] = out.reshape(dest.shape)
+            return out
+
+        out = fetch(plan.buffers['gramian'], plan.n_out, gramian)
         grad = None
         if plan.C == 2:
-            grad = np.empty(plan.n_grad, dtype=rs)
-            plan.buffers['gradient'].download(grad)
-        if gramian is not None:
-            gramian[:] = out
-        if gradient is not None and grad is not None:
-            gradient[:] = grad.reshape(gradient.shape) if plan.packed \
-                else grad
+            grad = fetch(plan.buffers['gradient'], plan.n_grad, gradient)
         return out, grad
 
     def iterations(self, plan):

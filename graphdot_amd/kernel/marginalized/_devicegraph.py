@@ -199,6 +199,8 @@ class DeviceGraph:
         else:
             edge_t = label_t
         self.edge_t = edge_t
+        # cheap equality token for "same node / edge record types"
+        self.signature = (self.weighted, str(self.node_t), str(edge_t))
         edges_aos = np.zeros(nnz, dtype=edge_t)
         edge_fa = []
         target = edges_aos['label'] if self.weighted and label_t.itemsize \

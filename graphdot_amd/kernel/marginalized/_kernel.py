@@ -13,6 +13,7 @@ import itertools as it
 import numbers
 import warnings
 from collections import namedtuple
+from collections import OrderedDict
 import numpy as np
 from ...graph import Graph
 from ...util import Timer
@@ -109,6 +110,33 @@ class MarginalizedGraphKernel:
         raise ValueError(f'Unknown starting probability: {p}')
 
     # ------------------------------------------------------------------ Gram
+    _jobs_cache = OrderedDict()     # (nx, ny) -> read-only job list (shared)
+
+    def _pairwise_jobs(self, nx, ny=None):
+        """The job list of the reference (_kernel.py:172-182): the upper
+        triangle including the diagonal for a symmetric matrix, all (i, nx+j)
+        otherwise.  Lists are kept (read-only) so that the backend can
+        recognise a repeated evaluation by the identity of the array."""
+        cache = MarginalizedGraphKernel._jobs_cache
+        key = (nx, ny)
+        if key in cache:
+            cache.move_to_end(key)
+            return cache[key]
+        if ny is None:
+            i, j = np.triu_indices(nx)
+            i, j = i.astype(np.uint32), j.astype(np.uint32)
+        else:
+            i, j = np.indices((nx, ny), dtype=np.uint32)
+            j = j + np.uint32(nx)
+        jobs = self.backend.array(
+            np.column_stack((i.ravel(), j.ravel())).ravel().view(_job_t))
+        if isinstance(jobs, np.ndarray):
+            jobs.flags.writeable = False
+            cache[key] = jobs
+            while len(cache) > 8:
+                cache.popitem(last=False)
+        return jobs
+
     def __call__(self, X, Y=None, eval_gradient=False, nodal=False, lmin=0,
                  timing=False):
         """Pairwise similarity matrix.
@@ -143,14 +171,7 @@ class MarginalizedGraphKernel:
 
         timer.tic('generating jobs')
         nx = len(X)
-        if traits.symmetric:
-            i, j = np.triu_indices(nx)
-            i, j = i.astype(np.uint32), j.astype(np.uint32)
-        else:
-            i, j = np.indices((nx, len(Y)), dtype=np.uint32)
-            j = j + np.uint32(nx)
-        jobs = backend.array(
-            np.column_stack((i.ravel(), j.ravel())).ravel().view(_job_t))
+        jobs = self._pairwise_jobs(nx, None if traits.symmetric else len(Y))
         timer.toc('generating jobs')
 
         timer.tic('creating output buffer')
@@ -201,8 +222,10 @@ class MarginalizedGraphKernel:
         gramian = gramian.reshape(*output_shape, order='F')
         if gradient is not None:
             gradient = gradient.reshape(
-                (*output_shape, self.n_dims), order='F'
-            )[:, :, self.active_theta_mask]
+                (*output_shape, self.n_dims), order='F')
+            mask = np.asarray(self.active_theta_mask)
+            if not mask.all():      # (a copy; skipped when nothing is fixed)
+                gradient = gradient[:, :, mask]
         timer.toc('collecting result')
 
         if timing:
@@ -210,9 +233,9 @@ class MarginalizedGraphKernel:
         timer.reset()
 
         if traits.eval_gradient is True:
-            return (gramian.astype(self.element_dtype),
-                    gradient.astype(self.element_dtype))
-        return gramian.astype(self.element_dtype)
+            return (gramian.astype(self.element_dtype, copy=False),
+                    gradient.astype(self.element_dtype, copy=False))
+        return gramian.astype(self.element_dtype, copy=False)
 
     # ------------------------------------------------------------------ diag
     def diag(self, X, eval_gradient=False, nodal=False, lmin=0,

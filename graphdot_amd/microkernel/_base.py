@@ -446,11 +446,21 @@ def _from_sympy(name, desc, expr, vars, *hyperparameter_specs, minmax=(0, 1)):
                         for n, v in self._theta_bounds.items()])
 
         def gen_expr(self, x, y, theta_scope=''):
-            nmap = {str(self._vars[0]): x, str(self._vars[1]): y}
-            nmap.update({t: theta_scope + t for t in self._hyperdefs})
-            return (hipcxxcode(self._expr, nmap),
-                    [hipcxxcode(sy.diff(self._expr, h), nmap)
-                     for h in self._hyperdefs])
+            # the strings depend on the class and the names only, never on
+            # hyperparameter values: printed once (SymPy printing is ~1 ms
+            # per expression, paid on every kernel evaluation otherwise)
+            cache = type(self).__dict__.get('_expr_cache')
+            if cache is None:
+                cache = type(self)._expr_cache = {}
+            key = (x, y, theta_scope)
+            if key not in cache:
+                nmap = {str(self._vars[0]): x, str(self._vars[1]): y}
+                nmap.update({t: theta_scope + t for t in self._hyperdefs})
+                cache[key] = (hipcxxcode(self._expr, nmap),
+                              [hipcxxcode(sy.diff(self._expr, h), nmap)
+                               for h in self._hyperdefs])
+            fun, jac = cache[key]
+            return fun, list(jac)
 
         @property
         def dtype(self):

@@ -241,3 +241,49 @@ def test_template_and_cpptype():
     assert decltype(k) == 'struct{float32 h;int32 n;}'
     with pytest.raises(TypeError):
         k.h = 'x'
+
+
+def test_job_lists_are_cached_read_only_and_match_the_reference_order():
+    """_kernel.py:172-182 of the reference: upper triangle incl. diagonal,
+    row-major, for a symmetric matrix; (i, nx + j) for X x Y."""
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._backend import Backend
+    from graphdot_amd.microkernel import Constant
+
+    class Dummy(Backend):
+        array = staticmethod(lambda a: a)
+
+        def __call__(self, *args, **kwargs):
+            raise AssertionError
+
+    k = MarginalizedGraphKernel(Constant(1.0), Constant(1.0), q=0.05,
+                                backend=Dummy())
+    jobs = k._pairwise_jobs(4)
+    assert [tuple(x) for x in jobs] == [
+        (0, 0), (0, 1), (0, 2), (0, 3), (1, 1), (1, 2), (1, 3), (2, 2),
+        (2, 3), (3, 3)]
+    assert not jobs.flags.writeable
+    assert k._pairwise_jobs(4) is jobs
+    full = k._pairwise_jobs(2, 3)
+    assert [tuple(x) for x in full] == [
+        (0, 2), (0, 3), (0, 4), (1, 2), (1, 3), (1, 4)]
+
+
+def test_row_type_cache_follows_graph_mutation():
+    import networkx as nx
+    from graphdot_amd.graph import Graph
+    a = nx.path_graph(3)
+    b = nx.path_graph(4)
+    for g, v in ((a, 1), (b, 1.5)):
+        for n in g.nodes:
+            g.nodes[n]['x'] = v
+        for e in g.edges:
+            g.edges[e]['w'] = 1.0
+    ga, gb = Graph.from_networkx(a, weight='w'), Graph.from_networkx(b, weight='w')
+    assert Graph.has_unified_types([ga, ga]) is True
+    bad = Graph.has_unified_types([ga, gb])
+    assert bad is not True and bad[0] == 'nodes'
+    ua, ub = Graph.unify_datatype([ga, gb])
+    assert Graph.has_unified_types([ua, ub]) is True
+    Graph.unify_datatype([ga, gb], inplace=True)      # clears the cookies
+    assert Graph.has_unified_types([ga, gb]) is True

@@ -531,3 +531,61 @@ def test_packed_shard_output_matches_matrix(backend):
     Kr = plans[0].assemble(np.concatenate(slabs))
     assert np.allclose(Kr, K, rtol=1e-6)
     assert np.count_nonzero(Kr - Kr.T) == 0
+
+
+def test_repeated_evaluation_reuses_the_layout(backend):
+    """The training-loop pattern: the same graphs evaluated again with new
+    hyperparameters.  The second call must hit the cached job layout (no
+    re-partitioning, no uploads) and still agree with a fresh backend; and a
+    layout must survive the eviction of its graph arena from the arena cache
+    (more than four other graph lists in between)."""
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    G = cases.config3_graphs(40, seed=11)
+    knode, kedge, q = cases.config3_kernels()
+    mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    K0, dK0 = mlgk(G, eval_gradient=True)
+    n_layouts = len(backend._layouts)
+    lay = next(reversed(backend._layouts.values()))
+    mlgk.theta = mlgk.theta + 0.05
+    K1, dK1 = mlgk(G, eval_gradient=True)
+    assert len(backend._layouts) == n_layouts           # a hit
+    assert next(reversed(backend._layouts.values())) is lay
+    fresh = MarginalizedGraphKernel(knode, kedge, q=q, backend=HIPBackend())
+    fresh.theta = mlgk.theta
+    K2, dK2 = fresh(G, eval_gradient=True)
+    assert np.array_equal(K1, K2) and np.array_equal(dK1, dK2)
+    assert not np.allclose(K0, K1, rtol=1e-6)           # theta did change
+    ref = oracle.gram(G[:6], mlgk.node_kernel, mlgk.edge_kernel, q=mlgk.q,
+                      p=float(mlgk.p.theta[0]))
+    assert np.allclose(K1[:6, :6], ref, rtol=1e-5)
+    # other graph lists push the arena (4 entries) out, the layout stays
+    for k in range(6):
+        mlgk(G[k:k + 5])
+    K3, _ = mlgk(G, eval_gradient=True)
+    assert np.array_equal(K3, K1)
+    # a writable job list is recognised by content, a changed one is not reused
+    job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
+    jobs = np.array([(0, 1), (2, 3), (4, 4)], dtype=job_t)
+    starts = np.arange(len(G) + 1, dtype=np.uint32)
+
+    def run(jobs):
+        out = np.zeros(len(G) ** 2, dtype=np.float32)
+        backend(G, mlgk.node_kernel, mlgk.edge_kernel, mlgk.p, mlgk.q,
+                mlgk.eps, mlgk.ftol, mlgk.gtol, jobs, starts, out, None,
+                len(G), len(G), mlgk.n_dims, mlgk.traits(symmetric=True),
+                mlgk.timer if hasattr(mlgk, 'timer') else _NoTimer())
+        return out.reshape(len(G), len(G), order='F')
+    A = run(jobs)
+    assert A[0, 1] == pytest.approx(K1[0, 1], rel=1e-6)
+    assert A[2, 3] == pytest.approx(K1[2, 3], rel=1e-6)
+    jobs[1] = (5, 6)
+    B = run(jobs)
+    assert B[5, 6] == pytest.approx(K1[5, 6], rel=1e-6)
+
+
+class _NoTimer:
+    def tic(self, *_):
+        pass
+
+    def toc(self, *_):
+        pass
