@@ -135,6 +135,27 @@ def main():
                            starts, n, n, nJ, traits, packed=(world > 1),
                            **out_ptrs)
 
+    # device-side reassembly of the gathered slabs into the F-order matrix
+    # (+ mirror; + one plane per gradient column): part of every step, so
+    # that a step ends with the same product at any N
+    t_src = t_dst = K_dev = None
+    if world > 1:
+        cap = shard.capacity
+        dst, slot, mdst, mslot = shard.scatter_index(
+            starts.astype(np.int64), starts.astype(np.int64))
+        all_dst = np.concatenate((dst, mdst))
+        all_slot = np.concatenate((slot, mslot))
+        r_, pos = all_slot // cap, all_slot % cap
+        srcs = [r_ * cap * n_cols + pos]
+        dsts = [all_dst]
+        for c in range(n_cols - 1):
+            srcs.append(r_ * cap * n_cols + cap + pos * (n_cols - 1) + c)
+            dsts.append((c + 1) * n * n + all_dst)
+        t_src = torch.from_numpy(np.concatenate(srcs)).cuda()
+        t_dst = torch.from_numpy(np.concatenate(dsts)).cuda()
+        K_dev = torch.zeros(n_cols * n * n, dtype=tdtype, device='cuda')
+        torch.cuda.synchronize()
+
     events = [runtime.Event() for _ in range(len(plan.launches) + 1)]
     kernel_ms = np.zeros(len(plan.launches))
 
@@ -177,6 +198,7 @@ def main():
                 gathered.copy_(g)
             else:
                 dist.all_gather_into_tensor(gathered, local_out)
+            K_dev.index_copy_(0, t_dst, gathered.index_select(0, t_src))
             ev_gathered.record()
 
     def sync():
@@ -227,8 +249,10 @@ def main():
     if world > 1:
         # reassemble the gathered slabs and compare a sample with the oracle
         from oracle import mgk
-        K = shard.assemble(gathered.cpu().numpy().reshape(
+        K = K_dev[:n * n].cpu().numpy().reshape(n, n, order='F')
+        K_host = shard.assemble(gathered.cpu().numpy().reshape(
             world, -1)[:, :shard.capacity].ravel())
+        assert np.array_equal(K, K_host), 'device and host reassembly differ'
         rng = np.random.default_rng(1)
         probe = rng.choice(n_pairs, size=min(3000, n_pairs), replace=False)
         batch = mgk.TensorProductBatch(graphs, knode, kedge)

@@ -177,7 +177,7 @@ class HIPBackend(Backend):
         self.uuid = uuid.uuid4()
         self.device = kwargs.pop('device', None)
         self.real = np.dtype(kwargs.pop('real', np.float32)).type
-        self.jobs_per_unit = kwargs.pop('jobs_per_unit', 8)
+        self.jobs_per_unit = kwargs.pop('jobs_per_unit', 1)
         self.hipcc_extra = list(kwargs.pop('hipcc_extra', [])) + \
             os.environ.get('GD_HIPCC_EXTRA', '').split()
         self.variants = list(kwargs.pop('variants', VARIANTS + [GENERAL]))
@@ -593,11 +593,12 @@ void ${name}(params_t prm) {
                 continue
             wpb = 4 if v.W == 1 else 1
             threads = 64 * v.W * wpb
-            # Many small workgroups (a few pairs per wave) rather than one
-            # persistent grid: the hardware dispatcher then balances the load
-            # whatever the achieved residency is (a grid of exactly
-            # CUs x blocks_per_cu left a near-idle second round when only
-            # blocks_per_cu - 1 workgroups fitted a CU).
+            # Many small workgroups (jobs_per_unit pairs per wave, default
+            # one) rather than one persistent grid: the hardware dispatcher
+            # then balances the load whatever the achieved residency is, and
+            # a launch of few jobs (a rare variant, one rank's shard of a
+            # multi-GPU run) still covers the chip.  Measured: 1 pair per wave
+            # = 8 per wave + 1 % on 500 500 pairs, + 28 % on 61 000.
             per_unit = self.jobs_per_unit
             grid = int(max(1, -(-len(idx) // (wpb * per_unit))))
             ucap = int(-(-ntask[idx].max() // 64) * 64) + 64   # + zero pad
