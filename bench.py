@@ -2,7 +2,7 @@
 """Gram-matrix throughput of the marginalized graph kernel on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-                    [--graphs 1000] [--dtype f32|f64] [--gradient]
+                    [--graphs 1000] [--dtype f64|f32] [--gradient]
 
 A *step* is one full pass of the hot path over the batch: every pair of the
 symmetric Gram matrix of the synthetic QM7-like set (config 3 of
@@ -10,6 +10,10 @@ BASELINE.json) is solved from device-resident graphs, job list
 and hyperparameters into the device-resident result.  With N > 1 (launched by
 torch.distributed.run, one rank per GPU) the pairs are sharded over the ranks
 and one RCCL all-gather per step reassembles the packed results.
+
+The default arithmetic is fp64, as BASELINE.json names it for this
+configuration; the reference's CUDA solver computes in fp32, and a short fp32
+measurement of the same step is reported in the same line ("other_arithmetic").
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with the
 extra objects "roofline" (dominant kernel, HIP-event timed inside the timed
@@ -35,7 +39,13 @@ def parse():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--graphs', type=int, default=1000)
-    ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
+    ap.add_argument('--dtype', default='f64', choices=['f32', 'f64'],
+                    help='arithmetic of the solver: f64 is what BASELINE.json '
+                         'names for the QM7-1000 configuration (default); '
+                         'f32 is the arithmetic of the reference CUDA solver')
+    ap.add_argument('--no-f32', action='store_true',
+                    help='skip the short fp32 measurement reported next to '
+                         'an fp64 run')
     ap.add_argument('--gradient', action='store_true',
                     help='also evaluate dK/dtheta (config 5 kernel part)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -61,6 +71,34 @@ def algorithmic_flops(n_node, n_nz, ji, jj, iters, Fv=9, Fe=8):
     N = n_node[ji] * n_node[jj]
     nnzx = n_nz[ji] * n_nz[jj]
     return iters * (2 * nnzx + 17 * N) + nnzx * Fe + N * Fv
+
+
+def measure_other_arithmetic(name, graphs, knode, kedge, q, jobs, starts, n,
+                             steps, warmup, device):
+    """Short measurement of the same step in the other arithmetic (N = 1):
+    reported next to the headline number, never instead of it."""
+    from graphdot_amd.hip import runtime
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    real = np.float32 if name == 'f32' else np.float64
+    backend = HIPBackend(device=device, real=real)
+    kernel = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    plan = backend.prepare(graphs, knode, kedge, kernel.p, kernel.q,
+                           kernel.eps, kernel.ftol, kernel.gtol, jobs, starts,
+                           n, n, kernel.n_dims,
+                           kernel.traits(symmetric=True))
+    for _ in range(max(warmup, 1)):
+        backend.launch(plan)
+    runtime.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        backend.launch(plan)
+        runtime.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {'dtype': name, 'value': len(jobs) / dt, 'unit': 'graph-pairs/s',
+            'ms_per_step': 1e3 * dt, 'steps': steps,
+            'note': 'same step, same graphs, solver built for the other '
+                    'arithmetic (f32 = the reference CUDA solver\'s)'}
 
 
 def main():
@@ -296,8 +334,8 @@ def main():
     # has been committed (scripts/profile.sh + scripts/summarize_profile.py)
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-            tr = json.load(f)['kernels'].get(roofline['kernel'])
-        if tr and args.dtype == 'f32' and not args.gradient and world == 1:
+            tr = json.load(f)[args.dtype]['kernels'].get(roofline['kernel'])
+        if tr and not args.gradient and world == 1:
             roofline['traffic'] = tr['hbm_bytes_per_launch']
             roofline['traffic_source'] = 'profiles/traffic.json (rocprofv3 ' \
                 'FETCH_SIZE + WRITE_SIZE, separate passes)'
@@ -341,6 +379,13 @@ def main():
         err = np.max(np.abs(K[i[sample], j[sample]] / ref - 1))
         cpu['max_rel_diff_vs_gpu'] = float(err)
 
+    other = None
+    if world == 1 and args.dtype == 'f64' and not args.no_f32 \
+            and not args.gradient:
+        other = measure_other_arithmetic(
+            'f32', graphs, knode, kedge, q, all_jobs, starts, n,
+            max(args.steps // 2, 3), args.warmup, local_rank)
+
     line = {
         'metric': 'graph-pairs/sec (Gram matrix)', 'value': value,
         'unit': 'graph-pairs/s', 'n_gpus': world, 'steps': args.steps,
@@ -350,13 +395,15 @@ def main():
         'config': {
             'workload': f'QM7-like synthetic set ({n} molecules, seed 7165, '
                         f'{n_pairs} pairs incl. diagonal), TensorProduct '
-                        'atom/bond microkernels, q=0.01'
+                        'atom/bond microkernels, q=0.01, '
+                        + ('fp64' if args.dtype == 'f64' else 'fp32')
                         + (', value + gradient' if args.gradient else ''),
             'graphs': n, 'pairs': n_pairs,
             'parallelism': f'pair-sharded x{world}' if world > 1 else 'single',
         },
         'roofline': roofline, 'compute': compute, 'kernels': per_kernel,
         'cpu_baseline': cpu, 'sharded_check': sharded_check,
+        'other_arithmetic': other,
     }
     print(json.dumps(line))
     if world > 1:

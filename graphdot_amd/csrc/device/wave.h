@@ -47,11 +47,28 @@ __device__ __forceinline__ float sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// 64-bit DPP move: both halves with the same control
+template<int CTRL, int ROW_MASK, bool BOUND> __device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int tlo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, BOUND);
+    const int thi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, BOUND);
+    return __hiloint2double(thi, tlo);
+}
+
+// Same reduction tree in double: v_add_f64 takes no DPP operand, so every
+// step is two v_mov_dpp + one v_add_f64 (20 instructions in all) -- against a
+// __shfl_xor butterfly, which on gfx950 is two ds_bpermute through the LDS
+// crossbar per step, i.e. six dependent LDS round trips per sum.
 __device__ __forceinline__ double sum(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-    // make the result exactly uniform (xor butterflies are, but be explicit)
-    return __shfl(v, 0, 64);
+    v += dpp_mov<0xB1, 0xF, true>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xF, true>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xF, true>(v);   // row_half_mirror
+    v += dpp_mov<0x140, 0xF, true>(v);   // row_mirror: 16-lane sums in every lane
+    v += dpp_mov<0x142, 0xA, false>(v);  // row_bcast:15 into rows 1 and 3 (others add 0)
+    v += dpp_mov<0x143, 0xC, false>(v);  // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 }  // namespace wave

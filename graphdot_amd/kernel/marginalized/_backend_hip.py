@@ -355,11 +355,13 @@ struct ${name}_t : ${name}_theta_t {
             ('p_start', theta(p)),
         ], align=True)
 
-    @staticmethod
-    def kernel_name(v, C, nodal=False):
+    def kernel_name(self, v, C, nodal=False):
+        """Entry point name: arithmetic, solver variant, flavour."""
+        f = 'f64' if np.dtype(self.real) == np.float64 else 'f32'
         if v == GENERAL:
-            return f'mgk_general_T{GENERAL_THREADS}_C{C}'
-        return f'mgk_W{v.W}_S{v.S}_R{v.R}_C{C}' + ('_nodal' if nodal else '')
+            return f'mgk_{f}_general_T{GENERAL_THREADS}_C{C}'
+        return f'mgk_{f}_W{v.W}_S{v.S}_R{v.R}_C{C}' + \
+            ('_nodal' if nodal else '')
 
     #: occupancy targets of the fp32 value solver, W = 1 (hipcc 7.2, gfx950):
     #: S -> waves per SIMD.  Spill-free or nearly so, except S = 24 where 16
@@ -371,7 +373,7 @@ struct ${name}_t : ${name}_theta_t {
     #: same for the value + gradient solver (C = 2) and the fp64 value solver:
     #: the fastest of a per-variant sweep (scripts/occupancy_sweep2.sh)
     _WAVES_F32_GRADIENT = {8: 5, 12: 4, 16: 3, 20: 2, 24: 2, 28: 2, 32: 1}
-    _WAVES_F64_VALUE = {8: 4, 12: 4, 16: 3, 20: 3, 24: 2, 28: 2, 32: 1}
+    _WAVES_F64_VALUE = {8: 5, 12: 4, 16: 3, 20: 3, 24: 2, 28: 2, 32: 2}
 
     def waves_per_eu(self, v, C):
         """Occupancy target handed to the register allocator

@@ -38,6 +38,15 @@ for k, v in traffic.items():
                                         + v.get('WRITE_SIZE_KiB', 0))
     v['hbm_bytes_per_launch_fetch_x2'] = 1024 * (
         2 * v.get('FETCH_SIZE_KiB', 0) + v.get('WRITE_SIZE_KiB', 0))
-json.dump({'source': f'profiles/{tag}_pmc.csv', 'kernels': traffic},
-          open('profiles/traffic.json', 'w'), indent=1)
+bench = json.loads([l for l in open(f'{src}/bench.json')
+                    if l.startswith('{')][-1])
+try:
+    everything = json.load(open('profiles/traffic.json'))
+    if 'kernels' in everything:          # pre-v7 layout: fp32 only
+        everything = {'f32': everything}
+except (OSError, ValueError):
+    everything = {}
+everything[bench['dtype']] = {'source': f'profiles/{tag}_pmc.csv',
+                              'kernels': traffic}
+json.dump(everything, open('profiles/traffic.json', 'w'), indent=1)
 print(json.dumps(traffic, indent=1))
