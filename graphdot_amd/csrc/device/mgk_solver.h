@@ -88,8 +88,7 @@ template<class real, class Graph, class NodeK, class EdgeK, class PStart> struct
 template<class real, int W> struct block_reduce {
     // Sum over all 64*W threads; `scratch` holds 2*W reals.
     __device__ static __forceinline__ void sum2(real &a, real &b, real *scratch) {
-        a = wave::sum(a);
-        b = wave::sum(b);
+        wave::sum2(a, b);
         if constexpr (W > 1) {
             const int w = threadIdx.x / 64;
             __syncthreads();  // previous readers of scratch are done

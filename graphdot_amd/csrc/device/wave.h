@@ -71,6 +71,38 @@ __device__ __forceinline__ double sum(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// Two wave sums for little more than the price of one.  v_permlane32_swap
+// exchanges the upper half of its first operand with the lower half of its
+// second, so after one swap and one add lanes 0-31 hold a(l) + a(l + 32) and
+// lanes 32-63 hold b(l - 32) + b(l); a 32-lane reduction (4 DPP steps + one
+// row_bcast:15) then leaves sum(a) in lane 31 and sum(b) in lane 63.
+// float: 7 VALU + 2 v_readlane instead of 12 + 2; double: 20 instead of 40.
+__device__ __forceinline__ void sum2(float &a, float &b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    float v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\ts_nop 0" : "+v"(v));
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ void sum2(double &a, double &b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    double v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    v += dpp_mov<0xB1, 0xF, true>(v);
+    v += dpp_mov<0x4E, 0xF, true>(v);
+    v += dpp_mov<0x141, 0xF, true>(v);
+    v += dpp_mov<0x140, 0xF, true>(v);
+    v += dpp_mov<0x142, 0xA, false>(v);
+    const int l = __double2loint(v), h = __double2hiint(v);
+    a = __hiloint2double(__builtin_amdgcn_readlane(h, 31), __builtin_amdgcn_readlane(l, 31));
+    b = __hiloint2double(__builtin_amdgcn_readlane(h, 63), __builtin_amdgcn_readlane(l, 63));
+}
+
 }  // namespace wave
 }  // namespace graphdot
 #endif
