@@ -85,11 +85,28 @@ def build_library(force=False):
     return LIB_PATH
 
 
+def _let_torch_initialise_first():
+    """PyTorch-ROCm ships its own copy of the HIP runtime.  If that copy is
+    initialised after this library's, torch reports no usable GPU
+    (`torch.cuda.is_available()` is False; measured on this image), the
+    other order works.  So when torch is already imported -- the multi-GPU
+    bench, the on-device algebra of model.gaussian_process -- let it go
+    first.  Nothing is imported here: the solver itself never needs torch."""
+    import sys
+    torch = sys.modules.get('torch')
+    if torch is not None:
+        try:
+            torch.cuda.is_available()
+        except Exception:
+            pass
+
+
 def lib():
     """The loaded library with argtypes set (builds it on first use)."""
     global _lib
     with _lock:
         if _lib is None:
+            _let_torch_initialise_first()
             L = ctypes.CDLL(build_library())
             for name, argtypes in SIGNATURES.items():
                 fn = getattr(L, name)

@@ -1,0 +1,188 @@
+"""GaussianProcessRegressor (graphdot_amd.model.gaussian_process) against
+direct numpy restatements of the reference's formulas (gpr.py:222-415 of the
+reference), with a small vector kernel that implements the kernel protocol --
+no GPU needed.  The marginalized graph kernel is plugged in by the GPU test
+at the end."""
+import copy
+import numpy as np
+import pytest
+from graphdot_amd.model.gaussian_process import GaussianProcessRegressor
+
+
+class RBF:
+    """k(x, y) = s^2 exp(-|x - y|^2 / (2 l^2)); theta = log([s, l])."""
+
+    def __init__(self, s=1.0, l=1.0):
+        self.s, self.l = s, l
+
+    @property
+    def theta(self):
+        return np.log([self.s, self.l])
+
+    @theta.setter
+    def theta(self, t):
+        self.s, self.l = np.exp(t)
+
+    @property
+    def bounds(self):
+        return np.log([[1e-3, 1e3], [1e-2, 1e2]])
+
+    def clone_with_theta(self, theta):
+        k = copy.deepcopy(self)
+        k.theta = theta
+        return k
+
+    def __call__(self, X, Y=None, eval_gradient=False):
+        X = np.asarray(X, float)
+        Y = X if Y is None else np.asarray(Y, float)
+        d2 = ((X[:, None, :] - Y[None, :, :])**2).sum(-1)
+        K = self.s**2 * np.exp(-0.5 * d2 / self.l**2)
+        if not eval_gradient:
+            return K
+        dK = np.stack((2 * K / self.s, K * d2 / self.l**3), axis=-1)
+        return K, dK
+
+    def diag(self, X):
+        return np.full(len(X), self.s**2)
+
+
+@pytest.fixture
+def data():
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-2, 2, size=(30, 2))
+    y = np.sin(X[:, 0]) + 0.5 * X[:, 1] + 0.05 * rng.normal(size=30)
+    return X, y
+
+
+def brute_lml(kernel, X, y, alpha):
+    K = kernel(X) + alpha * np.eye(len(X))
+    return y @ np.linalg.solve(K, y) + np.linalg.slogdet(K)[1]
+
+
+def brute_loocv(kernel, X, y, alpha):
+    K = kernel(X) + alpha * np.eye(len(X))
+    Kinv = np.linalg.inv(K)
+    e = (Kinv @ y) / np.diag(Kinv)
+    return 0.5 * (e**2).sum()
+
+
+@pytest.mark.parametrize('name,brute', [
+    ('log_marginal_likelihood', brute_lml),
+    ('squared_loocv_error', brute_loocv)])
+def test_objectives_and_gradients(data, name, brute):
+    X, y = data
+    gpr = GaussianProcessRegressor(RBF(1.3, 0.8), alpha=1e-2, device='cpu')
+    gpr.X, gpr.y = X, y
+    theta = gpr.kernel.theta + 0.1
+    val, grad = getattr(gpr, name)(theta, eval_gradient=True)
+    assert val == pytest.approx(
+        brute(gpr.kernel.clone_with_theta(theta), X, y, 1e-2), rel=1e-10)
+    assert getattr(gpr, name)(theta) == pytest.approx(val, rel=1e-12)
+    for k in range(2):
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += 1e-5
+        tm[k] -= 1e-5
+        fd = (brute(gpr.kernel.clone_with_theta(tp), X, y, 1e-2)
+              - brute(gpr.kernel.clone_with_theta(tm), X, y, 1e-2)) / 2e-5
+        assert grad[k] == pytest.approx(fd, rel=1e-5, abs=1e-7)
+    # clone_kernel=True leaves the model's kernel alone, False moves it
+    assert np.allclose(gpr.kernel.theta, theta - 0.1)
+    getattr(gpr, name)(theta, clone_kernel=False)
+    assert np.allclose(gpr.kernel.theta, theta)
+
+
+def test_fit_predict_and_loocv(data):
+    X, y = data
+    gpr = GaussianProcessRegressor(RBF(1.0, 1.0), alpha=1e-4, optimizer=True,
+                                   normalize_y=True, device='cpu')
+    before = gpr.log_marginal_likelihood(
+        gpr.kernel.theta, X=X, y=(y - y.mean()) / y.std())
+    gpr.fit(X, y, tol=1e-8)
+    after = gpr.log_marginal_likelihood()
+    assert after < before                       # the objective is minimised
+    assert np.allclose(gpr.y, y)
+    mean, std = gpr.predict(X, return_std=True)
+    assert np.abs(mean - y).max() < 0.2 and std.shape == (30,)
+    mean2, cov = gpr.predict(X[:5], return_cov=True)
+    assert np.allclose(mean2, mean[:5]) and cov.shape == (5, 5)
+    assert np.allclose(np.sqrt(np.diag(cov)), std[:5], atol=1e-8)
+    # leave-one-out prediction against refitting without each point
+    loo = gpr.predict_loocv(X, y)
+    for i in (0, 7, 29):
+        keep = np.arange(30) != i
+        g = GaussianProcessRegressor(gpr.kernel, alpha=1e-4, device='cpu',
+                                     normalize_y=False)
+        ym, ys = y.mean(), y.std()
+        g.fit(X[keep], (y[keep] - ym) / ys)
+        assert loo[i] == pytest.approx(
+            g.predict(X[i:i + 1])[0] * ys + ym, rel=1e-6, abs=1e-8)
+    with pytest.raises(RuntimeError):
+        GaussianProcessRegressor(RBF(), device='cpu').predict(X)
+
+
+def test_masked_targets_regularization_and_persistence(data, tmp_path):
+    X, y = data
+    y2 = list(y)
+    y2[3], y2[11] = None, float('nan')
+    keep = np.array([v is not None and np.isfinite(v) for v in y2])
+    gpr = GaussianProcessRegressor(RBF(1.1, 0.9), alpha=1e-3,
+                                   regularization='*', device='cpu')
+    gpr.fit(X, y2)
+    K = gpr.kernel(X[keep])
+    K[np.diag_indices_from(K)] *= 1 + 1e-3
+    assert np.allclose(gpr.K, K)
+    assert np.allclose(gpr.Ky, np.linalg.solve(K, y[keep]))
+    p = gpr.predict(X[:4])
+    gpr.save(tmp_path)
+    with pytest.raises(RuntimeError):
+        gpr.save(tmp_path)
+    other = GaussianProcessRegressor(RBF(5.0, 5.0), device='cpu')
+    other.load(tmp_path)
+    assert np.allclose(other.kernel.theta, gpr.kernel.theta)
+    assert np.allclose(other.predict(X[:4]), p)
+    with pytest.raises(RuntimeError):
+        GaussianProcessRegressor(RBF(), regularization='?',
+                                 device='cpu').fit(X, y)
+
+
+def test_singular_matrix_falls_back_to_pseudoinverse():
+    X = np.zeros((6, 1))                        # six identical inputs
+    y = np.ones(6)
+    gpr = GaussianProcessRegressor(RBF(), alpha=0.0, beta=1e-8, device='cpu')
+    with pytest.warns(UserWarning, match='singular'):
+        gpr.fit(X, y)
+    assert np.all(np.isfinite(gpr.Ky))
+    assert gpr.predict(X[:1])[0] == pytest.approx(1.0, rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpr_on_the_marginalized_graph_kernel():
+    """Configuration 5 in miniature: likelihood + gradient of a GPR whose
+    kernel is the HIP marginalized graph kernel, dense algebra on the same
+    GPU; the gradient agrees with central differences of the objective."""
+    import cases
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    G = cases.config3_graphs(40, seed=21)
+    knode, kedge, q = cases.config3_kernels()
+    kernel = MarginalizedGraphKernel(knode, kedge, q=0.05)
+    rng = np.random.default_rng(0)
+    y = rng.normal(size=len(G))
+    K0 = kernel(G)
+    gpr = GaussianProcessRegressor(kernel, alpha=float(0.5 * K0.diagonal().mean()),
+                                   normalize_y=True)
+    gpr.X, gpr.y = G, y
+    theta = np.array(kernel.theta)
+    val, grad = gpr.log_marginal_likelihood(theta, eval_gradient=True)
+    assert np.isfinite(val) and len(grad) == len(theta)
+    assert gpr._dense().device.type == 'cuda'
+    for k in range(len(theta)):
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += 1e-2
+        tm[k] -= 1e-2
+        fd = (gpr.log_marginal_likelihood(tp)
+              - gpr.log_marginal_likelihood(tm)) / 2e-2
+        assert abs(grad[k] - fd) <= 0.05 * abs(fd) \
+            + 0.02 * np.abs(grad).max() + 1e-3
+    gpr.fit(G, y)
+    mean, std = gpr.predict(G[:5], return_std=True)
+    assert mean.shape == (5,) and np.all(std >= 0)
