@@ -373,6 +373,23 @@ def main():
                'sample': f'{size} uniformly sampled pairs of the same '
                          f'{n}-graph set, oracle/mgk_oracle.c '
                          f'mgk_gram_tp_{args.dtype}, 1 thread'}
+        # same restatement, OpenMP over the pairs, every core of this host
+        # 
+        try:
+            ncore = len(os.sched_getaffinity(0))
+            size_all = int(min(n_pairs, max(4000, 0.5 * ncore * rate
+                                            * args.cpu_seconds / 2)))
+            sample_all = rng.choice(n_pairs, size=size_all, replace=False)
+            batch.run(i[probe], j[probe], q=q, real=args.dtype, omp=True)
+            t1 = time.perf_counter()
+            batch.run(i[sample_all], j[sample_all], q=q, real=args.dtype,
+                      omp=True)
+            cpu['all_cores'] = {
+                'value': size_all / (time.perf_counter() - t1),
+                'unit': 'graph-pairs/s', 'cores': ncore,
+                'sample': f'{size_all} pairs, OpenMP dynamic schedule'}
+        except Exception as e:                      # no libgomp etc.
+            cpu['all_cores'] = {'error': str(e)}
         # the sample doubles as an on-line parity check of the timed result
         got, _ = backend.collect(plan)
         K = got.reshape(n, n, order='F')
