@@ -589,3 +589,30 @@ class _NoTimer:
 
     def toc(self, *_):
         pass
+
+
+def test_pair_list_kernel(backend):
+    """AltMarginalizedGraphKernel: one similarity per requested pair, equal
+    to the matrix entries (value, lmin = 1 and the gradient extension)."""
+    from graphdot_amd.experimental.alterantive_mgk import \
+        AltMarginalizedGraphKernel
+    G = cases.config3_graphs(15, seed=4)
+    knode, kedge, q = cases.config3_kernels()
+    full = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    alt = AltMarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    ij = [(0, 0), (3, 7), (7, 3), (14, 2), (5, 5), (1, 13)]
+    K, dK = full(G, eval_gradient=True)
+    v = alt(G, ij)
+    assert v.shape == (len(ij),)
+    for t, (a, b) in enumerate(ij):
+        assert v[t] == pytest.approx(K[a, b], rel=2e-6)
+    v1 = alt(G, ij, lmin=1)
+    K1 = full(G, lmin=1)
+    assert np.allclose(v1, [K1[a, b] for a, b in ij], rtol=2e-6)
+    v2, g2 = alt(G, ij, eval_gradient=True)
+    assert g2.shape == (len(ij), dK.shape[2])
+    for t, (a, b) in enumerate(ij):
+        assert np.allclose(g2[t], dK[a, b], rtol=1e-4,
+                           atol=1e-5 * np.abs(dK).max())
+    with pytest.raises(IndexError):
+        alt(G, [(0, 15)])
