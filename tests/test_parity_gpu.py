@@ -616,3 +616,49 @@ def test_pair_list_kernel(backend):
                            atol=1e-5 * np.abs(dK).max())
     with pytest.raises(IndexError):
         alt(G, [(0, 15)])
+
+
+def test_maximin_distance(backend):
+    """MaxiMin (metric/maximin of the reference): distance, hotspot and
+    gradient against a brute-force evaluation of the definition on the nodal
+    similarities of the dense oracle."""
+    from graphdot_amd.metric.maximin import MaxiMin
+    G = cases.config3_graphs(7, seed=12)
+    knode, kedge, q = cases.config3_kernels()
+    mm = MaxiMin(knode, kedge, q=q, backend=backend)
+    D, (h1, h2) = mm(G, return_hotspot=True)
+    assert D.dtype == np.float32 and D.shape == (7, 7)
+    assert np.allclose(np.diag(D), 0, atol=2e-3)
+    assert np.array_equal(D, D.T)
+    Kn = oracle.gram(G, knode, kedge, q=q, nodal=True)
+    dn = oracle.diag(G, knode, kedge, q=q, nodal=True)
+    st = np.concatenate(([0], np.cumsum([len(g.nodes) for g in G])))
+    for a in range(7):
+        for b in range(7):
+            blk = Kn[st[a]:st[a + 1], st[b]:st[b + 1]]
+            k1, k2 = dn[st[a]:st[a + 1]], dn[st[b]:st[b + 1]]
+            d = np.sqrt(np.maximum(0, 0.9999995 - blk / np.sqrt(
+                k1[:, None] * k2[None, :])))
+            ref = max(d.min(axis=1).max(), d.min(axis=0).max())
+            assert D[a, b] == pytest.approx(ref, abs=3e-3)
+            # the reported hotspot attains the distance
+            assert d[h1[a, b], h2[a, b]] == pytest.approx(D[a, b], abs=3e-3)
+    # X vs Y blocks agree with the symmetric evaluation
+    Dxy = mm(G[:3], G[3:])
+    assert np.allclose(Dxy, D[:3, 3:], atol=1e-3)
+    # gradient against central differences of the distance (off-diagonal
+    # pairs, where the distance is not clamped at zero)
+    D0, g = mm(G[:4], eval_gradient=True)
+    theta = np.array(mm.theta)
+    assert g.shape == (4, 4, len(theta))
+    iu = np.triu_indices(4, 1)
+    for k in range(1, len(theta)):          # column 0: starting probability
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += 0.02
+        tm[k] -= 0.02
+        fd = (mm.clone_with_theta(tp)(G[:4]).astype(float)
+              - mm.clone_with_theta(tm)(G[:4]).astype(float)) / 0.04
+        got = g[..., k] * np.exp(theta[k])
+        assert np.allclose(got[iu], fd[iu], rtol=0.15,
+                           atol=0.05 * np.abs(fd[iu]).max() + 2e-3)
+    assert np.all(g[..., 0] == 0)
