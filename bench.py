@@ -319,7 +319,7 @@ def main():
     dur = kernel_ms[dom] * 1e-3
     v = L['variant']
     roofline = {
-        'bound': 'hbm', 'kernel': backend.kernel_name(v, plan.C),
+        'bound': 'hbm', 'kernel': backend.kernel_name(v, plan.C, False, L.get('tab', False)),
         'achieved': abytes / dur / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
         'frac': abytes / dur / 1e9 / 8000.0, 'traffic': None,
         'algorithmic_bytes_per_launch': abytes,
@@ -349,7 +349,8 @@ def main():
         'mean_cg_iterations': float(iters.mean()),
     }
     per_kernel = [
-        {'kernel': backend.kernel_name(l['variant'], plan.C),
+        {'kernel': backend.kernel_name(l['variant'], plan.C, False,
+                                       l.get('tab', False)),
          'pairs': int(l['count']), 'grid': int(l['grid']),
          'avg_ms': float(ms)} for l, ms in zip(plan.launches, kernel_ms)]
 

@@ -38,6 +38,7 @@
 #ifndef GRAPHDOT_HIP_MGK_SOLVER_H_
 #define GRAPHDOT_HIP_MGK_SOLVER_H_
 #include <hip/hip_runtime.h>
+#include <utility>
 #include "array.h"
 #include "fmath.h"
 #include "graph.h"
@@ -79,6 +80,9 @@ template<class real, class Graph, class NodeK, class EdgeK, class PStart> struct
     std::uint32_t order_offset;  // slot of order[0] in the packed output
     std::uint32_t u_capacity;    // tasks per pair slot in the dynamic LDS region
     std::uint32_t g_capacity;    // bytes per staged graph image in dynamic LDS
+    // label classes (GraphArena): counts and arena offsets of the class
+    // representatives node_t[n_vclass], edge_t[n_eclass]
+    std::uint32_t n_vclass, n_eclass, vrep, erep;
     real q, q0, eps, ftol, gtol;
     NodeK node_kernel;
     EdgeK edge_kernel;
@@ -245,7 +249,27 @@ template<int n> __device__ __forceinline__ double masked_sum(double const (&t)[4
 // S: register slots per lane for stage-1 nonzeros, R: rows per lane,
 // W: waves per pair, C: right-hand sides (1 = value, 2 = value + gradient),
 // NODAL: compile the node-wise output modes (F_NODAL / F_BLOCK) in.
-template<class real, int S, int R, int W, int C, bool NODAL, class Graph, class NodeK, class EdgeK, class PStart>
+// Does the edge record carry a weight (edge_t = {weight, label} for weighted
+// graphs, _devicegraph.py; the translation unit says so with GD_WEIGHTED)?
+// The class tables hold the label part only.
+#ifndef GD_WEIGHTED
+#define GD_WEIGHTED 0
+#endif
+template<class E, class = void> struct edge_weight {
+    constexpr static bool value = false;
+    __device__ static float get(E const &) { return 1.f; }
+};
+template<class E> struct edge_weight<E, decltype(void(std::declval<E const &>().weight))> {
+    constexpr static bool value = true;
+    __device__ static auto get(E const &e) { return e.weight; }
+};
+
+// TAB: the labels of this call fall into few classes (GraphArena.classes):
+//   every workgroup evaluates the node and edge microkernels once per class
+//   pair into an LDS table, and slot / row setup look values up by the u8
+//   class ids staged with the graph images instead of evaluating the
+//   microkernels per nonzero pair and per row.
+template<class real, int S, int R, int W, int C, bool NODAL, bool TAB, class Graph, class NodeK, class EdgeK, class PStart>
 struct pair_solver {
     using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
     using node_t = typename Graph::node_t;
@@ -318,6 +342,24 @@ struct pair_solver {
         real *const red = lds.red[slot];
         const unsigned lU_off = uni((int)lds_offset(lU));
         graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
+        // microkernel tables, shared by the pair slots of the workgroup:
+        // [kv: n_vclass^2][ke: n_eclass^2] behind the per-slot regions
+        real *const kvtab = reinterpret_cast<real *>(reinterpret_cast<char *>(dyn) + (size_t)WPB * slot_bytes);
+        real *const ketab = kvtab + prm.n_vclass * prm.n_vclass;
+        if constexpr (TAB) {
+            node_t const *const vr = reinterpret_cast<node_t const *>(prm.arena + prm.vrep);
+            edge_t const *const er = reinterpret_cast<edge_t const *>(prm.arena + prm.erep);
+            const unsigned nv = prm.n_vclass, ne = prm.n_eclass;
+            for (unsigned k = threadIdx.x; k < nv * nv; k += threads) {
+                const unsigned c1 = k / nv, c2 = k - c1 * nv;
+                kvtab[k] = real(prm.node_kernel(vr[c1], vr[c2]));
+            }
+            for (unsigned k = threadIdx.x; k < ne * ne; k += threads) {
+                const unsigned c1 = k / ne, c2 = k - c1 * ne;
+                ketab[k] = real(prm.edge_kernel(er[c1], er[c2]));   // weights of the representatives are 1
+            }
+            __syncthreads();
+        }
 
 #ifdef GD_STAMPS
         unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -343,6 +385,11 @@ struct pair_solver {
             const real q = prm.q, q0 = prm.q0;
             const real inv1q2 = real(1) / ((real(1) - q) * (real(1) - q));
             const real bscale = q * q / (q0 * q0);
+            // label-class section in front of each image (_devicegraph.class_bytes):
+            // u8 node classes [pad4(n)], u8 edge classes [pad4(nnz)], 16-aligned
+            const unsigned nzpad1 = ((unsigned)n1 + 3u) & ~3u, nzpad2 = ((unsigned)n2 + 3u) & ~3u;
+            const unsigned cb1 = TAB ? (nzpad1 + (((unsigned)nnz1 + 3u) & ~3u) + 15u) & ~15u : 0u;
+            const unsigned cb2 = TAB ? (nzpad2 + (((unsigned)h2.n_nz + 3u) & ~3u) + 15u) & ~15u : 0u;
 
             // ---- stage both graph images in LDS: one global round trip --------
             // A packed image is contiguous ([degree .. perm], graph.h); every
@@ -350,10 +397,10 @@ struct pair_solver {
             // attribute payloads stay in global memory behind their pointers.)
             job_sync<W>();  // previous pair is done with lU / lG
             {
-                const unsigned w1 = (h1.perm + 2u * n1 - h1.degree + 3u) / 4u;
-                const unsigned w2 = (h2.perm + 2u * n2 - h2.degree + 3u) / 4u;
-                const unsigned *const s1 = reinterpret_cast<const unsigned *>(prm.arena + h1.degree);
-                const unsigned *const s2 = reinterpret_cast<const unsigned *>(prm.arena + h2.degree);
+                const unsigned w1 = (h1.perm + 2u * n1 - h1.degree + cb1 + 3u) / 4u;
+                const unsigned w2 = (h2.perm + 2u * n2 - h2.degree + cb2 + 3u) / 4u;
+                const unsigned *const s1 = reinterpret_cast<const unsigned *>(prm.arena + h1.degree - cb1);
+                const unsigned *const s2 = reinterpret_cast<const unsigned *>(prm.arena + h2.degree - cb2);
                 unsigned *const d1 = reinterpret_cast<unsigned *>(lG1);
                 unsigned *const d2 = reinterpret_cast<unsigned *>(lG2);
                 constexpr int K = 4;   // loads in flight per graph and lane
@@ -376,8 +423,17 @@ struct pair_solver {
                 }
             }
             // graph views whose section pointers land in the LDS images
-            const Graph g1(lG1 - h1.degree, h1);
-            const Graph g2(lG2 - h2.degree, h2);
+            const Graph g1(lG1 + cb1 - h1.degree, h1);
+            const Graph g2(lG2 + cb2 - h2.degree, h2);
+            std::uint8_t const *const ncls1 = reinterpret_cast<std::uint8_t const *>(lG1);
+            std::uint8_t const *const ncls2 = reinterpret_cast<std::uint8_t const *>(lG2);
+            std::uint8_t const *const ecls1 = ncls1 + nzpad1;
+            std::uint8_t const *const ecls2 = ncls2 + nzpad2;
+            // microkernel value of a node / edge pair: table or direct
+            auto kappa_v = [&](int i1, int i2, node_t const &v1, node_t const &v2) -> real {
+                if constexpr (TAB) return kvtab[__umul24((unsigned)ncls1[i1], prm.n_vclass) + ncls2[i2]];
+                else return real(prm.node_kernel(v1, v2));
+            };
             std::uint16_t const *const lrp1 = g1.rowptr;
             std::uint16_t const *const lrp2 = g2.rowptr;
             // the last ZPAD entries of the U region stay zero: rows past N
@@ -460,8 +516,16 @@ struct pair_solver {
                     const bool ok = adr[s] != ~0u;
                     const unsigned a = ok ? (adr[s] >> 16) : 0u, b = ok ? (adr[s] & 0xFFFFu) : 0u;
                     const nz_t z1 = at32(g1.nz, a), z2 = at32(g2.nz, b);
-                    const edge_t e1 = at32(g1.edge, a), e2 = at32(g2.edge, b);
-                    const real e = prm.edge_kernel(e1, e2);
+                    real e;
+                    if constexpr (TAB) {
+                        e = ketab[__umul24((unsigned)ecls1[a], prm.n_eclass) + ecls2[b]];
+                        if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                            e *= real(edge_weight<edge_t>::get(at32(g1.edge, a))) *
+                                 real(edge_weight<edge_t>::get(at32(g2.edge, b)));
+                    } else {
+                        const edge_t e1 = at32(g1.edge, a), e2 = at32(g2.edge, b);
+                        e = prm.edge_kernel(e1, e2);
+                    }
                     val[s] = ok ? e : real(0);
                     unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
                     // pin the evaluation here: otherwise it is sunk below the
@@ -495,7 +559,7 @@ struct pair_solver {
                     const node_t v1 = at32(g1.node, (unsigned)i1), v2 = at32(g2.node, (unsigned)i2);
                     const real dx = real(at32(g1.degree, (unsigned)i1)) *
                                     real(at32(g2.degree, (unsigned)i2)) * inv1q2;
-                    const real vx = prm.node_kernel(v1, v2);
+                    const real vx = kappa_v(i1, i2, v1, v2);
                     dg[k] = ok ? dx / vx : real(0);
                     mi[k] = ok ? vx / dx : real(0);
                     const int rs = lrp1[i1];
@@ -718,7 +782,7 @@ struct pair_solver {
                     row.next();
                     const node_t v1 = g1.node[i1], v2 = g2.node[i2];
                     real xi = x[0][k];
-                    if (flags & F_LMIN1) xi -= real(prm.node_kernel(v1, v2)) * bscale;
+                    if (flags & F_LMIN1) xi -= kappa_v(i1, i2, v1, v2) * bscale;
                     const real pp = real(prm.p_start(v1)) * real(prm.p_start(v2));
                     const real rv = ok ? xi * pp : real(0);
                     ksum += rv;

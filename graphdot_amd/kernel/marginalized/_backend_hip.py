@@ -23,7 +23,7 @@ from ...hip import jit, runtime
 from ...microkernel import TensorProduct, Product
 from ...util.iterable import flatten, fold_like
 from ._backend import Backend
-from ._devicegraph import DeviceGraph, GraphArena
+from ._devicegraph import DeviceGraph, GraphArena, class_bytes
 
 _TEMPLATE = os.path.join(os.path.dirname(__file__), 'template.hip')
 
@@ -47,6 +47,9 @@ VARIANTS = [
 GENERAL = Variant(0, 0, 0)
 GENERAL_THREADS = 1024
 LDS_LIMIT = 160 * 1024
+#: microkernel value tables (label classes) are used when they fit this much
+#: LDS per workgroup: (n_node_classes^2 + n_edge_classes^2) reals
+TABLE_LDS_LIMIT = 8 * 1024
 
 
 def _real_name(real):
@@ -184,6 +187,12 @@ class HIPBackend(Backend):
         self.record_iterations = kwargs.pop('record_iterations', False)
         self.occupancy = kwargs.pop('occupancy', None)
         self.concurrent = kwargs.pop('concurrent', True)
+        # microkernel value tables over label classes: a gain where the
+        # microkernels are expensive (fp64: software exp; -16 % VALU, +2..5 %),
+        # a loss in fp32 (-4 %: v_exp_f32 is one instruction) -- 'auto'
+        tables = kwargs.pop('tables', 'auto')
+        self.tables = (np.dtype(self.real) == np.float64) \
+            if tables == 'auto' else bool(tables)
         self._streams = []
         if self.occupancy is None and os.environ.get('GD_OCCUPANCY'):
             # e.g. GD_OCCUPANCY="1:16:5,1:24:4"  (W:S:waves)
@@ -242,13 +251,33 @@ class HIPBackend(Backend):
                 'try to normalize automatically with '
                 '`Graph.unify_datatype`.')
 
-    def _arena(self, dgraphs):
-        key = tuple(id(g) for g in dgraphs)
+    @staticmethod
+    def _used_fields(kernel):
+        """Attributes a microkernel reads: the keys of a composite
+        (TensorProduct / Additive), or None (= any) for everything else."""
+        kk = getattr(kernel, 'kw_kernels', None)
+        return tuple(sorted(kk)) if kk is not None else None
+
+    def _table_bytes(self, arena):
+        """LDS bytes of the microkernel tables of `arena`'s label classes, or
+        0 if this call evaluates the microkernels directly (tables disabled,
+        labels not numberable, or tables beyond TABLE_LDS_LIMIT)."""
+        c = arena.classes
+        if not self.tables or c is None:
+            return 0
+        b = (c['nv']**2 + c['ne']**2) * np.dtype(self.real).itemsize
+        return int(-(-b // 16) * 16) if b <= TABLE_LDS_LIMIT else 0
+
+    def _host_arena(self, dgraphs, fields):
+        return GraphArena(dgraphs, *fields)
+
+    def _arena(self, dgraphs, fields=(None, None)):
+        key = (tuple(id(g) for g in dgraphs), fields)
         hit = self._arenas.get(key)
         if hit is not None:
             self._arenas.move_to_end(key)
             return hit
-        arena = GraphArena(dgraphs)
+        arena = self._host_arena(dgraphs, fields)
         buf = runtime.DeviceBuffer(arena.nbytes)
         buf.upload(arena.relocated(buf.ptr))
         runtime.synchronize()
@@ -348,6 +377,8 @@ struct ${name}_t : ${name}_theta_t {
             ('nY', np.uint32), ('nJ', np.uint32), ('flags', np.uint32),
             ('order_offset', np.uint32), ('u_capacity', np.uint32),
             ('g_capacity', np.uint32),
+            ('n_vclass', np.uint32), ('n_eclass', np.uint32),
+            ('vrep', np.uint32), ('erep', np.uint32),
             ('q', self.real), ('q0', self.real), ('eps', self.real),
             ('ftol', self.real), ('gtol', self.real),
             ('node_kernel', theta(node_kernel)),
@@ -355,13 +386,13 @@ struct ${name}_t : ${name}_theta_t {
             ('p_start', theta(p)),
         ], align=True)
 
-    def kernel_name(self, v, C, nodal=False):
+    def kernel_name(self, v, C, nodal=False, tab=False):
         """Entry point name: arithmetic, solver variant, flavour."""
         f = 'f64' if np.dtype(self.real) == np.float64 else 'f32'
         if v == GENERAL:
             return f'mgk_{f}_general_T{GENERAL_THREADS}_C{C}'
         return f'mgk_{f}_W{v.W}_S{v.S}_R{v.R}_C{C}' + \
-            ('_nodal' if nodal else '')
+            ('_nodal' if nodal else '') + ('_tab' if tab else '')
 
     #: occupancy targets of the fp32 value solver, W = 1 (hipcc 7.2, gfx950):
     #: S -> waves per SIMD.  Spill-free or nearly so, except S = 24 where 16
@@ -403,7 +434,7 @@ struct ${name}_t : ${name}_theta_t {
                 return max(n, floor)
         return max(1, floor)
 
-    def _entry_point(self, v, C, nodal=False):
+    def _entry_point(self, v, C, nodal=False, tab=False):
         if v == GENERAL:
             return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
@@ -420,21 +451,23 @@ extern "C" __global__ __launch_bounds__(${threads})
 __attribute__((amdgpu_waves_per_eu(${waves})))
 void ${name}(params_t prm) {
     using solver = graphdot::mgk::pair_solver<real_t, ${S}, ${R}, ${W}, ${C},
-        ${nodal}, graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
+        ${nodal}, ${tab}, graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
     __shared__ typename solver::lds_t lds;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     solver::run(prm, lds, reinterpret_cast<real_t *>(dyn_lds));
 }
-''').render(threads=threads, name=self.kernel_name(v, C, nodal), S=v.S,
-            R=v.R, W=v.W, C=C, waves=self.waves_per_eu(v, C),
-            nodal='true' if nodal else 'false')
+''').render(threads=threads, name=self.kernel_name(v, C, nodal, tab),
+            S=v.S, R=v.R, W=v.W, C=C, waves=self.waves_per_eu(v, C),
+            nodal='true' if nodal else 'false',
+            tab='true' if tab else 'false')
 
     def render_source(self, node_kernel, edge_kernel, p, node_t, edge_t,
-                      variants, C, nodal=False):
+                      variants, C, nodal=False, tab=False, weighted=False):
         """Full translation unit for the given solver variants."""
         pd = self._params_dtype(node_kernel, edge_kernel, p)
         return Template(_TEMPLATE).render(
             real=_real_name(self.real),
+            weighted='1' if weighted else '0',
             node_t=declstruct(node_t, 'node_t'),
             edge_t=declstruct(edge_t, 'edge_t'),
             node_kernel=self.gencode_kernel(node_kernel, 'node_kernel',
@@ -445,7 +478,7 @@ void ${name}(params_t prm) {
             node_size=np.dtype(node_t).itemsize,
             edge_size=max(np.dtype(edge_t).itemsize, 1),
             params_size=pd.itemsize,
-            entry_points=[self._entry_point(v, C, nodal)
+            entry_points=[self._entry_point(v, C, nodal, tab)
                           for v in variants] + [''],
         )
 
@@ -458,14 +491,15 @@ void ${name}(params_t prm) {
         return mod
 
     # -- job partitioning ---------------------------------------------------------
-    def lds_bytes(self, v, C, ntask=0, gbytes=0):
-        """LDS bytes of one workgroup: static p + scratch, dynamic U and the
-        two staged graph images."""
+    def lds_bytes(self, v, C, ntask=0, gbytes=0, tab_bytes=0):
+        """LDS bytes of one workgroup: static p + scratch, dynamic U, the two
+        staged graph images per pair slot and the microkernel tables."""
         wpb = 4 if v.W == 1 else 1
         T = 64 * v.W
         ucap = -(-np.asarray(ntask) // 64) * 64 + 64
         return ((v.R * T + ucap) * C * wpb + wpb * 2 * v.W) \
-            * np.dtype(self.real).itemsize + wpb * 2 * np.asarray(gbytes)
+            * np.dtype(self.real).itemsize + wpb * 2 * np.asarray(gbytes) \
+            + tab_bytes
 
     @staticmethod
     def slots_needed(nnz1, n2, jj, deg_sorted, W):
@@ -491,7 +525,7 @@ void ${name}(params_t prm) {
             worst = np.maximum(worst, total)
         return worst
 
-    def classify(self, ji, jj, dgraphs, C):
+    def classify(self, ji, jj, dgraphs, C, tab_bytes=0):
         """Assign every job the cheapest solver variant it fits.
         Returns (variant_index[n_jobs], cost[n_jobs])."""
         n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
@@ -511,6 +545,8 @@ void ${name}(params_t prm) {
         # CSR row pointers of both graphs during setup
         ntask = np.maximum((nnz1 + 1) * n2, n1 + n2 + 2)
         image = np.array([g.image_bytes for g in dgraphs], dtype=np.int64)
+        if tab_bytes:      # the label-class section is staged with the image
+            image = image + class_bytes(n_node, n_nz)
         gbytes = np.maximum(image[ji], image[jj])
         for k, v in enumerate(self.variants):
             todo = choice < 0
@@ -519,7 +555,8 @@ void ${name}(params_t prm) {
             if v == GENERAL:
                 continue
             fits = (todo & (NP <= 64 * v.W * v.R) & (NP <= 0xFFFF)
-                    & (self.lds_bytes(v, C, ntask, gbytes) <= LDS_LIMIT))
+                    & (self.lds_bytes(v, C, ntask, gbytes, tab_bytes)
+                       <= LDS_LIMIT))
             if not fits.any():
                 continue
             if v.W not in slots:
@@ -543,7 +580,8 @@ void ${name}(params_t prm) {
         return choice, cost, ntask, gbytes
 
     # -- the three phases -----------------------------------------------------------
-    def _graphs_and_kernels(self, graphs, edge_kernel, traits, timer=None):
+    def _graphs_and_kernels(self, graphs, node_kernel, edge_kernel, traits,
+                            timer=None):
         """Pack (or fetch the cached packing of) every graph; wrap the edge
         kernel for weighted graphs; pick the solver flavour C."""
         tic = timer.tic if timer else (lambda *_: None)
@@ -562,17 +600,22 @@ void ${name}(params_t prm) {
                 'value launches (HIPBackend._nodal_gradient), not by a '
                 'gradient plan')
         C = 2 if traits.eval_gradient is True else 1
+        # attributes the microkernels read: label classes are numbered over
+        # these (before the weighted wrapper: the weight is not a label)
+        fields = (self._used_fields(node_kernel),
+                  self._used_fields(edge_kernel))
         if dgraphs[0].weighted:
             edge_kernel = TensorProduct(weight=Product(), label=edge_kernel)
-        return dgraphs, edge_kernel, C
+        return dgraphs, edge_kernel, C, fields
 
-    def _partition(self, dgraphs, jobs, C):
+    def _partition(self, dgraphs, jobs, C, tab_bytes=0):
         """Host half of a layout: solver variant per job, launch order (by
         variant, then descending cost) and launch geometry.  No device."""
         jobs = np.ascontiguousarray(jobs)
         ji = jobs['i'].astype(np.int64)
         jj = jobs['j'].astype(np.int64)
-        choice, cost, ntask, gbytes = self.classify(ji, jj, dgraphs, C)
+        choice, cost, ntask, gbytes = self.classify(ji, jj, dgraphs, C,
+                                                    tab_bytes)
         used = sorted(set(choice.tolist()))
         rsize = np.dtype(self.real).itemsize
         n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
@@ -605,21 +648,24 @@ void ${name}(params_t prm) {
             grid = int(max(1, -(-len(idx) // (wpb * per_unit))))
             ucap = int(-(-ntask[idx].max() // 64) * 64) + 64   # + zero pad
             gcap = int(-(-gbytes[idx].max() // 16) * 16)
-            dyn = (ucap * C * rsize + 2 * gcap) * wpb
+            dyn = (ucap * C * rsize + 2 * gcap) * wpb + tab_bytes
             launches.append(dict(variant=v, k=k, offset=cursor, ucap=ucap,
                                  gcap=gcap, dynamic_lds=dyn, count=len(idx),
                                  grid=grid, threads=threads))
             cursor += len(idx)
         return jobs, used, order_all, launches
 
-    def _sources(self, used, node_kernel, edge_kernel, p, dgraphs, C, nodal):
+    def _sources(self, used, node_kernel, edge_kernel, p, dgraphs, C, nodal,
+                 tab=False):
         """One translation unit per solver variant in use.  The node / edge /
         start-probability code is shared text; only the entry point differs."""
         out = {}
         for k in used:
             out[k] = self.render_source(node_kernel, edge_kernel, p,
                                         dgraphs[0].node_t, dgraphs[0].edge_t,
-                                        [self.variants[k]], C, nodal)
+                                        [self.variants[k]], C, nodal,
+                                        tab=tab and self.variants[k] != GENERAL,
+                                        weighted=dgraphs[0].weighted)
         return out
 
     def _frontend(self, graphs, node_kernel, edge_kernel, p, jobs, traits,
@@ -627,11 +673,13 @@ void ${name}(params_t prm) {
         """Host-only half of `prepare` (used by `precompile`): pack graphs,
         partition the jobs and render one translation unit per solver variant
         in use."""
-        dgraphs, edge_kernel, C = self._graphs_and_kernels(
-            graphs, edge_kernel, traits, timer)
-        jobs, used, order_all, launches = self._partition(dgraphs, jobs, C)
+        dgraphs, edge_kernel, C, fields = self._graphs_and_kernels(
+            graphs, node_kernel, edge_kernel, traits, timer)
+        tab_bytes = self._table_bytes(self._host_arena(dgraphs, fields))
+        jobs, used, order_all, launches = self._partition(dgraphs, jobs, C,
+                                                          tab_bytes)
         sources = self._sources(used, node_kernel, edge_kernel, p, dgraphs, C,
-                                traits.nodal is not False)
+                                traits.nodal is not False, tab_bytes > 0)
         return dgraphs, edge_kernel, jobs, C, used, order_all, launches, \
             sources
 
@@ -642,7 +690,8 @@ void ${name}(params_t prm) {
                                      jobs, traits)
         return jit.compile_many(list(sources.values()), self.hipcc_extra)
 
-    def _layout(self, dgraphs, jobs, starts, C, timer=None):
+    def _layout(self, dgraphs, jobs, starts, C, fields=(None, None),
+                timer=None):
         """Everything of a plan that depends only on WHICH pairs of WHICH
         graphs are evaluated: variant per job, launch order and geometry, and
         the device copies of the job list, the order and `starts`.  Cached
@@ -657,7 +706,7 @@ void ${name}(params_t prm) {
         jobs_id = ('id', id(jobs)) if not jobs.flags.writeable else \
             ('crc', zlib.crc32(jobs.view(np.uint8)))
         key = (tuple(map(id, dgraphs)), len(jobs), jobs_id,
-               zlib.crc32(starts.view(np.uint8)), C)
+               zlib.crc32(starts.view(np.uint8)), C, fields, self.tables)
         hit = self._layouts.get(key)
         if hit is not None:
             self._layouts.move_to_end(key)
@@ -668,9 +717,10 @@ void ${name}(params_t prm) {
         lay = Layout()
         lay.dgraphs = list(dgraphs)          # keeps the ids in `key` alive
         lay.jobs_host = jobs
-        lay.arena, lay.arena_buf, _ = self._arena(dgraphs)
+        lay.arena, lay.arena_buf, _ = self._arena(dgraphs, fields)
+        lay.tab_bytes = self._table_bytes(lay.arena)
         jobs, lay.used, lay.order_host, lay.launches = self._partition(
-            dgraphs, jobs, C)
+            dgraphs, jobs, C, lay.tab_bytes)
         lay.n_jobs = len(jobs)
         lay.b_jobs = runtime.DeviceBuffer(max(jobs.nbytes, 8))
         lay.b_order = runtime.DeviceBuffer(max(lay.order_host.nbytes, 4))
@@ -699,14 +749,15 @@ void ${name}(params_t prm) {
         tic = timer.tic if timer else (lambda *_: None)
         toc = timer.toc if timer else (lambda *_: None)
         runtime.ensure_device(self.device)
-        dgraphs, edge_kernel, C = self._graphs_and_kernels(
-            graphs, edge_kernel, traits, timer)
-        lay = self._layout(dgraphs, jobs, starts, C, timer)
+        dgraphs, edge_kernel, C, fields = self._graphs_and_kernels(
+            graphs, node_kernel, edge_kernel, traits, timer)
+        lay = self._layout(dgraphs, jobs, starts, C, fields, timer)
+        tab = lay.tab_bytes > 0
 
         tic('code generation')
         nodal = traits.nodal is not False
         sources = self._sources(lay.used, node_kernel, edge_kernel, p,
-                                dgraphs, C, nodal)
+                                dgraphs, C, nodal, tab)
         toc('code generation')
         tic('JIT')
         missing = [s for s in sources.values()
@@ -745,8 +796,9 @@ void ${name}(params_t prm) {
         for G in lay.launches:
             L = dict(G)
             L['module'] = modules[L['k']]
+            L['tab'] = tab and L['variant'] != GENERAL
             L['fn'] = fn = L['module'].function(
-                self.kernel_name(L['variant'], C, nodal))
+                self.kernel_name(L['variant'], C, nodal, L['tab']))
             if L['variant'] == GENERAL:
                 L['grid'] = int(min(L['count'],
                                     2 * self.props.compute_units))
@@ -783,6 +835,10 @@ void ${name}(params_t prm) {
         base['scratch'] = b_scratch.ptr if b_scratch is not None else 0
         base['nX'], base['nY'], base['nJ'] = plan.nX, plan.nY, plan.nJ
         base['flags'] = flags
+        if tab:
+            c = lay.arena.classes
+            base['n_vclass'], base['n_eclass'] = c['nv'], c['ne']
+            base['vrep'], base['erep'] = c['vrep'], c['erep']
         base['q'] = q
         base['q0'] = q
         base['eps'], base['ftol'], base['gtol'] = eps, ftol, gtol

@@ -25,6 +25,7 @@ many graphs are concatenated into one arena and uploaded with a single copy.
 """
 import itertools as it
 import numpy as np
+from numpy.lib.recfunctions import repack_fields
 from ...codegen.cpptool import cpptype
 from ...codegen.typetool import common_min_type, is_scalar_type
 
@@ -277,23 +278,133 @@ class DeviceGraph:
             'by GraphArena once the blob has a device address.')
 
 
+def class_bytes(n_node, n_nz):
+    """Bytes of the label-class section that precedes a graph's blob in the
+    arena: u8 node classes [pad4(n_node)] then u8 edge classes [pad4(n_nz)],
+    padded to the section alignment.  mgk_solver.h computes the same."""
+    n_node, n_nz = np.asarray(n_node), np.asarray(n_nz)
+    return ((n_node + 3) // 4 * 4 + (n_nz + 3) // 4 * 4 + _ALIGN - 1) \
+        // _ALIGN * _ALIGN
+
+
+def _label_classes(dgraphs, vfields=None, efields=None, max_classes=255):
+    """Number the distinct node records and the distinct edge *labels* (the
+    weight of a weighted edge is not part of its class) over all graphs,
+    looking only at the attributes `vfields` / `efields` (None: all) -- the
+    ones the microkernels read.  Returns None if some graph carries
+    variable-length attributes or there are too many classes; else
+    (per-graph node class ids, per-graph edge class ids, representatives
+    node_t[NV], representatives edge_t[NE])."""
+    if not dgraphs or any(len(g.relocs) for g in dgraphs):
+        return None
+    g0 = dgraphs[0]
+    node_t, edge_t = np.dtype(g0.node_t), np.dtype(g0.edge_t)
+
+    def number(records, fields):
+        dt = records.dtype
+        if fields is not None:
+            if not set(fields) <= set(dt.names or ()):
+                return None
+            keys = records[sorted(fields)] if fields else None
+            if keys is not None:
+                keys = repack_fields(keys)
+        else:
+            keys = records if dt.itemsize else None
+        if keys is None or len(records) == 0 or keys.dtype.itemsize == 0:
+            return np.zeros(len(records), np.int64), records[:1]
+        raw = np.ascontiguousarray(keys).view(np.uint8).reshape(
+            len(keys), keys.dtype.itemsize)
+        _, first, inv = np.unique(raw, axis=0, return_index=True,
+                                  return_inverse=True)
+        return inv.reshape(-1), records[first]
+
+    nodes = np.concatenate([
+        g.blob[g.offsets['node']:g.offsets['node']
+               + g.n_node * node_t.itemsize].view(node_t) for g in dgraphs])
+    edges = np.concatenate([
+        g.blob[g.offsets['edge']:g.offsets['edge']
+               + g.n_nz * edge_t.itemsize].view(edge_t)
+        if edge_t.itemsize else np.zeros(g.n_nz, edge_t) for g in dgraphs])
+    numbered = number(nodes, vfields)
+    if numbered is None:
+        return None
+    ncls, vrep = numbered
+    if g0.weighted:
+        label_t = edge_t.fields['label'][0]
+        numbered = number(np.ascontiguousarray(edges['label']), efields)
+        if numbered is None:
+            return None
+        ecls, lrep = numbered
+        erep = np.zeros(max(len(lrep), 1), dtype=edge_t)
+        erep['weight'] = 1
+        if label_t.itemsize and len(lrep):
+            erep['label'] = lrep
+    else:
+        numbered = number(edges, efields)
+        if numbered is None:
+            return None
+        ecls, erep = numbered
+        if len(erep) == 0:
+            erep = np.zeros(1, dtype=edge_t)
+    if len(vrep) == 0:
+        vrep = np.zeros(1, dtype=node_t)
+    if len(vrep) > max_classes or len(erep) > max_classes:
+        return None
+    n_node = np.array([g.n_node for g in dgraphs])
+    n_nz = np.array([g.n_nz for g in dgraphs])
+    ncls = np.split(ncls.astype(np.uint8), np.cumsum(n_node)[:-1])
+    ecls = np.split(ecls.astype(np.uint8), np.cumsum(n_nz)[:-1])
+    return ncls, ecls, vrep, erep
+
+
 class GraphArena:
     """Concatenation of DeviceGraph blobs + the graph_t header table, ready
-    for one host-to-device copy.  Layout: [headers][blob 0][blob 1]..."""
+    for one host-to-device copy.  Layout::
 
-    def __init__(self, dgraphs):
+        [headers][node class representatives][edge class representatives]
+        [classes of graph 0][blob 0][classes of graph 1][blob 1]...
+
+    The class section of a graph (`class_bytes`) sits directly in front of
+    its blob so that the solver stages [classes | degree .. perm] into LDS
+    with one contiguous copy.  `classes` is None when the labels cannot be
+    numbered (`_label_classes`); the sections are then zero."""
+
+    def __init__(self, dgraphs, vfields=None, efields=None):
         self.n = len(dgraphs)
         hdr_bytes = _pad(self.n * HEADER_DTYPE.itemsize)
+        cls = _label_classes(dgraphs, vfields, efields)
+        self.classes = None
+        cursor = hdr_bytes
+        if cls is not None:
+            ncls, ecls, vrep, erep = cls
+            self.classes = dict(nv=len(vrep), ne=len(erep), vrep=cursor,
+                                erep=cursor + _pad(vrep.nbytes))
+            cursor = self.classes['erep'] + _pad(erep.nbytes)
         sizes = np.array([len(g.blob) for g in dgraphs], dtype=np.int64)
-        starts = hdr_bytes + np.concatenate(([0], np.cumsum(sizes)[:-1])) \
+        cbytes = class_bytes(np.array([g.n_node for g in dgraphs], np.int64),
+                             np.array([g.n_nz for g in dgraphs], np.int64)) \
             if self.n else np.zeros(0, np.int64)
-        self.nbytes = int(hdr_bytes + sizes.sum())
+        ends = cursor + np.cumsum(sizes + cbytes)
+        starts = ends - sizes if self.n else np.zeros(0, np.int64)
+        self.nbytes = int(ends[-1]) if self.n else int(cursor)
         self.host = np.zeros(self.nbytes, dtype=np.uint8)
         self.blob_start = starts
+        self.class_bytes = cbytes
+        if cls is not None:
+            c = self.classes
+            self.host[c['vrep']:c['vrep'] + vrep.nbytes] = \
+                vrep.view(np.uint8).ravel() if vrep.nbytes else []
+            self.host[c['erep']:c['erep'] + erep.nbytes] = \
+                erep.view(np.uint8).ravel() if erep.nbytes else []
         self._relocs = []
         hdr = np.zeros(self.n, dtype=HEADER_DTYPE)
         for k, (g, s) in enumerate(zip(dgraphs, starts)):
             self.host[s:s + len(g.blob)] = g.blob
+            if cls is not None:
+                c0 = s - cbytes[k]
+                self.host[c0:c0 + g.n_node] = ncls[k]
+                c1 = c0 + (g.n_node + 3) // 4 * 4
+                self.host[c1:c1 + g.n_nz] = ecls[k]
             hdr['n_node'][k] = g.n_node
             hdr['n_nz'][k] = g.n_nz
             for name in SECTIONS:

@@ -4,6 +4,7 @@
 // extern "C" entry point per requested solver variant.  (Role of the
 // reference's graphdot/kernel/marginalized/template.cu.)
 #define GD_REAL ${real}
+#define GD_WEIGHTED ${weighted}
 #include <hip/hip_runtime.h>
 #include <numpy_type.h>
 #include <fmath.h>

@@ -13,9 +13,10 @@ from graphdot_amd.hip import runtime
 from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
 from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
 
+real = np.float64 if '--f64' in sys.argv else np.float32
 backend = HIPBackend(hipcc_extra=['-DGD_STAMPS'], record_iterations=True,
-                     concurrent=False)
-graphs = cases.config3_graphs(int(sys.argv[1]) if len(sys.argv) > 1 else 1000)
+                     concurrent=False, real=real)
+graphs = cases.config3_graphs(1000)
 knode, kedge, q = cases.config3_kernels()
 kernel = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
 n = len(graphs)
@@ -42,7 +43,7 @@ for L in plan.launches:
         out.ctypes.data, plan.buffers['iters'].ptr + off, 64, None))
     runtime.synchronize()
     tot = float(out[:3].sum())
-    print(backend.kernel_name(L['variant'], 1), 'pairs', int(out[3]),
+    print(backend.kernel_name(L['variant'], 1, False, L.get('tab', False)), 'pairs', int(out[3]),
           'cycles/pair', round(tot / max(int(out[3]), 1)),
           'setup %.1f%% loop %.1f%% epilogue %.1f%%' % tuple(
               100 * out[:3] / tot),

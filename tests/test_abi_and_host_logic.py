@@ -190,3 +190,39 @@ def test_pair_sharding_world_size_2_gloo(tmp_path):
         K = np.load(os.path.join(str(tmp_path), f'K{r}.npy'))
         assert np.allclose(K, ref, rtol=1e-9)
         assert np.count_nonzero(K - K.T) == 0
+
+
+def test_label_classes_are_numbered_over_the_attributes_the_kernels_read():
+    from graphdot_amd.kernel.marginalized._devicegraph import (
+        DeviceGraph, GraphArena, class_bytes)
+    G = cases.config3_graphs(40, seed=1)
+    dgs = [DeviceGraph(g, np.float32) for g in G]
+    full = GraphArena(dgs)
+    used = GraphArena(dgs, ('aromatic', 'atomic_number', 'hcount'),
+                      ('conjugated', 'order'))
+    assert used.classes['nv'] <= full.classes['nv']
+    assert GraphArena(dgs, (), ()).classes['nv'] == 1
+    assert GraphArena(dgs, ('no_such_attribute',), ()).classes is None
+    # class ids sit in front of every blob; equal ids <=> equal attributes
+    node_t = np.dtype(dgs[0].node_t)
+    seen = {}
+    for k, g in enumerate(dgs):
+        s = int(used.blob_start[k])
+        cb = int(class_bytes(g.n_node, g.n_nz))
+        assert cb % 16 == 0 and cb == used.class_bytes[k]
+        ids = used.host[s - cb:s - cb + g.n_node]
+        nodes = g.blob[g.offsets['node']:g.offsets['node']
+                       + g.n_node * node_t.itemsize].view(node_t)
+        for c, v in zip(ids, nodes):
+            key = (int(v['aromatic']), int(v['atomic_number']),
+                   int(v['hcount']))
+            assert seen.setdefault(int(c), key) == key
+    assert len(set(seen.values())) == len(seen) == used.classes['nv']
+    # headers still address the blobs
+    img = used.relocated(0)
+    hdr = img[:32 * len(dgs)].view(np.dtype([
+        ('n_node', np.int32), ('n_nz', np.int32), ('degree', np.uint32),
+        ('node', np.uint32), ('rowptr', np.uint32), ('nz', np.uint32),
+        ('edge', np.uint32), ('perm', np.uint32)]))
+    assert np.array_equal(hdr['degree'], used.blob_start
+                          + dgs[0].offsets['degree'])
