@@ -184,6 +184,9 @@ class HIPBackend(Backend):
         self.hipcc_extra = list(kwargs.pop('hipcc_extra', [])) + \
             os.environ.get('GD_HIPCC_EXTRA', '').split()
         self.variants = list(kwargs.pop('variants', VARIANTS + [GENERAL]))
+        if os.environ.get('GD_VARIANTS'):     # experiments: "W:S:R,W:S:R,..."
+            self.variants = [Variant(*map(int, item.split(':'))) for item in
+                             os.environ['GD_VARIANTS'].split(',')] + [GENERAL]
         self.record_iterations = kwargs.pop('record_iterations', False)
         self.occupancy = kwargs.pop('occupancy', None)
         self.concurrent = kwargs.pop('concurrent', True)
