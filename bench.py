@@ -25,6 +25,8 @@ import os
 import sys
 import time
 
+# the host driver only supports dmabuf IPC (RCCL / cross-process tensors)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, 'tests')):
     if p not in sys.path:
@@ -194,40 +196,39 @@ def main():
         K_dev = torch.zeros(n_cols * n * n, dtype=tdtype, device='cuda')
         torch.cuda.synchronize()
 
-    events = [runtime.Event() for _ in range(len(plan.launches) + 1)]
     kernel_ms = np.zeros(len(plan.launches))
-
+    nL = len(plan.launches)
     streams = [runtime.Stream() for _ in plan.launches] \
         if not args.serial else None
-    ev2 = [(runtime.Event(), runtime.Event()) for _ in plan.launches]
-    ev_gathered = runtime.Event()      # previous all-gather has read the slab
+    # one (start, stop) event pair per timed step and launch: durations are
+    # read after the timed region, so a step never waits on the host
+    ev_sets = [[(runtime.Event(), runtime.Event()) for _ in range(nL)]
+               for _ in range(args.steps + 1)]
+    ev_join = runtime.Event()    # previous step (and its all-gather) is done
 
-    def step(timed, first=False):
+    def step(index, first=False):
+        """One pass.  Everything is enqueued without host synchronisation;
+        device-side events order the passes: every solver stream waits for
+        the join of the previous pass, the join (null stream, which also
+        runs the collective and the reassembly) waits for every solver."""
+        ev = ev_sets[index]
         if streams is not None:
-            # one stream per solver variant; events bracket each kernel on
-            # the stream it runs on.  No host synchronisation inside a step:
-            # the solver streams wait (device-side) for the previous
-            # all-gather, the collective's stream waits for the solvers.
             for k, L in enumerate(plan.launches):
-                if world > 1 and not first:
-                    streams[k].wait_event(ev_gathered)
-                if timed:
-                    ev2[k][0].record(streams[k].h)
+                if not first:
+                    streams[k].wait_event(ev_join)
+                ev[k][0].record(streams[k].h)
                 runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
                                stream=streams[k].h,
                                dynamic_lds=L['dynamic_lds'])
-                ev2[k][1].record(streams[k].h)
-            if world > 1:
-                for k in range(len(plan.launches)):
-                    runtime.null_stream_wait_event(ev2[k][1])
+                ev[k][1].record(streams[k].h)
+            for k in range(nL):
+                runtime.null_stream_wait_event(ev[k][1])
         else:
-            if timed:
-                events[0].record()
             for k, L in enumerate(plan.launches):
+                ev[k][0].record()
                 runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
                                dynamic_lds=L['dynamic_lds'])
-                if timed:
-                    events[k + 1].record()
+                ev[k][1].record()
         if world > 1:
             if host_collective:
                 h = local_out.cpu()
@@ -237,7 +238,7 @@ def main():
             else:
                 dist.all_gather_into_tensor(gathered, local_out)
             K_dev.index_copy_(0, t_dst, gathered.index_select(0, t_src))
-            ev_gathered.record()
+        ev_join.record()
 
     def sync():
         runtime.synchronize()
@@ -249,24 +250,15 @@ def main():
             dist.barrier()
 
     for w in range(args.warmup):
-        step(False, first=(w == 0))
-    if args.warmup == 0 and world > 1:
-        ev_gathered.record()
+        step(args.steps, first=(w == 0))
+    if args.warmup == 0:
+        ev_join.record()
     sync()
     barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-        # per-kernel durations from the events of this step
-        if streams is not None:
-            for k in range(len(plan.launches)):
-                ev2[k][1].sync()
-                kernel_ms[k] += ev2[k][0].elapsed_ms(ev2[k][1])
-        else:
-            events[-1].sync()
-            for k in range(len(plan.launches)):
-                kernel_ms[k] += events[k].elapsed_ms(events[k + 1])
+    for it in range(args.steps):
+        step(it)
     sync()
     barrier()
     sync()
@@ -276,6 +268,10 @@ def main():
                          device='cpu' if host_collective else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # per-kernel durations: HIP events on the stream each kernel ran on
+    for it in range(args.steps):
+        for k in range(nL):
+            kernel_ms[k] += ev_sets[it][k][0].elapsed_ms(ev_sets[it][k][1])
     kernel_ms /= max(args.steps, 1)
 
     if rank != 0:
