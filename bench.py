@@ -344,6 +344,21 @@ def main():
         'algorithmic_flops_per_launch': aflops,
         'mean_cg_iterations': float(iters.mean()),
     }
+    # LDS traffic model of SURVEY 8(d): per CG iteration 2 reals per product-
+    # graph nonzero (gather + U) and 10 per row, against the aggregate LDS
+    # rate of the access width in use (MI355X_MICROARCH.md, LDS: ~75 TB/s
+    # for ds_read_b32, ~150 TB/s for ds_read_b64)
+    N_ = n_node[lji] * n_node[ljj]
+    nnzx_ = n_nz[lji] * n_nz[ljj]
+    lds_bytes = int((iters * (2 * nnzx_ + 10 * N_)).sum() * rsize
+                    * (2 if args.gradient else 1))
+    lds_peak = 75.0 if rsize == 4 else 150.0
+    lds = {'bound': 'lds', 'achieved': lds_bytes / dur / 1e12,
+           'peak': lds_peak, 'unit': 'TB/s',
+           'frac': lds_bytes / dur / 1e12 / lds_peak,
+           'algorithmic_lds_bytes_per_launch': lds_bytes,
+           'note': 'durations of concurrent launches overlap: the dominant '
+                   'kernel shares the chip with the other variants'}
     per_kernel = [
         {'kernel': backend.kernel_name(l['variant'], plan.C, False,
                                        l.get('tab', False)),
@@ -415,7 +430,8 @@ def main():
             'graphs': n, 'pairs': n_pairs,
             'parallelism': f'pair-sharded x{world}' if world > 1 else 'single',
         },
-        'roofline': roofline, 'compute': compute, 'kernels': per_kernel,
+        'roofline': roofline, 'compute': compute, 'lds': lds,
+        'kernels': per_kernel,
         'cpu_baseline': cpu, 'sharded_check': sharded_check,
         'other_arithmetic': other,
     }
