@@ -11,6 +11,7 @@ There is no CPU path: a missing ``libgdhip.so`` / hipcc / device raises.
 """
 import copy
 import os
+import re
 import uuid
 import zlib
 import warnings
@@ -256,10 +257,15 @@ class HIPBackend(Backend):
 
     @staticmethod
     def _used_fields(kernel):
-        """Attributes a microkernel reads: the keys of a composite
-        (TensorProduct / Additive), or None (= any) for everything else."""
-        kk = getattr(kernel, 'kw_kernels', None)
-        return tuple(sorted(kk)) if kk is not None else None
+        """Attributes a microkernel reads, taken from the code it generates:
+        ``x1.<name>`` / ``x2.<name>`` accesses.  () for a kernel that ignores
+        its arguments (Constant), None (= every attribute) if an argument is
+        used as a whole."""
+        fun, jac = kernel.gen_expr('x1', 'x2')
+        text = ' '.join([fun, *jac])
+        names = set(re.findall(r'\bx[12]\.([A-Za-z_]\w*)', text))
+        bare = re.search(r'\bx[12]\b(?!\.[A-Za-z_])', text)
+        return None if bare else tuple(sorted(names))
 
     def _table_bytes(self, arena):
         """LDS bytes of the microkernel tables of `arena`'s label classes, or

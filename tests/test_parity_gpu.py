@@ -707,3 +707,20 @@ def test_label_class_tables_on_the_molecular_set():
     K2 = MarginalizedGraphKernel(kn2, ke2, q=0.05, backend=on)(G2)
     assert not any(L['tab'] for L in on.last_plan.launches)
     assert np.allclose(K2, oracle.gram(G2, kn2, ke2, q=0.05), rtol=1e-5)
+
+
+def test_label_class_tables_with_multi_wave_variants():
+    """Larger weighted graphs (config 2a: discrete node labels, constant
+    edge kernel) reach the W = 4 / W = 16 solver variants; tables on and off
+    agree there too, in float and double."""
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    G = cases.config2_graphs(10, seed=5)
+    knode, kedge, q = cases.config2a_kernels()
+    for real, tol in ((np.float32, 5e-6), (np.float64, 1e-9)):
+        on = HIPBackend(tables=True, real=real)
+        off = HIPBackend(tables=False, real=real)
+        Ka = MarginalizedGraphKernel(knode, kedge, q=q, backend=on)(G)
+        Kb = MarginalizedGraphKernel(knode, kedge, q=q, backend=off)(G)
+        assert all(L['tab'] for L in on.last_plan.launches)
+        assert {L['variant'].W for L in on.last_plan.launches} & {4, 16}
+        assert np.allclose(Ka, Kb, rtol=tol)
