@@ -276,7 +276,10 @@ struct pair_solver {
     using edge_t = typename Graph::edge_t;
     constexpr static int T = 64 * W;   // threads per pair
     constexpr static int NV = R * T;   // capacity of p (rows)
-    constexpr static int WPB = (W == 1) ? 4 : 1;  // independent pairs per workgroup
+#ifndef GD_WPB
+#define GD_WPB 1
+#endif
+    constexpr static int WPB = (W == 1) ? GD_WPB : 1;  // independent pairs per workgroup
     constexpr static int threads = 64 * W * WPB;
     constexpr static int NM = (S + 31) / 32;      // 32-bit flush-mask words
     constexpr static int SETUP_CHUNK = 4;

@@ -48,6 +48,9 @@ VARIANTS = [
 GENERAL = Variant(0, 0, 0)
 GENERAL_THREADS = 1024
 LDS_LIMIT = 160 * 1024
+#: independent pairs (waves) per workgroup of the one-wave variants;
+#: mgk_solver.h reads the same number from GD_WPB
+WPB1 = int(os.environ.get('GD_WPB', 1))
 #: microkernel value tables (label classes) are used when they fit this much
 #: LDS per workgroup: (n_node_classes^2 + n_edge_classes^2) reals
 TABLE_LDS_LIMIT = 8 * 1024
@@ -191,12 +194,16 @@ class HIPBackend(Backend):
         self.record_iterations = kwargs.pop('record_iterations', False)
         self.occupancy = kwargs.pop('occupancy', None)
         self.concurrent = kwargs.pop('concurrent', True)
-        # microkernel value tables over label classes: a gain where the
-        # microkernels are expensive (fp64: software exp; -16 % VALU, +2..5 %),
-        # a loss in fp32 (-4 %: v_exp_f32 is one instruction) -- 'auto'
-        tables = kwargs.pop('tables', 'auto')
-        self.tables = (np.dtype(self.real) == np.float64) \
-            if tables == 'auto' else bool(tables)
+        # microkernel value tables over label classes (GraphArena.classes):
+        # opt-in.  They remove 16 % of the fp64 VALU instructions per pair,
+        # but the table is rebuilt per workgroup, and with one pair per
+        # workgroup (the fastest geometry) direct evaluation wins: fp64
+        # 79.1 M pairs/s without against 74.0 M with tables (77.6 M at two
+        # pairs per workgroup); fp32 loses 4 % in any geometry.
+        tables = kwargs.pop('tables', False)
+        if os.environ.get('GD_TABLES'):           # experiments
+            tables = os.environ['GD_TABLES'] == '1'
+        self.tables = bool(tables)
         self._streams = []
         if self.occupancy is None and os.environ.get('GD_OCCUPANCY'):
             # e.g. GD_OCCUPANCY="1:16:5,1:24:4"  (W:S:waves)
@@ -423,7 +430,7 @@ struct ${name}_t : ${name}_theta_t {
         occupancies with at most a handful of spilled registers, which were
         also the fastest or within 2 % of it in a per-variant sweep
         (scripts/occupancy_sweep.sh) and keep scratch traffic out of HBM."""
-        floor = -(-64 * v.W * (4 if v.W == 1 else 1) // 256)  # block must fit
+        floor = -(-64 * v.W * (WPB1 if v.W == 1 else 1) // 256)  # block must fit
         if self.occupancy is not None and (v.W, v.S) in self.occupancy:
             return max(self.occupancy[(v.W, v.S)], floor)
         if v.W == 1:
@@ -454,7 +461,7 @@ void ${name}(params_t prm) {
     solver::run(prm, lds, prm.scratch);
 }
 ''').render(threads=GENERAL_THREADS, name=self.kernel_name(v, C), C=C)
-        threads = 64 * v.W * (4 if v.W == 1 else 1)
+        threads = 64 * v.W * (WPB1 if v.W == 1 else 1)
         return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
 __attribute__((amdgpu_waves_per_eu(${waves})))
@@ -477,6 +484,7 @@ void ${name}(params_t prm) {
         return Template(_TEMPLATE).render(
             real=_real_name(self.real),
             weighted='1' if weighted else '0',
+            wpb=WPB1,
             node_t=declstruct(node_t, 'node_t'),
             edge_t=declstruct(edge_t, 'edge_t'),
             node_kernel=self.gencode_kernel(node_kernel, 'node_kernel',
@@ -503,7 +511,7 @@ void ${name}(params_t prm) {
     def lds_bytes(self, v, C, ntask=0, gbytes=0, tab_bytes=0):
         """LDS bytes of one workgroup: static p + scratch, dynamic U, the two
         staged graph images per pair slot and the microkernel tables."""
-        wpb = 4 if v.W == 1 else 1
+        wpb = WPB1 if v.W == 1 else 1
         T = 64 * v.W
         ucap = -(-np.asarray(ntask) // 64) * 64 + 64
         return ((v.R * T + ucap) * C * wpb + wpb * 2 * v.W) \
@@ -645,7 +653,7 @@ void ${name}(params_t prm) {
                     threads=GENERAL_THREADS, per_wg=per_wg))
                 cursor += len(idx)
                 continue
-            wpb = 4 if v.W == 1 else 1
+            wpb = WPB1 if v.W == 1 else 1
             threads = 64 * v.W * wpb
             # Many small workgroups (jobs_per_unit pairs per wave, default
             # one) rather than one persistent grid: the hardware dispatcher
