@@ -3,13 +3,11 @@ edges, composable with ``+ * **`` and the feature-wise combinators below.
 Same public names as ``graphdot.microkernel`` (reference
 ``graphdot/microkernel/__init__.py:7-37``)."""
 from ._base import MicroKernel, Constant, Normalize
-from .product import Product
-from .kronecker_delta import KroneckerDelta
+from .closed_form import Product, DotProduct, KroneckerDelta
 from .square_exponential import SquareExponential
 from .rational_quadratic import RationalQuadratic
 from .composite import Composite, TensorProduct, Additive
 from .convolution import Convolution
-from .dotproduct import DotProduct
 
 __all__ = [
     'MicroKernel', 'Product', 'Constant', 'KroneckerDelta',
