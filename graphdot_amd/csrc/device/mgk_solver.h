@@ -283,7 +283,10 @@ struct pair_solver {
     constexpr static int threads = 64 * W * WPB;
     constexpr static int NM = (S + 31) / 32;      // 32-bit flush-mask words
     constexpr static int SETUP_CHUNK = 4;
-    constexpr static int GCH = 8;                 // stage-1 gathers in flight
+#ifndef GD_GCH
+#define GD_GCH 8
+#endif
+    constexpr static int GCH = GD_GCH;            // stage-1 gathers in flight
     constexpr static int ZPAD = 64;               // zero entries at the end of U
     constexpr static int DU = 4;                  // stage-2 degree bound of the unrolled path
 #ifndef GD_RCH

@@ -724,3 +724,31 @@ def test_label_class_tables_with_multi_wave_variants():
         assert all(L['tab'] for L in on.last_plan.launches)
         assert {L['variant'].W for L in on.last_plan.launches} & {4, 16}
         assert np.allclose(Ka, Kb, rtol=tol)
+
+
+@pytest.mark.parametrize('real', [np.float32, np.float64])
+def test_full_size_gram_matrix_properties(real):
+    """BASELINE.json's full configuration (1000 QM7-like graphs, 500 500
+    pairs), checked through size-independent properties: exact symmetry, the
+    diagonal equals `diag()`, Cauchy-Schwarz on the normalised matrix,
+    positive semi-definiteness, and a random sample against the oracle."""
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    G = cases.config3_graphs(1000)
+    knode, kedge, q = cases.config3_kernels()
+    k = MarginalizedGraphKernel(knode, kedge, q=q,
+                                backend=HIPBackend(real=real))
+    K = k(G)
+    assert K.shape == (1000, 1000) and np.all(np.isfinite(K))
+    assert np.array_equal(K, K.T)
+    d = k.diag(G)
+    assert np.allclose(np.diag(K), d, rtol=1e-6 if real is np.float32 else 1e-12)
+    Kn = K / np.sqrt(np.outer(d, d))
+    assert Kn.max() <= 1 + (2e-6 if real is np.float32 else 1e-9)
+    w = np.linalg.eigvalsh(Kn.astype(np.float64))
+    assert w.min() > -(1e-4 if real is np.float32 else 1e-7) * w.max()
+    rng = np.random.default_rng(9)
+    ii, jj = rng.integers(0, 1000, 300), rng.integers(0, 1000, 300)
+    batch = oracle.TensorProductBatch(G, knode, kedge)
+    ref, _ = batch.run(ii, jj, q=q, real='f64', tol=1e-13)
+    assert np.allclose(K[ii, jj], ref,
+                       rtol=1e-5 if real is np.float32 else 1e-7)
