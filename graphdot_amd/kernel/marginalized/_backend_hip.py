@@ -421,6 +421,7 @@ struct ${name}_t : ${name}_theta_t {
     #: the fastest of a per-variant sweep (scripts/occupancy_sweep2.sh)
     _WAVES_F32_GRADIENT = {8: 5, 12: 4, 16: 3, 20: 2, 24: 2, 28: 2, 32: 1}
     _WAVES_F64_VALUE = {8: 5, 12: 4, 16: 3, 20: 3, 24: 2, 28: 2, 32: 2}
+    _WAVES_F64_GRADIENT = {8: 3, 12: 3, 16: 2, 20: 2, 24: 1, 28: 1, 32: 1}
 
     def waves_per_eu(self, v, C):
         """Occupancy target handed to the register allocator
@@ -437,7 +438,8 @@ struct ${name}_t : ${name}_theta_t {
             f64 = np.dtype(self.real) == np.float64
             table = {(1, False): self._WAVES_F32_VALUE,
                      (2, False): self._WAVES_F32_GRADIENT,
-                     (1, True): self._WAVES_F64_VALUE}.get((C, f64), {})
+                     (1, True): self._WAVES_F64_VALUE,
+                     (2, True): self._WAVES_F64_GRADIENT}.get((C, f64), {})
             if v.S in table:
                 return max(table[v.S], floor)
         need = 5.3 * v.S + 4 * v.R + 6
