@@ -191,6 +191,35 @@ class DeviceBuffer:
         self.free()
 
 
+class DeviceArray:
+    """A strided view of device memory that other libraries can adopt
+    without a copy (``__cuda_array_interface__`` version 2; on ROCm builds of
+    PyTorch ``torch.as_tensor(view, device='cuda')`` takes it).  `owner`
+    keeps the allocation alive as long as the view object lives; the *content*
+    is only valid until whoever owns the buffer writes it again."""
+
+    def __init__(self, ptr, shape, dtype, strides=None, owner=None):
+        import numpy as np
+        dtype = np.dtype(dtype)
+        self.ptr, self.shape, self.dtype, self.owner = ptr, tuple(shape), \
+            dtype, owner
+        self.strides = tuple(strides) if strides is not None else None
+        self.__cuda_array_interface__ = dict(
+            shape=self.shape, strides=self.strides, typestr=dtype.str,
+            data=(int(ptr), False), version=2)
+
+    @classmethod
+    def fortran(cls, ptr, shape, dtype, owner=None):
+        """Column-major view (the layout of the solver's outputs)."""
+        import numpy as np
+        item = np.dtype(dtype).itemsize
+        strides, step = [], item
+        for n in shape:
+            strides.append(step)
+            step *= int(n)
+        return cls(ptr, shape, dtype, strides, owner)
+
+
 class Event:
     def __init__(self):
         p = ctypes.c_void_p()

@@ -237,6 +237,44 @@ class MarginalizedGraphKernel:
                     gradient.astype(self.element_dtype, copy=False))
         return gramian.astype(self.element_dtype, copy=False)
 
+    def device_gram(self, X, eval_gradient=False, lmin=0):
+        """The symmetric Gram matrix of `X` (and its gradient) left in device
+        memory: the HIP backend's output buffers as zero-copy views
+        (`graphdot_amd.hip.runtime.DeviceArray`; ``torch.as_tensor(view,
+        device='cuda')`` adopts them), in the backend's arithmetic, column-
+        major like the reference's outputs.  The gradient has all `n_dims`
+        columns; `active_theta_mask` is the caller's to apply.  The views are
+        valid until the next evaluation on this backend.  For consumers that
+        continue on the GPU (model.gaussian_process): saves the download, the
+        float64 conversion on the host and the upload of ``n^2 (1 + n_dims)``
+        numbers per call."""
+        from ...hip.runtime import DeviceArray
+        backend = self.backend
+        if not hasattr(backend, 'prepare'):
+            raise TypeError('device_gram needs the HIP backend')
+        pred = Graph.has_unified_types(X)
+        if pred is not True:
+            raise _type_error(
+                pred, 'If the attributes match in name but differ in type, '
+                'try `Graph.unify_datatype` as an automatic fix.')
+        nx = len(X)
+        traits = self.traits(symmetric=True, lmin=lmin,
+                             eval_gradient=eval_gradient)
+        plan = backend.prepare(
+            X, self.node_kernel, self.edge_kernel, self.p, self.q, self.eps,
+            self.ftol, self.gtol, self._pairwise_jobs(nx),
+            np.arange(nx + 1, dtype=np.uint32), nx, nx, self.n_dims, traits)
+        backend.launch(plan)
+        backend.synchronize()
+        real = np.dtype(backend.real)
+        K = DeviceArray.fortran(plan.buffers['gramian'].ptr, (nx, nx), real,
+                                owner=plan)
+        if not eval_gradient:
+            return K
+        dK = DeviceArray.fortran(plan.buffers['gradient'].ptr,
+                                 (nx, nx, self.n_dims), real, owner=plan)
+        return K, dK
+
     # ------------------------------------------------------------------ diag
     def diag(self, X, eval_gradient=False, nodal=False, lmin=0,
              active_theta_only=True, timing=False):

@@ -292,19 +292,51 @@ class GaussianProcessRegressor:
             kernel = self.kernel
             kernel.theta = theta
         t = time.perf_counter()
-        if eval_gradient is True:
-            K, dK = self._gramian(self.alpha, X, kernel=kernel, jac=True)
-        else:
-            K, dK = self._gramian(self.alpha, X, kernel=kernel), None
-        t_kernel = time.perf_counter() - t
         la = self._dense()
+        on_device = self._device_gramian(la, kernel, X, eval_gradient)
+        if on_device is not None:
+            Kt, dKt = on_device
+        elif eval_gradient is True:
+            K, dK = self._gramian(self.alpha, X, kernel=kernel, jac=True)
+            Kt, dKt = la.tensor(K), la.tensor(dK)
+        else:
+            Kt, dKt = la.tensor(self._gramian(self.alpha, X, kernel=kernel)), \
+                None
+        t_kernel = time.perf_counter() - t
         if not y_mask.all():
-            K = K[y_mask, :][:, y_mask]
-            if dK is not None:
-                dK = dK[y_mask, :, :][:, y_mask, :]
-        Kt = la.tensor(K)
-        dKt = la.tensor(dK) if dK is not None else None
+            keep = _torch().as_tensor(np.flatnonzero(y_mask),
+                                      device=la.device)
+            Kt = Kt.index_select(0, keep).index_select(1, keep)
+            if dKt is not None:
+                dKt = dKt.index_select(0, keep).index_select(1, keep)
         return theta, la, Kt, dKt, la.tensor(y), t_kernel
+
+    def _device_gramian(self, la, kernel, X, jac):
+        """Regularised float64 kernel matrix (and gradient over the active
+        hyperparameters) as device tensors, straight from the kernel's device
+        buffers -- if the kernel offers them (`device_gram` of the HIP
+        marginalized graph kernel), the algebra runs on that GPU and no
+        kernel options are in the way; None otherwise."""
+        if la.device.type != 'cuda' or self.kernel_options \
+                or not hasattr(kernel, 'device_gram'):
+            return None
+        torch = _torch()
+        try:
+            out = kernel.device_gram(X, eval_gradient=jac)
+        except TypeError:            # not the HIP backend
+            return None
+        Kd, dKd = out if jac else (out, None)
+        K = torch.as_tensor(Kd, device=la.device).to(torch.float64)
+        diag = torch.diagonal(K)
+        diag.copy_(self._regularize(diag, self.alpha))
+        dK = None
+        if dKd is not None:
+            cols = torch.as_tensor(
+                np.flatnonzero(np.asarray(kernel.active_theta_mask)),
+                device=la.device)
+            dK = torch.as_tensor(dKd, device=la.device).index_select(
+                2, cols).to(torch.float64)
+        return K, dK
 
     def log_marginal_likelihood(self, theta=None, X=None, y=None,
                                 eval_gradient=False, clone_kernel=True,

@@ -183,6 +183,21 @@ def test_gpr_on_the_marginalized_graph_kernel():
               - gpr.log_marginal_likelihood(tm)) / 2e-2
         assert abs(grad[k] - fd) <= 0.05 * abs(fd) \
             + 0.02 * np.abs(grad).max() + 1e-3
+    # the zero-copy device path (kernel.device_gram) and the numpy path of
+    # the kernel protocol give the same objective and gradient
+    host = GaussianProcessRegressor(kernel, alpha=gpr.alpha, normalize_y=True,
+                                    kernel_options={'lmin': 0})
+    host.X, host.y = G, y
+    assert host._device_gramian(host._dense(), kernel, G, True) is None
+    assert gpr._device_gramian(gpr._dense(), kernel, G, True) is not None
+    val_h, grad_h = host.log_marginal_likelihood(theta, eval_gradient=True)
+    assert val_h == pytest.approx(val, rel=1e-6)
+    assert np.allclose(grad_h, grad, rtol=1e-4, atol=1e-6 * np.abs(grad).max())
+    y_masked = list(y)
+    y_masked[3] = None
+    a = gpr.log_marginal_likelihood(theta, y=y_masked)
+    b = host.log_marginal_likelihood(theta, y=y_masked)
+    assert a == pytest.approx(b, rel=1e-6)
     gpr.fit(G, y)
     mean, std = gpr.predict(G[:5], return_std=True)
     assert mean.shape == (5,) and np.all(std >= 0)
