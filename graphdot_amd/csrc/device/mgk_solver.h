@@ -182,6 +182,33 @@ template<class T> __device__ __forceinline__ unsigned lds_offset(T *p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) T *)p;
 }
 
+// The C interleaved components of element `i` (C = 2: one 8- or 16-byte
+// vector access instead of two scalar ones -- `ds_read2_b32` of an element
+// pair banks like two ds_read_b32 whose addresses are all even: a guaranteed
+// 2-way conflict; `ds_read_b64` uses the 64-bank mapping).  `base` must be
+// aligned to C reals.
+template<int C, class real> __device__ __forceinline__ void load_elem(real const *base, unsigned i, real (&out)[C]) {
+    if constexpr (C == 2) {
+        typedef real vec2 __attribute__((ext_vector_type(2)));
+        const vec2 v = reinterpret_cast<vec2 const *>(base)[i];
+        out[0] = v.x;
+        out[1] = v.y;
+    } else {
+        out[0] = base[i];
+    }
+}
+template<int C, class real> __device__ __forceinline__ void store_elem(real *base, unsigned i, real const (&in)[C]) {
+    if constexpr (C == 2) {
+        typedef real vec2 __attribute__((ext_vector_type(2)));
+        vec2 v;
+        v.x = in[0];
+        v.y = in[1];
+        reinterpret_cast<vec2 *>(base)[i] = v;
+    } else {
+        base[i] = in[0];
+    }
+}
+
 // base[lane] = v for the 64 lanes of a wave, `base` wave-uniform: the store
 // takes its address from M0 + 4 lane (ds_write_addtid_b32), i.e. no address
 // VGPR and half the LDS cycles of ds_write_b32 (MI355X_MICROARCH.md, LDS).
@@ -304,7 +331,7 @@ struct pair_solver {
     // task, at most u_capacity per pair) lives in the dynamic LDS region,
     // sized per launch from the largest pair in it.
     struct lds_t {
-        real p[WPB][NV * C];
+        alignas(16) real p[WPB][NV * C];
         real red[WPB][2 * W];
     };
 
@@ -327,9 +354,12 @@ struct pair_solver {
             }
         } else {
 #pragma unroll
-            for (int kk = 0; kk < R; ++kk)
+            for (int kk = 0; kk < R; ++kk) {
+                real e[C];
 #pragma unroll
-                for (int c = 0; c < C; ++c) lp[(kk * T + tid) * C + c] = p[c][kk];
+                for (int c = 0; c < C; ++c) e[c] = p[c][kk];
+                store_elem<C>(lp, kk * T + tid, e);
+            }
         }
     }
 
@@ -634,10 +664,14 @@ struct pair_solver {
                         if (s0 >= n_slots) break;   // wave-uniform: no slots left
                         real g[C][GCH];
 #pragma unroll
-                        for (int j = 0; j < GCH; ++j)
+                        for (int j = 0; j < GCH; ++j) {
+                            real e[C];
 #pragma unroll
-                            for (int c = 0; c < C; ++c)
-                                g[c][j] = (s0 + j < S) ? lp[gather_index(s0 + j) * C + c] : real(0);
+                            for (int c = 0; c < C; ++c) e[c] = 0;
+                            if (s0 + j < S) load_elem<C>(lp, gather_index(s0 + j), e);
+#pragma unroll
+                            for (int c = 0; c < C; ++c) g[c][j] = e[c];
+                        }
 #pragma unroll
                         for (int j = 0; j < GCH; ++j) {
                             const int s = s0 + j;
@@ -649,11 +683,9 @@ struct pair_solver {
                                         store_lane_contiguous<0>(lU_off + kb * (T * 4), (float)acc[0]);
                                         acc[0] = 0;
                                     } else {
+                                        store_elem<C>(lU, kb * T + tid, acc);
 #pragma unroll
-                                        for (int c = 0; c < C; ++c) {
-                                            lU[(kb * T + tid) * C + c] = acc[c];
-                                            acc[c] = 0;
-                                        }
+                                        for (int c = 0; c < C; ++c) acc[c] = 0;
                                     }
                                     ++kb;
                                 }
@@ -692,9 +724,12 @@ struct pair_solver {
                             for (int k = kc; k < kc + RCH && k < R; ++k) {
                                 real const *const u0 = lU + ubase[k] * C;
 #pragma unroll
-                                for (int j = 0; j < DU; ++j)
+                                for (int j = 0; j < DU; ++j) {
+                                    real e[C];
+                                    load_elem<C>(u0, j, e);
 #pragma unroll
-                                    for (int c = 0; c < C; ++c) u[k - kc][c][j] = u0[j * C + c];
+                                    for (int c = 0; c < C; ++c) u[k - kc][c][j] = e[c];
+                                }
                             }
 #pragma unroll
                             for (int k = kc; k < kc + RCH && k < R; ++k) {
@@ -826,8 +861,8 @@ struct pair_solver {
                 job_sync<W>();
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    lp[(k * T + tid) * 2 + 0] = x[0][k];
-                    lp[(k * T + tid) * 2 + 1] = x[1][k];
+                    const real e[2] = {x[0][k], x[1][k]};
+                    store_elem<2>(lp, k * T + tid, e);
                 }
                 real jac[n_jac];
 #pragma unroll
