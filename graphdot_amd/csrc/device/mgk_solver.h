@@ -599,8 +599,11 @@ struct pair_solver {
                     dg[k] = ok ? dx / vx : real(0);
                     mi[k] = ok ? vx / dx : real(0);
                     const int rs = lrp1[i1];
-                    ubase[k] = ok ? (int)__umul24((unsigned)i2, (unsigned)ldu) + rs : zbase;
                     udeg[k] = ok ? lrp1[i1 + 1] - rs : 0;
+                    // rows without neighbours (isolated nodes, dead lanes, pad
+                    // rows) point at the zero pad: whatever stage 2 reads for
+                    // them unmasked is zero
+                    ubase[k] = udeg[k] > 0 ? (int)__umul24((unsigned)i2, (unsigned)ldu) + rs : zbase;
                     // rows of one wave are consecutive: the first has the largest
                     // degree, the last the smallest (0 if the batch has dead rows)
                     const int f1 = uni(first.hi);

@@ -752,3 +752,34 @@ def test_full_size_gram_matrix_properties(real):
     ref, _ = batch.run(ii, jj, q=q, real='f64', tol=1e-13)
     assert np.allclose(K[ii, jj], ref,
                        rtol=1e-5 if real is np.float32 else 1e-7)
+
+
+@pytest.mark.parametrize('real', [np.float32, np.float64])
+def test_graphs_with_many_isolated_nodes(real):
+    """Isolated nodes are legal (degree 0 -> 1.0, reference
+    _octilegraph.py:139).  With enough of them whole 64-row batches of the
+    product system have no off-diagonal entries at all: stage 2 must then
+    contribute exactly zero, not a neighbouring row's entry."""
+    import networkx as nx
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    graphs = []
+    for n_path, n_iso, seed in ((5, 12, 0), (3, 20, 1), (8, 9, 2), (6, 0, 3)):
+        g = nx.path_graph(n_path)
+        g.add_nodes_from(range(n_path, n_path + n_iso))
+        rng = np.random.default_rng(seed)
+        for v in g.nodes:
+            g.nodes[v]['category'] = int(rng.integers(1, 4))
+        for e in g.edges:
+            g.edges[e]['order'] = float(rng.integers(1, 3))
+        graphs.append(Graph.from_networkx(g))
+    knode = TensorProduct(category=KroneckerDelta(0.5))
+    kedge = TensorProduct(order=SquareExponential(1.0))
+    k = MarginalizedGraphKernel(knode, kedge, q=0.1,
+                                backend=HIPBackend(real=real))
+    K = k(graphs)
+    ref = oracle.gram(graphs, knode, kedge, q=0.1)
+    assert np.allclose(K, ref, rtol=1e-5 if real is np.float32 else 1e-7)
+    Kn = k(graphs, nodal=True)      # (single entries: CG tolerance 1e-8 N)
+    assert np.allclose(Kn, oracle.gram(graphs, knode, kedge, q=0.1,
+                                       nodal=True),
+                       rtol=1e-5 if real is np.float32 else 1e-6)
