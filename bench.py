@@ -180,19 +180,9 @@ def main():
     # that a step ends with the same product at any N
     t_src = t_dst = K_dev = None
     if world > 1:
-        cap = shard.capacity
-        dst, slot, mdst, mslot = shard.scatter_index(
-            starts.astype(np.int64), starts.astype(np.int64))
-        all_dst = np.concatenate((dst, mdst))
-        all_slot = np.concatenate((slot, mslot))
-        r_, pos = all_slot // cap, all_slot % cap
-        srcs = [r_ * cap * n_cols + pos]
-        dsts = [all_dst]
-        for c in range(n_cols - 1):
-            srcs.append(r_ * cap * n_cols + cap + pos * (n_cols - 1) + c)
-            dsts.append((c + 1) * n * n + all_dst)
-        t_src = torch.from_numpy(np.concatenate(srcs)).cuda()
-        t_dst = torch.from_numpy(np.concatenate(dsts)).cuda()
+        src_idx, dst_idx = shard.reassembly_index(n_cols - 1)
+        t_src = torch.from_numpy(src_idx).cuda()
+        t_dst = torch.from_numpy(dst_idx).cuda()
         K_dev = torch.zeros(n_cols * n * n, dtype=tdtype, device='cuda')
         torch.cuda.synchronize()
 

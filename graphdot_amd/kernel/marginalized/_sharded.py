@@ -62,6 +62,35 @@ class ShardPlan:
             return dst, self.slot, mdst, self.slot[off]
         return dst, self.slot, None, None
 
+    def reassembly_index(self, n_grad=0):
+        """(src, dst) flat indices that turn the all-gathered slabs into the
+        column-major result on the device with one gather + one scatter
+        (``out[dst] = gathered[src]``).  Every rank's slab is laid out as
+        ``[capacity values | capacity * n_grad gradient entries, job-major]``
+        (what the packed solver writes: mgk_solver.h, F_PACKED); the result is
+        ``[nX * nY values | n_grad planes of nX * nY]`` with the mirrored
+        entries of a symmetric matrix filled in."""
+        n_cols = 1 + n_grad
+        sx = np.arange(self.nX + 1, dtype=np.int64)
+        jy = self.jj if self.symmetric else self.jj - self.nX
+        saved, self.jj = self.jj, jy
+        try:
+            dst, slot, mdst, mslot = self.scatter_index(sx, sx if self.symmetric
+                                                        else np.arange(self.nY + 1))
+        finally:
+            self.jj = saved
+        if mdst is not None:
+            dst = np.concatenate((dst, mdst))
+            slot = np.concatenate((slot, mslot))
+        cap = self.capacity
+        rank, pos = slot // cap, slot % cap
+        base = rank * cap * n_cols
+        srcs, dsts = [base + pos], [dst]
+        for c in range(n_grad):
+            srcs.append(base + cap + pos * n_grad + c)
+            dsts.append((c + 1) * self.nX * self.nY + dst)
+        return np.concatenate(srcs), np.concatenate(dsts)
+
     def assemble(self, gathered, n_cols=1):
         """Host reassembly of the gathered slabs into the (nX, nY[, n_cols])
         matrix (graph-level outputs: starts are 0..n)."""
