@@ -14,7 +14,6 @@ import os
 import re
 import uuid
 import zlib
-import warnings
 from collections import OrderedDict, namedtuple
 import numpy as np
 from ...codegen import Template
