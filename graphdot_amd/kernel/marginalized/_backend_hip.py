@@ -162,9 +162,21 @@ class HIPBackend(Backend):
     real: numpy float32 (reference arithmetic, default) or float64
     jobs_per_unit: int
         Graph pairs handled by one wave (small pairs) or workgroup (large
-        pairs) before it retires; sets the launch grid.
+        pairs) before it retires; sets the launch grid.  Default 1.
     hipcc_extra: list of str
-        Extra compiler flags.
+        Extra compiler flags (also ``$GD_HIPCC_EXTRA``).
+    variants: list of Variant
+        Solver menu ``(W, S, R)`` in order of preference; ``GENERAL`` (the
+        global-scratch solver for pairs of any size) last.
+    record_iterations: bool
+        Keep per-job CG iteration counts on the device (`iterations(plan)`).
+    occupancy: dict (W, S) -> waves per SIMD, or None
+        Overrides the measured occupancy targets (also ``$GD_OCCUPANCY``).
+    concurrent: bool
+        One HIP stream per solver variant (default) or all on one stream.
+    tables: bool
+        Evaluate the microkernels once per pair of label classes into LDS
+        tables instead of per nonzero pair (off by default; see __init__).
     """
 
     @staticmethod
