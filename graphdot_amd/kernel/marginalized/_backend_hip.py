@@ -229,6 +229,7 @@ class HIPBackend(Backend):
         self._arenas = OrderedDict()       # tuple(id(DeviceGraph)) -> (arena, buf)
         self._pool = {}                    # name -> DeviceBuffer (grow-only)
         self._layouts = OrderedDict()      # job-list key -> Layout (LRU)
+        self._source_cache = {}            # (code signature, variant) -> text
         self.layout_cache_size = 8
         self._props = None
         self.last_plan = None
@@ -689,13 +690,22 @@ void ${name}(params_t prm) {
                  tab=False):
         """One translation unit per solver variant in use.  The node / edge /
         start-probability code is shared text; only the entry point differs."""
+        # rendering is pure text work on hyperparameter-independent inputs:
+        # memoised on the generated expressions and the record types
+        sig = (node_kernel.gen_expr('x1', 'x2')[0], str(node_kernel.dtype),
+               edge_kernel.gen_expr('x1', 'x2')[0], str(edge_kernel.dtype),
+               p.gen_expr()[0], str(np.dtype(p.dtype)), dgraphs[0].signature,
+               C, nodal, tab)
         out = {}
         for k in used:
-            out[k] = self.render_source(node_kernel, edge_kernel, p,
-                                        dgraphs[0].node_t, dgraphs[0].edge_t,
-                                        [self.variants[k]], C, nodal,
-                                        tab=tab and self.variants[k] != GENERAL,
-                                        weighted=dgraphs[0].weighted)
+            key = (sig, k)
+            if key not in self._source_cache:
+                self._source_cache[key] = self.render_source(
+                    node_kernel, edge_kernel, p, dgraphs[0].node_t,
+                    dgraphs[0].edge_t, [self.variants[k]], C, nodal,
+                    tab=tab and self.variants[k] != GENERAL,
+                    weighted=dgraphs[0].weighted)
+            out[k] = self._source_cache[key]
         return out
 
     def _frontend(self, graphs, node_kernel, edge_kernel, p, jobs, traits,
