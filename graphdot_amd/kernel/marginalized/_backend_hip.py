@@ -195,7 +195,8 @@ class HIPBackend(Backend):
         self.uuid = uuid.uuid4()
         self.device = kwargs.pop('device', None)
         self.real = np.dtype(kwargs.pop('real', np.float32)).type
-        self.jobs_per_unit = kwargs.pop('jobs_per_unit', 1)
+        self.jobs_per_unit = int(kwargs.pop(
+            'jobs_per_unit', os.environ.get('GD_JOBS_PER_UNIT', 1)))
         self.hipcc_extra = list(kwargs.pop('hipcc_extra', [])) + \
             os.environ.get('GD_HIPCC_EXTRA', '').split()
         self.variants = list(kwargs.pop('variants', VARIANTS + [GENERAL]))
