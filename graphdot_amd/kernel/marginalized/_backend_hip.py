@@ -298,10 +298,11 @@ class HIPBackend(Backend):
         return int(-(-b // 16) * 16) if b <= TABLE_LDS_LIMIT else 0
 
     def _host_arena(self, dgraphs, fields):
-        return GraphArena(dgraphs, *fields)
+        # (label classes are only numbered when the tables are in use)
+        return GraphArena(dgraphs, *fields, classes=self.tables)
 
     def _arena(self, dgraphs, fields=(None, None)):
-        key = (tuple(id(g) for g in dgraphs), fields)
+        key = (tuple(id(g) for g in dgraphs), fields if self.tables else None)
         hit = self._arenas.get(key)
         if hit is not None:
             self._arenas.move_to_end(key)

@@ -369,10 +369,10 @@ class GraphArena:
     with one contiguous copy.  `classes` is None when the labels cannot be
     numbered (`_label_classes`); the sections are then zero."""
 
-    def __init__(self, dgraphs, vfields=None, efields=None):
+    def __init__(self, dgraphs, vfields=None, efields=None, classes=True):
         self.n = len(dgraphs)
         hdr_bytes = _pad(self.n * HEADER_DTYPE.itemsize)
-        cls = _label_classes(dgraphs, vfields, efields)
+        cls = _label_classes(dgraphs, vfields, efields) if classes else None
         self.classes = None
         cursor = hdr_bytes
         if cls is not None:
