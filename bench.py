@@ -392,6 +392,16 @@ def main():
                 'sample': f'{size_all} pairs, OpenMP dynamic schedule'}
         except Exception as e:                      # no libgomp etc.
             cpu['all_cores'] = {'error': str(e)}
+        # the reference's own Python CPU path cannot travel to this host; its
+        # rate was recorded in the build container (provenance in the file)
+        try:
+            with open(os.path.join(ROOT, 'profiles',
+                                   'r01_reference_python_cpu.json')) as f:
+                rp = json.load(f)
+            cpu['reference_python'] = {
+                k: rp[k] for k in ('value', 'unit', 'cores', 'what', 'where')}
+        except (OSError, KeyError, ValueError):
+            pass
         # the sample doubles as an on-line parity check of the timed result
         got, _ = backend.collect(plan)
         K = got.reshape(n, n, order='F')
