@@ -964,7 +964,7 @@ struct pair_solver {
 #ifdef GD_STAMPS
         if (tid == 0 && prm.iters != nullptr) {
             unsigned long long *acc = reinterpret_cast<unsigned long long *>(
-                prm.iters + ((prm.nJ + 1) & ~1u));   // host passes nJ := n_jobs
+                prm.iters + ((prm.nX * prm.nY + 1) & ~1u));   // behind the per-job counters
             for (int k = 0; k < 7; ++k) atomicAdd(acc + k, st_acc[k]);
         }
 #endif

@@ -23,13 +23,15 @@ n = len(graphs)
 i, j = np.triu_indices(n)
 job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
 jobs = np.column_stack((i, j)).astype(np.uint32).ravel().view(job_t)
-# iters buffer: n_jobs counters + 4 x u64 accumulators; nJ carries n_jobs
-backend._buffer('iters', 4 * (len(jobs) + 2) + 128)
+# iters buffer: per-job counters, then (behind nX * nY entries) the u64
+# phase accumulators
+backend._buffer('iters', 4 * (n * n + 2) + 128)
 plan = backend.prepare(graphs, knode, kedge, kernel.p, kernel.q, kernel.eps,
                        kernel.ftol, kernel.gtol, jobs,
-                       np.arange(n + 1, dtype=np.uint32), n, n, len(jobs),
-                       kernel.traits(symmetric=True))
-off = 4 * ((len(jobs) + 1) & ~1)
+                       np.arange(n + 1, dtype=np.uint32), n, n, kernel.n_dims,
+                       kernel.traits(symmetric=True,
+                                     eval_gradient='--gradient' in sys.argv))
+off = 4 * ((n * n + 1) & ~1)
 acc = np.zeros(8, dtype=np.uint64)
 for L in plan.launches:
     plan.buffers['iters'].upload(acc * 0, offset=off)
@@ -43,7 +45,7 @@ for L in plan.launches:
         out.ctypes.data, plan.buffers['iters'].ptr + off, 64, None))
     runtime.synchronize()
     tot = float(out[:3].sum())
-    print(backend.kernel_name(L['variant'], 1, False, L.get('tab', False)), 'pairs', int(out[3]),
+    print(backend.kernel_name(L['variant'], plan.C, False, L.get('tab', False)), 'pairs', int(out[3]),
           'cycles/pair', round(tot / max(int(out[3]), 1)),
           'setup %.1f%% loop %.1f%% epilogue %.1f%%' % tuple(
               100 * out[:3] / tot),
