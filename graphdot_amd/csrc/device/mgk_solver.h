@@ -433,22 +433,26 @@ struct pair_solver {
             // attribute payloads stay in global memory behind their pointers.)
             job_sync<W>();  // previous pair is done with lU / lG
             {
-                const unsigned w1 = (h1.perm + 2u * n1 - h1.degree + cb1 + 3u) / 4u;
-                const unsigned w2 = (h2.perm + 2u * n2 - h2.degree + cb2 + 3u) / 4u;
-                const unsigned *const s1 = reinterpret_cast<const unsigned *>(prm.arena + h1.degree - cb1);
-                const unsigned *const s2 = reinterpret_cast<const unsigned *>(prm.arena + h2.degree - cb2);
-                unsigned *const d1 = reinterpret_cast<unsigned *>(lG1);
-                unsigned *const d2 = reinterpret_cast<unsigned *>(lG2);
-                constexpr int K = 4;   // loads in flight per graph and lane
+                // 16 bytes per lane and load: every section (and the class
+                // section in front) is 16-byte aligned in the arena, the LDS
+                // images are too, and g_capacity is a multiple of 16
+                typedef unsigned v4 __attribute__((ext_vector_type(4)));
+                const unsigned w1 = (h1.perm + 2u * n1 - h1.degree + cb1 + 15u) / 16u;
+                const unsigned w2 = (h2.perm + 2u * n2 - h2.degree + cb2 + 15u) / 16u;
+                const v4 *const s1 = reinterpret_cast<const v4 *>(prm.arena + h1.degree - cb1);
+                const v4 *const s2 = reinterpret_cast<const v4 *>(prm.arena + h2.degree - cb2);
+                v4 *const d1 = reinterpret_cast<v4 *>(lG1);
+                v4 *const d2 = reinterpret_cast<v4 *>(lG2);
+                constexpr int K = 2;   // loads in flight per graph and lane
                 const unsigned wmax = w1 > w2 ? w1 : w2;
 #pragma nounroll
                 for (unsigned base = 0; base < wmax; base += K * T) {
-                    unsigned v1[K], v2[K];
+                    v4 v1[K], v2[K];
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
                         const unsigned w = base + k * T + tid;
-                        v1[k] = w < w1 ? s1[w] : 0u;
-                        v2[k] = w < w2 ? s2[w] : 0u;
+                        v1[k] = w < w1 ? s1[w] : v4{0u, 0u, 0u, 0u};
+                        v2[k] = w < w2 ? s2[w] : v4{0u, 0u, 0u, 0u};
                     }
 #pragma unroll
                     for (int k = 0; k < K; ++k) {
