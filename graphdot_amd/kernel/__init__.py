@@ -1,1 +1,2 @@
-"""Graph kernels.  Only the marginalized graph kernel is in scope."""
+"""Graph kernels: the marginalized graph kernel (the hot path), the kernel
+transformers of ``fix`` and the ready-made molecular kernel."""

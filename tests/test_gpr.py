@@ -201,3 +201,87 @@ def test_gpr_on_the_marginalized_graph_kernel():
     gpr.fit(G, y)
     mean, std = gpr.predict(G[:5], return_std=True)
     assert mean.shape == (5,) and np.all(std >= 0)
+
+
+def test_normalization_and_exponentiation_follow_the_protocol(data):
+    """kernel/fix.py: values, gradients (against finite differences) and the
+    hyperparameter interface of the two transformers."""
+    from graphdot_amd.kernel.fix import Normalization, Exponentiation
+    X, _ = data
+    X, Y = X[:8], X[8:13]
+
+    class Scaled(RBF):                     # a kernel whose diagonal varies
+        def __call__(self, X, Y=None, eval_gradient=False):
+            X = np.asarray(X, float)
+            sx = 1 + X[:, 0]**2
+            sy = sx if Y is None else 1 + np.asarray(Y, float)[:, 0]**2
+            out = super().__call__(X, Y, eval_gradient)
+            w = np.outer(sx, sy)
+            if eval_gradient:
+                return out[0] * w, out[1] * w[:, :, None]
+            return out * w
+
+        def diag(self, X, eval_gradient=False):
+            X = np.asarray(X, float)
+            d = self.s**2 * (1 + X[:, 0]**2)**2
+            if eval_gradient:
+                return d, np.stack((2 * d / self.s, 0 * d), axis=1)
+            return d
+
+    base = Scaled(1.3, 0.7)
+    for wrap in (Normalization(base), Exponentiation(base, xi=1.7),
+                 Normalization(Exponentiation(base, xi=0.6))):
+        theta = np.array(wrap.theta, dtype=float)
+        assert len(wrap.bounds) == len(theta)
+        for args in ((X,), (X, Y)):
+            K, dK = wrap(*args, eval_gradient=True)
+            assert np.allclose(K, wrap(*args))
+            assert dK.shape == K.shape + (len(theta),)
+            for k in range(len(theta)):
+                tp, tm = theta.copy(), theta.copy()
+                tp[k] += 1e-6
+                tm[k] -= 1e-6
+                fd = (wrap.clone_with_theta(tp)(*args)
+                      - wrap.clone_with_theta(tm)(*args)) / 2e-6
+                # gradients are w.r.t. the raw hyperparameters
+                raw = np.exp(theta[k])
+                assert np.allclose(dK[:, :, k] * raw, fd, rtol=1e-5,
+                                   atol=1e-7)
+        assert np.allclose(wrap.theta, theta)      # clones left it alone
+    n = Normalization(base)
+    assert np.allclose(np.diag(n(X)), 1) and np.all(n.diag(X) == 1)
+    assert np.allclose(Exponentiation(base, 2.0).diag(X), base.diag(X)**2)
+
+
+@pytest.mark.gpu
+def test_molecular_kernel_normalised_in_a_gpr():
+    """Tang2019MolecularKernel on graphs with `element` / `length`
+    attributes, normalised, inside the GPR: the usual stack on top of the
+    HIP path."""
+    import networkx as nx
+    from graphdot_amd.graph import Graph
+    from graphdot_amd.kernel.fix import Normalization
+    from graphdot_amd.kernel.molecular import Tang2019MolecularKernel
+    rng = np.random.default_rng(2)
+    graphs = []
+    for _ in range(12):
+        n = int(rng.integers(4, 9))
+        g = nx.random_labeled_tree(n, seed=int(rng.integers(1 << 30)))
+        for v in g.nodes:
+            g.nodes[v]['element'] = int(rng.choice([1, 6, 8]))
+        for e in g.edges:
+            g.edges[e]['length'] = float(rng.uniform(0.9, 1.6))
+        graphs.append(g)
+    G = Graph.unify_datatype([Graph.from_networkx(g) for g in graphs])
+    mol = Tang2019MolecularKernel(edge_length_scale=0.2)
+    K = Normalization(mol)(G)
+    assert np.allclose(np.diag(K), 1) and np.all(K <= 1 + 1e-6)
+    assert np.allclose(K, K.T)
+    y = rng.normal(size=len(G))
+    gpr = GaussianProcessRegressor(Normalization(mol), alpha=1e-2,
+                                   normalize_y=True)
+    gpr.fit(G, y)
+    val, grad = gpr.log_marginal_likelihood(eval_gradient=True)
+    assert np.isfinite(val) and np.all(np.isfinite(grad))
+    assert len(grad) == len(mol.theta)
+    assert np.abs(gpr.predict(G) - y).max() < 1.0
