@@ -45,6 +45,25 @@ class _Transformed:
         clone.theta = theta
         return clone
 
+    # -- optional device path (see MarginalizedGraphKernel.device_gram) --------
+    @property
+    def active_theta_mask(self):
+        return self.kernel.active_theta_mask
+
+    def _inner_device_gram(self, X, eval_gradient):
+        """float64 torch tensors (K, dK over all hyperparameter columns) of
+        the wrapped kernel on the GPU; TypeError if it has no device path."""
+        inner = getattr(self.kernel, 'device_gram', None)
+        if inner is None:
+            raise TypeError('the wrapped kernel has no device_gram')
+        import torch
+        out = inner(X, eval_gradient=eval_gradient)
+        R, dR = out if eval_gradient else (out, None)
+        R = torch.as_tensor(R, device='cuda').to(torch.float64)
+        if dR is not None:
+            dR = torch.as_tensor(dR, device='cuda').to(torch.float64)
+        return R, dR
+
 
 class Normalization(_Transformed):
     r""":math:`k_n(x, y) = k(x, y) / \sqrt{k(x, x)\,k(y, y)}`."""
@@ -75,6 +94,20 @@ class Normalization(_Transformed):
                                        + (ddr / dr[:, None])[None, :, :]))
         return K, np.asfortranarray(dK)
 
+    def device_gram(self, X, eval_gradient=False):
+        """`__call__(X)` computed on the GPU from the wrapped kernel's device
+        buffers; returns torch tensors."""
+        R, dR = self._inner_device_gram(X, eval_gradient)
+        d = R.diagonal()
+        s = d.rsqrt()
+        K = s[:, None] * R * s[None, :]
+        if not eval_gradient:
+            return K
+        rel = dR.diagonal(dim1=0, dim2=1).T / d[:, None]      # d log k(x, x)
+        dK = (s[:, None, None] * dR * s[None, :, None]
+              - 0.5 * K[:, :, None] * (rel[:, None, :] + rel[None, :, :]))
+        return K, dK
+
     def diag(self, X, eval_gradient=False, **options):
         """Ones (and, like the reference, ones for the 'gradient')."""
         one = np.ones(len(X))
@@ -102,6 +135,20 @@ class Exponentiation(_Transformed):
                              (self.xi * R**(self.xi - 1))[:, :, None] * dR),
                             axis=2)
         return K, dK
+
+    def device_gram(self, X, eval_gradient=False):
+        import torch
+        R, dR = self._inner_device_gram(X, eval_gradient)
+        K = R**self.xi
+        if not eval_gradient:
+            return K
+        return K, torch.cat(((K * R.log())[:, :, None],
+                             (self.xi * R**(self.xi - 1))[:, :, None] * dR),
+                            dim=2)
+
+    @property
+    def active_theta_mask(self):
+        return np.concatenate(([True], self.kernel.active_theta_mask))
 
     def diag(self, X, eval_gradient=False, **options):
         """``kernel.diag(X) ** xi`` (with the gradient, which the reference's

@@ -331,11 +331,14 @@ class GaussianProcessRegressor:
         diag.copy_(self._regularize(diag, self.alpha))
         dK = None
         if dKd is not None:
-            cols = torch.as_tensor(
-                np.flatnonzero(np.asarray(kernel.active_theta_mask)),
-                device=la.device)
-            dK = torch.as_tensor(dKd, device=la.device).index_select(
-                2, cols).to(torch.float64)
+            dK = torch.as_tensor(dKd, device=la.device)
+            # a graph kernel hands over all its columns; transformers
+            # (kernel/fix.py) already work on what the kernel protocol returns
+            mask = np.asarray(kernel.active_theta_mask)
+            if dK.shape[2] == len(mask) and not mask.all():
+                dK = dK.index_select(2, torch.as_tensor(
+                    np.flatnonzero(mask), device=la.device))
+            dK = dK.to(torch.float64)
         return K, dK
 
     def log_marginal_likelihood(self, theta=None, X=None, y=None,

@@ -284,4 +284,19 @@ def test_molecular_kernel_normalised_in_a_gpr():
     val, grad = gpr.log_marginal_likelihood(eval_gradient=True)
     assert np.isfinite(val) and np.all(np.isfinite(grad))
     assert len(grad) == len(mol.theta)
+    # the transformers pass the device path through: same numbers as the
+    # numpy path of the kernel protocol
+    from graphdot_amd.kernel.fix import Exponentiation
+    for wrapped in (Normalization(mol),
+                    Normalization(Exponentiation(mol, xi=1.5))):
+        dev = GaussianProcessRegressor(wrapped, alpha=1e-2, normalize_y=True)
+        host = GaussianProcessRegressor(wrapped, alpha=1e-2, normalize_y=True,
+                                        device='cpu')
+        dev.X = host.X = G
+        dev.y = host.y = y
+        assert dev._device_gramian(dev._dense(), wrapped, G, True) is not None
+        v1, g1 = dev.log_marginal_likelihood(eval_gradient=True)
+        v2, g2 = host.log_marginal_likelihood(eval_gradient=True)
+        assert v1 == pytest.approx(v2, rel=1e-5)
+        assert np.allclose(g1, g2, rtol=2e-3, atol=1e-4 * np.abs(g2).max())
     assert np.abs(gpr.predict(G) - y).max() < 1.0
