@@ -783,3 +783,29 @@ def test_graphs_with_many_isolated_nodes(real):
     assert np.allclose(Kn, oracle.gram(graphs, knode, kedge, q=0.1,
                                        nodal=True),
                        rtol=1e-5 if real is np.float32 else 1e-6)
+
+
+def test_config2_full_size_properties(backend):
+    """BASELINE.json configuration 2 at full size (256 weighted random graphs
+    of 8..48 nodes, 32 896 pairs; the BASELINE-faithful kernels): symmetry,
+    the diagonal against `diag()`, Cauchy-Schwarz, positive semi-definiteness
+    and a sample of pairs against the C restatement in fp64."""
+    G = cases.config2_graphs(256, seed=0)
+    knode, kedge, q = cases.config2b_kernels()
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    K = k(G)
+    assert K.shape == (256, 256) and np.all(np.isfinite(K))
+    assert np.array_equal(K, K.T)
+    d = k.diag(G)
+    assert np.allclose(np.diag(K), d, rtol=1e-6)
+    Kn = K / np.sqrt(np.outer(d, d))
+    assert Kn.max() <= 1 + 2e-6
+    w = np.linalg.eigvalsh(Kn.astype(np.float64))
+    assert w.min() > -1e-4 * w.max()
+    used = {L['variant'].W for L in backend.last_plan.launches}
+    assert used >= {1, 4}, used
+    rng = np.random.default_rng(5)
+    ii, jj = rng.integers(0, 256, 200), rng.integers(0, 256, 200)
+    batch = oracle.TensorProductBatch(G, knode, kedge)
+    ref, _ = batch.run(ii, jj, q=q, real='f64', tol=1e-13)
+    assert np.allclose(K[ii, jj], ref, rtol=2e-5)
