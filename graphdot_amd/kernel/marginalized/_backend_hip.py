@@ -436,6 +436,8 @@ struct ${name}_t : ${name}_theta_t {
     _WAVES_F32_GRADIENT = {8: 5, 12: 4, 16: 3, 20: 2, 24: 2, 28: 2, 32: 1}
     _WAVES_F64_VALUE = {8: 5, 12: 4, 16: 3, 20: 3, 24: 2, 28: 2, 32: 2}
     _WAVES_F64_GRADIENT = {8: 3, 12: 3, 16: 2, 20: 2, 24: 1, 28: 1, 32: 1}
+    _WAVES_F32_VALUE_W4 = {(4, 32): 3, (4, 64): 2}
+    _WAVES_F64_VALUE_W4 = {(4, 32): 2}
 
     def waves_per_eu(self, v, C):
         """Occupancy target handed to the register allocator
@@ -456,6 +458,14 @@ struct ${name}_t : ${name}_theta_t {
                      (2, True): self._WAVES_F64_GRADIENT}.get((C, f64), {})
             if v.S in table:
                 return max(table[v.S], floor)
+        # four-wave variants of the fp32 value solver, measured on the
+        # 8..48-node random graphs of configuration 2
+        if C == 1:
+            w4 = self._WAVES_F32_VALUE_W4 \
+                if np.dtype(self.real) == np.float32 \
+                else self._WAVES_F64_VALUE_W4
+            if (v.W, v.S) in w4:
+                return max(w4[(v.W, v.S)], floor)
         need = 5.3 * v.S + 4 * v.R + 6
         if C == 2:
             need = 1.6 * need
