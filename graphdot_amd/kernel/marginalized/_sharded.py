@@ -109,3 +109,101 @@ class ShardPlan:
             out[mdst] = g[msrc]
         out = out.reshape(self.nY, self.nX, n_cols).transpose(1, 0, 2)
         return out[:, :, 0] if n_cols == 1 else out
+
+
+def distributed_backend(**kwargs):
+    """A HIPBackend that shards every graph-level evaluation over the ranks
+    of the initialised ``torch.distributed`` process group (one process per
+    GPU, launched e.g. by ``python -m torch.distributed.run``):
+
+        kernel = MarginalizedGraphKernel(knode, kedge, q=q,
+                                         backend=distributed_backend())
+        K = kernel(graphs)          # every rank gets the full matrix
+
+    Pairs are independent, so each rank solves its cost-balanced share of the
+    job list into a packed slab (`ShardPlan`), one all-gather of equal-sized
+    slabs follows (RCCL for the "nccl" backend, host memory for "gloo"), and
+    every rank scatters the gathered values into the caller's arrays.  Nodal
+    and diagonal evaluations, and runs without a process group, take the
+    single-GPU path.  Keyword arguments as for HIPBackend."""
+    from ._backend_hip import HIPBackend
+
+    class DistributedHIPBackend(HIPBackend):
+
+        def __init__(self, **kw):
+            super().__init__(**kw)
+            self._shard_plans = {}
+
+        def _shard_plan(self, dgraphs, jobs, nX, nY, symmetric, rank, world):
+            key = (tuple(map(id, dgraphs)), id(jobs) if not
+                   jobs.flags.writeable else hash(jobs.tobytes()),
+                   nX, nY, symmetric, rank, world)
+            hit = self._shard_plans.get(key)
+            if hit is None:
+                if len(self._shard_plans) > 8:
+                    self._shard_plans.clear()
+                n_node = np.array([g.n_node for g in dgraphs], np.int64)
+                n_nz = np.array([g.n_nz for g in dgraphs], np.int64)
+                sp = ShardPlan(jobs['i'].astype(np.int64),
+                               jobs['j'].astype(np.int64), n_node, n_nz,
+                               nX, nY, symmetric, rank, world)
+                hit = self._shard_plans[key] = (sp, jobs, list(dgraphs), {})
+            return hit
+
+        def __call__(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol,
+                     gtol, jobs, starts, gramian, gradient, nX, nY, nJ,
+                     traits, timer):
+            import torch
+            import torch.distributed as dist
+            graph_level = (traits.nodal is False and not traits.diagonal)
+            if not (dist.is_available() and dist.is_initialized()
+                    and dist.get_world_size() > 1 and graph_level):
+                return super().__call__(
+                    graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
+                    jobs, starts, gramian, gradient, nX, nY, nJ, traits,
+                    timer)
+            rank, world = dist.get_rank(), dist.get_world_size()
+            jobs = np.ascontiguousarray(jobs)
+            dgraphs = [self._register_graph(g) for g in graphs]
+            sp, _, _, index_cache = self._shard_plan(
+                dgraphs, jobs, int(nX), int(nY), bool(traits.symmetric), rank,
+                world)
+            n_grad = int(nJ) if traits.eval_gradient is True else 0
+            n_cols = 1 + n_grad
+            timer.tic('GPU kernel execution')
+            local_jobs = jobs[sp.local]
+            local_jobs.flags.writeable = True      # fresh array: by checksum
+            plan = self.prepare(graphs, node_kernel, edge_kernel, p, q, eps,
+                                ftol, gtol, local_jobs, starts, nX, nY, nJ,
+                                traits, timer, packed=True)
+            self.launch(plan)
+            values, grads = self.collect(plan)
+            timer.toc('GPU kernel execution')
+
+            # slab of this rank: [capacity values | capacity * n_grad entries]
+            cap = sp.capacity
+            slab = np.zeros(cap * n_cols, dtype=values.dtype)
+            slab[:len(values)] = values
+            if n_grad:
+                slab[cap:cap + len(grads)] = grads
+            on_device = dist.get_backend() == 'nccl'
+            t_slab = torch.from_numpy(slab)
+            if on_device:
+                t_slab = t_slab.cuda()
+            gathered = torch.empty(world * len(slab), dtype=t_slab.dtype,
+                                   device=t_slab.device)
+            dist.all_gather_into_tensor(gathered, t_slab)
+            gathered = gathered.cpu().numpy()
+
+            if n_grad not in index_cache:
+                index_cache[n_grad] = sp.reassembly_index(n_grad)
+            src, dst = index_cache[n_grad]
+            n_out = int(nX) * int(nY)
+            gramian[:] = 0
+            gramian[dst[dst < n_out]] = gathered[src[dst < n_out]]
+            if n_grad:
+                sel = dst >= n_out
+                gradient[:] = 0
+                gradient[dst[sel] - n_out] = gathered[src[sel]]
+
+    return DistributedHIPBackend(**kwargs)

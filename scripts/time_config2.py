@@ -20,7 +20,7 @@ job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
 jobs = np.column_stack((i, j)).astype(np.uint32).ravel().view(job_t)
 for name, kernels in (('2a', cases.config2a_kernels),
                       ('2b', cases.config2b_kernels)):
-    for real in ((np.float64,) if "--f64" in sys.argv else (np.float32, np.float64)):
+    for real in ((np.float64,) if "--f64" in sys.argv else (np.float32,) if "--f32" in sys.argv else (np.float32, np.float64)):
         kn, ke, q = kernels()
         b = HIPBackend(real=real)
         k = MarginalizedGraphKernel(kn, ke, q=q, backend=b)
