@@ -252,6 +252,10 @@ class MarginalizedGraphKernel:
         backend = self.backend
         if not hasattr(backend, 'prepare'):
             raise TypeError('device_gram needs the HIP backend')
+        if getattr(backend, 'shards_over_ranks', lambda: False)():
+            # the sharded evaluation ends in host arrays on every rank
+            raise TypeError('device_gram is a single-GPU path; the '
+                            'distributed backend goes through __call__')
         pred = Graph.has_unified_types(X)
         if pred is not True:
             raise _type_error(

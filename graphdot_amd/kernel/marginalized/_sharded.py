@@ -134,6 +134,13 @@ def distributed_backend(**kwargs):
             super().__init__(**kw)
             self._shard_plans = {}
 
+        @staticmethod
+        def shards_over_ranks():
+            """True when a process group with more than one rank is up."""
+            import torch.distributed as dist
+            return (dist.is_available() and dist.is_initialized()
+                    and dist.get_world_size() > 1)
+
         def _shard_plan(self, dgraphs, jobs, nX, nY, symmetric, rank, world):
             key = (tuple(map(id, dgraphs)), id(jobs) if not
                    jobs.flags.writeable else hash(jobs.tobytes()),
@@ -156,8 +163,7 @@ def distributed_backend(**kwargs):
             import torch
             import torch.distributed as dist
             graph_level = (traits.nodal is False and not traits.diagonal)
-            if not (dist.is_available() and dist.is_initialized()
-                    and dist.get_world_size() > 1 and graph_level):
+            if not (self.shards_over_ranks() and graph_level):
                 return super().__call__(
                     graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
                     jobs, starts, gramian, gradient, nX, nY, nJ, traits,

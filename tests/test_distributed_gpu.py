@@ -28,8 +28,15 @@ def _worker(rank, world, port, tmp):
     K2, dK = k(G, eval_gradient=True)
     Kxy = k(G[:12], G[12:])
     d = k.diag(G)                                   # single-GPU path
+    # a GPR on top: the zero-copy device path steps aside, the likelihood
+    # goes through the sharded __call__ and is the same on every rank
+    from graphdot_amd.model.gaussian_process import GaussianProcessRegressor
+    gpr = GaussianProcessRegressor(k, alpha=float(0.1 * d.mean()))
+    gpr.X, gpr.y = G, np.cos(np.arange(len(G)))
+    assert gpr._device_gramian(gpr._dense(), k, G, True) is None
+    lml, glml = gpr.log_marginal_likelihood(eval_gradient=True)
     np.savez(os.path.join(tmp, f'rank{rank}.npz'), K=K, K2=K2, dK=dK,
-             Kxy=Kxy, d=d)
+             Kxy=Kxy, d=d, lml=lml, glml=glml)
     dist.destroy_process_group()
 
 
@@ -53,3 +60,11 @@ def test_two_ranks_through_the_kernel_api(tmp_path):
         assert np.array_equal(r['Kxy'], Kxy)
         assert np.array_equal(r['d'], d)
         assert np.array_equal(r['K'], r['K'].T)
+    from graphdot_amd.model.gaussian_process import GaussianProcessRegressor
+    gpr = GaussianProcessRegressor(k, alpha=float(0.1 * d.mean()),
+                                   kernel_options={'lmin': 0})   # numpy path
+    gpr.X, gpr.y = G, np.cos(np.arange(len(G)))
+    lml, glml = gpr.log_marginal_likelihood(eval_gradient=True)
+    r0, r1 = (np.load(tmp_path / f'rank{r}.npz') for r in range(2))
+    assert float(r0['lml']) == float(r1['lml']) == pytest.approx(lml, rel=1e-9)
+    assert np.allclose(r0['glml'], glml, rtol=1e-7)
