@@ -2,22 +2,34 @@
 """Gram-matrix throughput of the marginalized graph kernel on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-                    [--graphs 1000] [--dtype f64|f32] [--gradient]
+                    [--config 3|2] [--dtype f64|f32] [--gradient]
+                    [--graphs n] [--sharded] [--serial]
 
 A *step* is one full pass of the hot path over the batch: every pair of the
-symmetric Gram matrix of the synthetic QM7-like set (config 3 of
-BASELINE.json) is solved from device-resident graphs, job list
-and hyperparameters into the device-resident result.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) the pairs are sharded over the ranks
-and one RCCL all-gather per step reassembles the packed results.
+symmetric Gram matrix of the workload is solved from device-resident graphs,
+job list and hyperparameters into the device-resident result.
 
-The default arithmetic is fp64, as BASELINE.json names it for this
-configuration; the reference's CUDA solver computes in fp32, and a short fp32
-measurement of the same step is reported in the same line ("other_arithmetic").
+  --config 3 (default)  the synthetic QM7-like set, 1000 molecules, 500 500
+                        pairs (BASELINE.json's headline configuration;
+                        SURVEY.md 8d), fp64 by default as BASELINE.json names it
+  --config 2            256 weighted Newman-Watts-Strogatz graphs of 8..48
+                        nodes, 32 896 pairs, KroneckerDelta node x
+                        SquareExponential edge kernels (BASELINE.json config 2;
+                        reference workload benchmark/kernel/marginalized/
+                        time_kernel.py:14-29), fp32 by default (the reference
+                        solver's arithmetic)
+  --gradient            value + dK/dtheta (the kernel part of config 5)
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with the
-extra objects "roofline" (dominant kernel, HIP-event timed inside the timed
-region) and "cpu_baseline" (the C oracle timed on this host, rank 0, N = 1).
+With N > 1 (launched by torch.distributed.run, one rank per GPU) the pairs are
+sharded over the ranks and one RCCL all-gather per step reassembles the packed
+results (`graphdot_amd.kernel.marginalized._sharded.ShardedStep`, the code
+path of `distributed_backend()`); `--sharded` takes that path on one rank too.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+"roofline" (dominant kernel; durations from HIP events on the launch streams),
+"step_aggregate" (all launches of a step against the step time),
+"cpu_baseline" (the C oracle timed on this host, rank 0, N = 1) and
+"api_inclusive" (numpy in -> numpy out through MarginalizedGraphKernel).
 """
 import argparse
 import json
@@ -34,45 +46,123 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
 
 import numpy as np  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md
+VALU_PEAK_TF = {'f32': 157.3, 'f64': 78.6}  # vector (non-MFMA) peaks
+LDS_PEAK_TBS = {'f32': 75.0, 'f64': 150.0}  # ds_read_b32 / ds_read_b64 aggregate
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--graphs', type=int, default=1000)
-    ap.add_argument('--dtype', default='f64', choices=['f32', 'f64'],
-                    help='arithmetic of the solver: f64 is what BASELINE.json '
-                         'names for the QM7-1000 configuration (default); '
-                         'f32 is the arithmetic of the reference CUDA solver')
+    ap.add_argument('--config', type=int, default=3, choices=[2, 3])
+    ap.add_argument('--graphs', type=int, default=None,
+                    help='number of graphs (default: 1000 for config 3, '
+                         '256 for config 2)')
+    ap.add_argument('--dtype', default=None, choices=['f32', 'f64'],
+                    help='arithmetic of the solver (default: f64 for config '
+                         '3 as BASELINE.json names it; f32, the reference '
+                         'CUDA solver\'s arithmetic, for config 2)')
     ap.add_argument('--no-f32', action='store_true',
-                    help='skip the short fp32 measurement reported next to '
-                         'an fp64 run')
+                    help='skip the short measurement in the other arithmetic')
     ap.add_argument('--gradient', action='store_true',
                     help='also evaluate dK/dtheta (config 5 kernel part)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-api', action='store_true',
+                    help='skip the numpy-in / numpy-out measurement')
+    ap.add_argument('--sharded', action='store_true',
+                    help='one rank through the multi-GPU code path (process '
+                         'group of size 1, RCCL all-gather, device reassembly)')
     ap.add_argument('--serial', action='store_true',
                     help='all solver variants on one stream (default: one '
                          'HIP stream per variant so short launches fill the '
                          'tails of long ones)')
+    ap.add_argument('--isolated-steps', type=int, default=3,
+                    help='serial steps after the timed region that give the '
+                         'isolated per-kernel durations (0: skip)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     return ap.parse_args()
 
 
+# ---- algorithmic work of a set of jobs ----------
 def algorithmic_bytes(arena, ji, jj, rsize, n_cols):
-    """compulsory HBM bytes of a pair = both graph images (as
-    packed in HBM) + the result."""
+    """Compulsory HBM bytes of a pair = both graph images (as packed in HBM)
+    + two 32-byte headers + the result."""
     blob = np.diff(np.concatenate((arena.blob_start, [arena.nbytes])))
-    hdr = 32
-    return (blob[ji] + blob[jj] + 2 * hdr + rsize * n_cols).astype(np.int64)
+    return (blob[ji] + blob[jj] + 64 + rsize * n_cols).astype(np.int64)
 
 
 def algorithmic_flops(n_node, n_nz, ji, jj, iters, Fv=9, Fe=8):
-    """SURVEY 8(d) with cached edge/node kernel tables:
-    k (2 nnzx + 17 N) + nnzx F_e + N F_v."""
+    """k (2 nnzx + 17 N) + nnzx F_e + N F_v (cached edge/node values)."""
     N = n_node[ji] * n_node[jj]
     nnzx = n_nz[ji] * n_nz[jj]
     return iters * (2 * nnzx + 17 * N) + nnzx * Fe + N * Fv
+
+
+def algorithmic_lds_reals(n_node, n_nz, ji, jj, iters):
+    """Per CG iteration 2 reals per product-graph nonzero (gather + U) and
+    10 per row."""
+    N = n_node[ji] * n_node[jj]
+    nnzx = n_nz[ji] * n_nz[jj]
+    return iters * (2 * nnzx + 10 * N)
+
+
+class LocalStep:
+    """One rank, no collective: the plan's launches, one stream per solver
+    variant, ordered against the previous step by device-side events."""
+
+    def __init__(self, backend, plan):
+        from graphdot_amd.hip import runtime
+        self.rt = runtime
+        self.plan = plan
+        self.streams = [runtime.Stream() for _ in plan.launches]
+        self.done = [runtime.Event() for _ in plan.launches]
+        self.join = runtime.Event()
+        self.first = True
+
+    def enqueue(self, events=None, serial=False):
+        rt = self.rt
+        for k, L in enumerate(self.plan.launches):
+            s = None if serial else self.streams[k]
+            if s is not None and not self.first:
+                s.wait_event(self.join)
+            if events is not None:
+                events[k][0].record(s.h if s else None)
+            rt.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                      stream=s.h if s else None, dynamic_lds=L['dynamic_lds'])
+            if events is not None:
+                events[k][1].record(s.h if s else None)
+            if s is not None:
+                self.done[k].record(s.h)
+                rt.null_stream_wait_event(self.done[k])
+        self.join.record()
+        self.first = False
+
+    def synchronize(self):
+        self.rt.synchronize()
+
+
+def workload(args):
+    import cases
+    if args.config == 3:
+        n = args.graphs or 1000
+        graphs = cases.config3_graphs(n)
+        knode, kedge, q = cases.config3_kernels()
+        name = (f'QM7-like synthetic set ({n} molecules, seed 7165, '
+                f'{n * (n + 1) // 2} pairs incl. diagonal), TensorProduct '
+                'atom/bond microkernels, q=0.01')
+        F = (9, 8)
+    else:
+        n = args.graphs or 256
+        graphs = cases.config2_graphs(n, seed=0)
+        knode, kedge, q = cases.config2b_kernels()
+        name = (f'config 2: {n} weighted Newman-Watts-Strogatz graphs (k=5, '
+                f'p=0.05, 8..48 nodes, seed 0, {n * (n + 1) // 2} pairs incl. '
+                'diagonal), KroneckerDelta node x SquareExponential edge '
+                'microkernels, q=0.05')
+        F = (2, 6)
+    return graphs, knode, kedge, q, name, F
 
 
 def measure_other_arithmetic(name, graphs, knode, kedge, q, jobs, starts, n,
@@ -103,6 +193,31 @@ def measure_other_arithmetic(name, graphs, knode, kedge, q, jobs, starts, n,
                     'arithmetic (f32 = the reference CUDA solver\'s)'}
 
 
+def measure_api(graphs, knode, kedge, q, real, device, gradient, n_pairs):
+    """numpy in -> numpy out, as a user of the reference calls it
+    (`MarginalizedGraphKernel.__call__`): a fresh backend's first call (graph
+    packing, code-object load, upload, solve, download) and the repeated call
+    of a training loop (cached layout; new kernel arguments, solve, D2H of the
+    matrix, the reference's float64 conversion)."""
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    for g in graphs:                      # forget earlier packings
+        g.cookie.clear()
+    backend = HIPBackend(device=device, real=real)
+    kernel = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    t0 = time.perf_counter()
+    kernel(graphs, eval_gradient=gradient)
+    first = time.perf_counter() - t0
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        kernel(graphs, eval_gradient=gradient)
+    rep = (time.perf_counter() - t0) / reps
+    return {'first_call_ms': 1e3 * first, 'repeat_call_ms': 1e3 * rep,
+            'value': n_pairs / rep, 'unit': 'graph-pairs/s',
+            'note': 'host-, PCIe- and conversion-inclusive; never `value`'}
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -110,18 +225,20 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus and world > 1:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-
-    import cases
-    from graphdot_amd.hip import runtime
-    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
-    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
-    from graphdot_amd.kernel.marginalized._sharded import ShardPlan
+    if args.dtype is None:
+        args.dtype = 'f64' if args.config == 3 else 'f32'
+    sharded = world > 1 or args.sharded
 
     dist = torch = None
     host_collective = False
-    if world > 1:
+    if sharded:
         import torch
         import torch.distributed as dist
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 400))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         n_dev = torch.cuda.device_count()
         if n_dev >= world:
             torch.cuda.set_device(local_rank)
@@ -134,11 +251,15 @@ def main():
             local_rank = local_rank % max(n_dev, 1)
             torch.cuda.set_device(local_rank)
             dist.init_process_group('gloo')
+
+    from graphdot_amd.hip import runtime
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    from graphdot_amd.kernel.marginalized._sharded import ShardedStep
+
     real = np.float32 if args.dtype == 'f32' else np.float64
     backend = HIPBackend(device=local_rank, real=real, record_iterations=True)
-
-    graphs = cases.config3_graphs(args.graphs)
-    knode, kedge, q = cases.config3_kernels()
+    graphs, knode, kedge, q, workload_name, (Fv, Fe) = workload(args)
     kernel = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
     n = len(graphs)
     i, j = np.triu_indices(n)
@@ -150,105 +271,41 @@ def main():
     n_cols = 1 + (nJ if args.gradient else 0)
     starts = np.arange(n + 1, dtype=np.uint32)
 
-    # ---- shard (world == 1: the single shard is the whole job list) ---------
     dgs = [backend._register_graph(g) for g in graphs]
     n_node = np.array([g.n_node for g in dgs], dtype=np.int64)
     n_nz = np.array([g.n_nz for g in dgs], dtype=np.int64)
-    shard = ShardPlan(i, j, n_node, n_nz, n, n, True, rank, world)
-    local_jobs = all_jobs[shard.local] if world > 1 else all_jobs
-    local_out = gathered = None
-    out_ptrs = {}
-    if world > 1:
-        # every rank's packed slab [cap values | cap*nJ gradient entries] is
-        # written by the kernels straight into the all-gather input
-        cap = shard.capacity
-        tdtype = torch.float32 if real is np.float32 else torch.float64
-        local_out = torch.zeros(cap * n_cols, dtype=tdtype, device='cuda')
-        gathered = torch.empty(world * cap * n_cols, dtype=tdtype,
-                               device='cuda')
-        rs_ = np.dtype(real).itemsize
-        out_ptrs = dict(gramian_ptr=local_out.data_ptr(),
-                        gradient_ptr=local_out.data_ptr() + cap * rs_)
-        torch.cuda.synchronize()
-    plan = backend.prepare(graphs, knode, kedge, kernel.p, kernel.q,
-                           kernel.eps, kernel.ftol, kernel.gtol, local_jobs,
-                           starts, n, n, nJ, traits, packed=(world > 1),
-                           **out_ptrs)
+    if sharded:
+        step = ShardedStep(backend, graphs, knode, kedge, kernel.p, kernel.q,
+                           kernel.eps, kernel.ftol, kernel.gtol, all_jobs,
+                           starts, n, n, nJ, traits)
+        plan, local_jobs, shard = step.plan, step.local_jobs, step.shard
+    else:
+        plan = backend.prepare(graphs, knode, kedge, kernel.p, kernel.q,
+                               kernel.eps, kernel.ftol, kernel.gtol, all_jobs,
+                               starts, n, n, nJ, traits)
+        step, local_jobs, shard = LocalStep(backend, plan), all_jobs, None
 
-    # device-side reassembly of the gathered slabs into the F-order matrix
-    # (+ mirror; + one plane per gradient column): part of every step, so
-    # that a step ends with the same product at any N
-    t_src = t_dst = K_dev = None
-    if world > 1:
-        src_idx, dst_idx = shard.reassembly_index(n_cols - 1)
-        t_src = torch.from_numpy(src_idx).cuda()
-        t_dst = torch.from_numpy(dst_idx).cuda()
-        K_dev = torch.zeros(n_cols * n * n, dtype=tdtype, device='cuda')
-        torch.cuda.synchronize()
-
-    kernel_ms = np.zeros(len(plan.launches))
     nL = len(plan.launches)
-    streams = [runtime.Stream() for _ in plan.launches] \
-        if not args.serial else None
     # one (start, stop) event pair per timed step and launch: durations are
     # read after the timed region, so a step never waits on the host
     ev_sets = [[(runtime.Event(), runtime.Event()) for _ in range(nL)]
                for _ in range(args.steps + 1)]
-    ev_join = runtime.Event()    # previous step (and its all-gather) is done
-
-    def step(index, first=False):
-        """One pass.  Everything is enqueued without host synchronisation;
-        device-side events order the passes: every solver stream waits for
-        the join of the previous pass, the join (null stream, which also
-        runs the collective and the reassembly) waits for every solver."""
-        ev = ev_sets[index]
-        if streams is not None:
-            for k, L in enumerate(plan.launches):
-                if not first:
-                    streams[k].wait_event(ev_join)
-                ev[k][0].record(streams[k].h)
-                runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                               stream=streams[k].h,
-                               dynamic_lds=L['dynamic_lds'])
-                ev[k][1].record(streams[k].h)
-            for k in range(nL):
-                runtime.null_stream_wait_event(ev[k][1])
-        else:
-            for k, L in enumerate(plan.launches):
-                ev[k][0].record()
-                runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                               dynamic_lds=L['dynamic_lds'])
-                ev[k][1].record()
-        if world > 1:
-            if host_collective:
-                h = local_out.cpu()
-                g = torch.empty(world * h.numel(), dtype=h.dtype)
-                dist.all_gather_into_tensor(g, h)
-                gathered.copy_(g)
-            else:
-                dist.all_gather_into_tensor(gathered, local_out)
-            K_dev.index_copy_(0, t_dst, gathered.index_select(0, t_src))
-        ev_join.record()
 
     def sync():
-        runtime.synchronize()
-        if world > 1:
-            torch.cuda.synchronize()
+        step.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
 
     for w in range(args.warmup):
-        step(args.steps, first=(w == 0))
-    if args.warmup == 0:
-        ev_join.record()
+        step.enqueue(ev_sets[args.steps], serial=args.serial)
     sync()
     barrier()
     sync()
     t0 = time.perf_counter()
     for it in range(args.steps):
-        step(it)
+        step.enqueue(ev_sets[it], serial=args.serial)
     sync()
     barrier()
     sync()
@@ -258,24 +315,53 @@ def main():
                          device='cpu' if host_collective else 'cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # per-kernel durations: HIP events on the stream each kernel ran on
+    # per-kernel durations inside the timed region: HIP events on the stream
+    # each kernel ran on (the streams share the chip: durations overlap)
+    kernel_ms = np.zeros(nL)
     for it in range(args.steps):
         for k in range(nL):
             kernel_ms[k] += ev_sets[it][k][0].elapsed_ms(ev_sets[it][k][1])
     kernel_ms /= max(args.steps, 1)
 
+    # isolated durations: the same launches one after another on one stream
+    isolated_ms = None
+    if args.isolated_steps > 0:
+        isolated_ms = np.zeros(nL)
+        iso_ev = [(runtime.Event(), runtime.Event()) for _ in range(nL)]
+        for it in range(args.isolated_steps):
+            step.enqueue(iso_ev, serial=True)
+            sync()
+            for k in range(nL):
+                isolated_ms[k] += iso_ev[k][0].elapsed_ms(iso_ev[k][1])
+        isolated_ms /= args.isolated_steps
+    barrier()
+
     if rank != 0:
-        if world > 1:
+        if sharded:
             dist.destroy_process_group()
         return
 
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_pairs / (elapsed / args.steps)
+    rsize = np.dtype(real).itemsize
+    mult = 2 if args.gradient else 1
+
+    # ---- results of this rank's launches on the host ---------------------------
+    if sharded:
+        vals, grads = step.download()
+        K = vals.reshape(n, n, order='F')
+        dK = grads.reshape(n, n, nJ, order='F') if args.gradient else None
+    else:
+        got, ggot = backend.collect(plan)
+        K = got.reshape(n, n, order='F')
+        dK = ggot.reshape(n, n, nJ, order='F') if args.gradient else None
+
     sharded_check = None
-    if world > 1:
-        # reassemble the gathered slabs and compare a sample with the oracle
+    if sharded:
         from oracle import mgk
-        K = K_dev[:n * n].cpu().numpy().reshape(n, n, order='F')
-        K_host = shard.assemble(gathered.cpu().numpy().reshape(
-            world, -1)[:, :shard.capacity].ravel())
+        K_host = shard.assemble(
+            step.gathered.cpu().numpy().reshape(world, -1)[
+                :, :shard.capacity].ravel())
         assert np.array_equal(K, K_host), 'device and host reassembly differ'
         rng = np.random.default_rng(1)
         probe = rng.choice(n_pairs, size=min(3000, n_pairs), replace=False)
@@ -285,107 +371,139 @@ def main():
             'max_rel_diff_vs_oracle': float(np.max(np.abs(
                 K[i[probe], j[probe]] / ref - 1))),
             'symmetric': bool(np.count_nonzero(K - K.T) == 0),
-            'collective': 'gloo/host' if host_collective else 'nccl(RCCL)'}
+            'collective': 'gloo/host' if host_collective else 'nccl(RCCL)',
+            'ranks': world}
 
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = n_pairs / (elapsed / args.steps)
-
-    # ---- roofline of the dominant kernel -------------------------------------
+    # ---- per-launch algorithmic work ---------------------------------------------
     arena = plan.keep[0]
-    dom = int(np.argmax(kernel_ms))
-    L = plan.launches[dom]
-    ids = plan.order_host[L['offset']:L['offset'] + L['count']]
-    lj = local_jobs[ids]
-    lji, ljj = lj['i'].astype(np.int64), lj['j'].astype(np.int64)
-    iters = backend.iterations(plan)[ids].astype(np.int64)
-    rsize = np.dtype(real).itemsize
-    abytes = int(algorithmic_bytes(arena, lji, ljj, rsize, n_cols).sum())
-    aflops = int(algorithmic_flops(n_node, n_nz, lji, ljj, iters).sum()
-                 * (2 if args.gradient else 1))
-    dur = kernel_ms[dom] * 1e-3
-    v = L['variant']
+    iters_all = backend.iterations(plan).astype(np.int64)
+    per_kernel, tot = [], dict(bytes=0, flops=0, lds=0)
+    for k, L in enumerate(plan.launches):
+        ids = plan.order_host[L['offset']:L['offset'] + L['count']]
+        lj = local_jobs[ids]
+        lji, ljj = lj['i'].astype(np.int64), lj['j'].astype(np.int64)
+        it_ = iters_all[ids]
+        ab = int(algorithmic_bytes(arena, lji, ljj, rsize, n_cols).sum())
+        af = int(algorithmic_flops(n_node, n_nz, lji, ljj, it_, Fv, Fe).sum()
+                 * mult)
+        al = int(algorithmic_lds_reals(n_node, n_nz, lji, ljj, it_).sum()
+                 * rsize * mult)
+        tot['bytes'] += ab
+        tot['flops'] += af
+        tot['lds'] += al
+        per_kernel.append({
+            'kernel': backend.kernel_name(L['variant'], plan.C, False,
+                                          L.get('tab', False)),
+            'pairs': int(L['count']), 'grid': int(L['grid']),
+            'avg_ms': float(kernel_ms[k]),
+            'isolated_ms': float(isolated_ms[k]) if isolated_ms is not None
+            else None,
+            'algorithmic_bytes': ab, 'algorithmic_flops': af,
+            'algorithmic_lds_bytes': al,
+            'mean_cg_iterations': float(it_.mean()) if len(it_) else 0.0})
+
+    # ---- roofline of the dominant kernel (by isolated duration) ------------------
+    basis = isolated_ms if isolated_ms is not None else kernel_ms
+    dom = int(np.argmax(basis))
+    D = per_kernel[dom]
+    dur = basis[dom] * 1e-3
     roofline = {
-        'bound': 'hbm', 'kernel': backend.kernel_name(v, plan.C, False, L.get('tab', False)),
-        'achieved': abytes / dur / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
-        'frac': abytes / dur / 1e9 / 8000.0, 'traffic': None,
-        'algorithmic_bytes_per_launch': abytes,
-        'pairs_per_launch': int(L['count']),
-        'avg_launch_ms': float(kernel_ms[dom]),
-        'launch_streams': 'one per solver variant (durations overlap)'
-                          if not args.serial else 'single stream',
+        'bound': 'hbm', 'kernel': D['kernel'],
+        'achieved': D['algorithmic_bytes'] / dur / 1e9, 'peak': HBM_PEAK_GBS,
+        'unit': 'GB/s',
+        'frac': D['algorithmic_bytes'] / dur / 1e9 / HBM_PEAK_GBS,
+        'traffic': None,
+        'algorithmic_bytes_per_launch': D['algorithmic_bytes'],
+        'pairs_per_launch': D['pairs'],
+        'avg_launch_ms': float(basis[dom]),
+        'duration_basis': 'isolated: the launch alone on one stream, HIP '
+                          'events, after the timed region (agrees with '
+                          'rocprofv3 --kernel-trace of `bench.py --serial`)'
+                          if isolated_ms is not None else
+                          'timed region (launch streams overlap)',
+        'avg_launch_ms_in_timed_region': float(kernel_ms[dom]),
         'note': 'the solver is LDS/VALU-bound by design (CG vectors and the '
-                'product-graph operator live in LDS/registers); see compute',
+                'product-graph operator live in LDS/registers; graph images '
+                'are L2-resident): see compute / lds and step_aggregate',
     }
     # measured HBM traffic of that kernel, if a PMC profile of this command
     # has been committed (scripts/profile.sh + scripts/summarize_profile.py)
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
             tr = json.load(f)[args.dtype]['kernels'].get(roofline['kernel'])
-        if tr and not args.gradient and world == 1:
+        if tr and not args.gradient and world == 1 and args.config == 3:
             roofline['traffic'] = tr['hbm_bytes_per_launch']
             roofline['traffic_source'] = 'profiles/traffic.json (rocprofv3 ' \
                 'FETCH_SIZE + WRITE_SIZE, separate passes)'
     except (OSError, KeyError, ValueError):
         pass
-    peak_tf = 157.3 if real is np.float32 else 78.6
+    peak_tf, lds_peak = VALU_PEAK_TF[args.dtype], LDS_PEAK_TBS[args.dtype]
     compute = {
-        'bound': 'valu', 'achieved': aflops / dur / 1e12, 'peak': peak_tf,
-        'unit': 'TFLOP/s', 'frac': aflops / dur / 1e12 / peak_tf,
-        'algorithmic_flops_per_launch': aflops,
-        'mean_cg_iterations': float(iters.mean()),
-    }
-    # LDS traffic model of SURVEY 8(d): per CG iteration 2 reals per product-
-    # graph nonzero (gather + U) and 10 per row, against the aggregate LDS
-    # rate of the access width in use (MI355X_MICROARCH.md, LDS: ~75 TB/s
-    # for ds_read_b32, ~150 TB/s for ds_read_b64)
-    N_ = n_node[lji] * n_node[ljj]
-    nnzx_ = n_nz[lji] * n_nz[ljj]
-    lds_bytes = int((iters * (2 * nnzx_ + 10 * N_)).sum() * rsize
-                    * (2 if args.gradient else 1))
-    lds_peak = 75.0 if rsize == 4 else 150.0
-    lds = {'bound': 'lds', 'achieved': lds_bytes / dur / 1e12,
+        'bound': 'valu', 'achieved': D['algorithmic_flops'] / dur / 1e12,
+        'peak': peak_tf, 'unit': 'TFLOP/s',
+        'frac': D['algorithmic_flops'] / dur / 1e12 / peak_tf,
+        'algorithmic_flops_per_launch': D['algorithmic_flops'],
+        'mean_cg_iterations': D['mean_cg_iterations']}
+    lds = {'bound': 'lds', 'achieved': D['algorithmic_lds_bytes'] / dur / 1e12,
            'peak': lds_peak, 'unit': 'TB/s',
-           'frac': lds_bytes / dur / 1e12 / lds_peak,
-           'algorithmic_lds_bytes_per_launch': lds_bytes,
-           'note': 'durations of concurrent launches overlap: the dominant '
-                   'kernel shares the chip with the other variants'}
-    per_kernel = [
-        {'kernel': backend.kernel_name(l['variant'], plan.C, False,
-                                       l.get('tab', False)),
-         'pairs': int(l['count']), 'grid': int(l['grid']),
-         'avg_ms': float(ms)} for l, ms in zip(plan.launches, kernel_ms)]
+           'frac': D['algorithmic_lds_bytes'] / dur / 1e12 / lds_peak,
+           'algorithmic_lds_bytes_per_launch': D['algorithmic_lds_bytes']}
+    # the whole step: every launch of this rank against the step time
+    st = ms_per_step * 1e-3
+    step_aggregate = {
+        'ms_per_step': ms_per_step, 'launches': nL,
+        'pairs': int(sum(d['pairs'] for d in per_kernel)),
+        'hbm': {'algorithmic_bytes': tot['bytes'],
+                'achieved_GBs': tot['bytes'] / st / 1e9,
+                'frac_step': tot['bytes'] / st / 1e9 / HBM_PEAK_GBS},
+        'compute': {'algorithmic_flops': tot['flops'],
+                    'achieved_TFLOPs': tot['flops'] / st / 1e12,
+                    'frac_step': tot['flops'] / st / 1e12 / peak_tf},
+        'lds': {'algorithmic_bytes': tot['lds'],
+                'achieved_TBs': tot['lds'] / st / 1e12,
+                'frac_step': tot['lds'] / st / 1e12 / lds_peak},
+        'sum_isolated_ms': float(isolated_ms.sum())
+        if isolated_ms is not None else None}
 
     # ---- CPU baseline (oracle, 1 core, bounded sample), N = 1 only -----------
     cpu = None
-    if world == 1 and not args.no_cpu_baseline and not args.gradient:
+    if world == 1 and not args.no_cpu_baseline:
         from oracle import mgk
         batch = mgk.TensorProductBatch(graphs, knode, kedge)
         rng = np.random.default_rng(0)
-        probe = rng.choice(n_pairs, size=min(2000, n_pairs), replace=False)
+
+        def run(sel, omp=False):
+            if args.gradient:
+                v, g, _ = batch.run_gradient(i[sel], j[sel], q=q,
+                                             real=args.dtype, omp=omp)
+                return v, g
+            v, _ = batch.run(i[sel], j[sel], q=q, real=args.dtype, omp=omp)
+            return v, None
+
+        probe = rng.choice(n_pairs, size=min(500, n_pairs), replace=False)
         t1 = time.perf_counter()
-        batch.run(i[probe], j[probe], q=q, real=args.dtype)
+        run(probe)
         rate = len(probe) / (time.perf_counter() - t1)
-        size = int(min(n_pairs, max(2000, rate * args.cpu_seconds)))
+        size = int(min(n_pairs, max(500, rate * args.cpu_seconds)))
         sample = rng.choice(n_pairs, size=size, replace=False)
         t1 = time.perf_counter()
-        ref, _ = batch.run(i[sample], j[sample], q=q, real=args.dtype)
+        ref, gref = run(sample)
         dt = time.perf_counter() - t1
+        fn = 'mgk_gram_tp_grad_' if args.gradient else 'mgk_gram_tp_'
         cpu = {'value': size / dt, 'unit': 'graph-pairs/s', 'cores': 1,
                'kind': 'port',
                'sample': f'{size} uniformly sampled pairs of the same '
                          f'{n}-graph set, oracle/mgk_oracle.c '
-                         f'mgk_gram_tp_{args.dtype}, 1 thread'}
+                         f'{fn}{args.dtype}, 1 thread'}
         # same restatement, OpenMP over the pairs, every core of this host
-        # 
         try:
             ncore = len(os.sched_getaffinity(0))
-            size_all = int(min(n_pairs, max(4000, 0.5 * ncore * rate
-                                            * args.cpu_seconds / 2)))
+            size_all = int(min(n_pairs, max(2000, 0.25 * ncore * rate
+                                            * args.cpu_seconds)))
             sample_all = rng.choice(n_pairs, size=size_all, replace=False)
-            batch.run(i[probe], j[probe], q=q, real=args.dtype, omp=True)
+            run(probe, omp=True)
             t1 = time.perf_counter()
-            batch.run(i[sample_all], j[sample_all], q=q, real=args.dtype,
-                      omp=True)
+            run(sample_all, omp=True)
             cpu['all_cores'] = {
                 'value': size_all / (time.perf_counter() - t1),
                 'unit': 'graph-pairs/s', 'cores': ncore,
@@ -394,26 +512,41 @@ def main():
             cpu['all_cores'] = {'error': str(e)}
         # the reference's own Python CPU path cannot travel to this host; its
         # rate was recorded in the build container (provenance in the file)
-        try:
-            with open(os.path.join(ROOT, 'profiles',
-                                   'r01_reference_python_cpu.json')) as f:
-                rp = json.load(f)
-            cpu['reference_python'] = {
-                k: rp[k] for k in ('value', 'unit', 'cores', 'what', 'where')}
-        except (OSError, KeyError, ValueError):
-            pass
+        if args.config == 3 and not args.gradient:
+            try:
+                with open(os.path.join(ROOT, 'profiles',
+                                       'r01_reference_python_cpu.json')) as f:
+                    rp = json.load(f)
+                cpu['reference_python'] = {
+                    k: rp[k] for k in ('value', 'unit', 'cores', 'what',
+                                       'where')}
+            except (OSError, KeyError, ValueError):
+                pass
         # the sample doubles as an on-line parity check of the timed result
-        got, _ = backend.collect(plan)
-        K = got.reshape(n, n, order='F')
-        err = np.max(np.abs(K[i[sample], j[sample]] / ref - 1))
-        cpu['max_rel_diff_vs_gpu'] = float(err)
+        cpu['max_rel_diff_vs_gpu'] = float(np.max(np.abs(
+            K[i[sample], j[sample]] / ref - 1)))
+        if args.gradient:
+            mask = np.ones(nJ, dtype=bool)
+            dg = dK[i[sample], j[sample], :]
+            scale = np.abs(gref).max(axis=0, keepdims=True)
+            rt, at = (2e-3, 2e-5) if args.dtype == 'f32' else (1e-6, 1e-9)
+            cpu['gradient_max_violation_of_elementwise_bound'] = float(np.max(
+                np.abs(dg - gref) / (rt * np.abs(gref) + at * scale)))
+            cpu['gradient_bound'] = f'|d| <= {rt} |ref| + {at} colscale'
+            cpu['gradient_max_diff_over_colscale'] = float(np.max(
+                np.abs(dg - gref) / scale))
+
+    api = None
+    if world == 1 and not args.no_api and not sharded:
+        api = measure_api(graphs, knode, kedge, q, real, local_rank,
+                          args.gradient, n_pairs)
 
     other = None
-    if world == 1 and args.dtype == 'f64' and not args.no_f32 \
-            and not args.gradient:
+    if world == 1 and not args.no_f32 and not args.gradient and not sharded:
         other = measure_other_arithmetic(
-            'f32', graphs, knode, kedge, q, all_jobs, starts, n,
-            max(args.steps // 2, 3), args.warmup, local_rank)
+            'f32' if args.dtype == 'f64' else 'f64', graphs, knode, kedge, q,
+            all_jobs, starts, n, max(args.steps // 2, 3), args.warmup,
+            local_rank)
 
     line = {
         'metric': 'graph-pairs/sec (Gram matrix)', 'value': value,
@@ -422,21 +555,19 @@ def main():
         'higher_is_better': True, 'scaling': 'strong',
         'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {
-            'workload': f'QM7-like synthetic set ({n} molecules, seed 7165, '
-                        f'{n_pairs} pairs incl. diagonal), TensorProduct '
-                        'atom/bond microkernels, q=0.01, '
-                        + ('fp64' if args.dtype == 'f64' else 'fp32')
-                        + (', value + gradient' if args.gradient else ''),
+            'workload': workload_name + ', '
+            + ('fp64' if args.dtype == 'f64' else 'fp32')
+            + (', value + gradient' if args.gradient else ''),
             'graphs': n, 'pairs': n_pairs,
-            'parallelism': f'pair-sharded x{world}' if world > 1 else 'single',
+            'parallelism': f'pair-sharded x{world}' if sharded else 'single',
         },
         'roofline': roofline, 'compute': compute, 'lds': lds,
-        'kernels': per_kernel,
-        'cpu_baseline': cpu, 'sharded_check': sharded_check,
-        'other_arithmetic': other,
+        'step_aggregate': step_aggregate, 'kernels': per_kernel,
+        'cpu_baseline': cpu, 'api_inclusive': api,
+        'sharded_check': sharded_check, 'other_arithmetic': other,
     }
     print(json.dumps(line))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -43,13 +43,10 @@ hipcxxcode = HIPCXXCodePrinter(dict(
     type_aliases={ast.real: ast.float32, ast.integer: ast.int32},
 ))
 
-# kept under the reference's name so user code importing it keeps working
-cudacxxcode = hipcxxcode
 
 _float_literal = re.compile(
     r'(?<![\w.])((?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?)[fF]\b')
 _float_funcs = {
-    '__powf': 'pow', '__logf': 'log', '__expf': 'exp',
     'powf': 'pow', 'logf': 'log', 'expf': 'exp', 'sqrtf': 'sqrt',
     'rsqrtf': 'graphdot::rsqrt', 'fabsf': 'fabs', 'sinf': 'sin',
     'cosf': 'cos', 'tanhf': 'tanh', 'erff': 'erf', 'floorf': 'floor',
@@ -60,10 +57,21 @@ _float_func_re = re.compile(
                                      key=len, reverse=True)) + r')\s*\(')
 
 
+# the reference's fast-math intrinsics have no HIP spelling: both builds send
+# them to the type-generic overloads of device/fmath.h
+_intrinsics = {'__powf': 'graphdot::pow', '__logf': 'graphdot::log',
+               '__expf': 'graphdot::exp'}
+_intrinsic_re = re.compile(r'(?<![\w.])(__powf|__logf|__expf)\s*\(')
+
+
 def to_real_expr(expr, real='float32'):
-    """Rewrite a float32-flavoured expression for a float64 build: drop the
-    ``f`` literal suffixes and swap ``expf``-style calls for their double
-    overloads.  A float32 build returns the expression untouched."""
+    """Device spelling of a generated expression.  The grammar the
+    microkernels print is the reference's (float32 literals, ``expf``,
+    ``__powf``); the CUDA fast-math intrinsics among it are rewritten to the
+    overloads of ``device/fmath.h`` for either arithmetic, and a float64
+    build additionally drops the ``f`` literal suffixes and swaps
+    ``expf``-style calls for their double overloads."""
+    expr = _intrinsic_re.sub(lambda m: _intrinsics[m.group(1)] + '(', expr)
     if real == 'float32':
         return expr
     expr = _float_literal.sub(

@@ -1,9 +1,7 @@
 // Scalar math helpers referenced by generated microkernel expressions:
 // graphdot::ipow<N>, graphdot::ripow<N> (integer powers by repeated squaring,
 // same results as the reference's graphdot/cpp/fmath.h:8-33) and
-// graphdot::rsqrt.  The float spellings the code generator emits for a
-// --use_fast_math CUDA build (__powf, __logf, rsqrtf) map onto the gfx950
-// hardware transcendentals.
+// graphdot::rsqrt, graphdot::pow / log / exp.
 #ifndef GRAPHDOT_HIP_FMATH_H_
 #define GRAPHDOT_HIP_FMATH_H_
 #include <hip/hip_runtime.h>
@@ -28,12 +26,25 @@ template<int E, class F> __host__ __device__ constexpr inline F ripow(F base) {
 __device__ __forceinline__ float rsqrt(float x) { return __frsqrt_rn(x); }
 __device__ __forceinline__ double rsqrt(double x) { return 1.0 / sqrt(x); }
 
+// pow / log / exp in the arithmetic of their arguments.  The code generator
+// prints the reference's fast-math float spellings (__powf, __logf, __expf:
+// microkernel/_base.py, `k**c`); the backend rewrites them to these overloads
+// (codegen/sympy_printer.py::to_real_expr), so that a float build takes the
+// gfx950 hardware transcendentals (v_log_f32 / v_exp_f32 under -ffast-math)
+// and a double build stays in double.
+__device__ __forceinline__ float pow(float x, float y) { return __builtin_powf(x, y); }
+// (double: the OCML routines of the HIP math header -- the gfx950 backend has
+// no selection for the fast-math f64 llvm.pow / llvm.log intrinsics)
+__device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
+template<class A, class B> __device__ __forceinline__ auto pow(A x, B y) {
+    using T = decltype(x + y);
+    return graphdot::pow(T(x), T(y));
+}
+__device__ __forceinline__ float log(float x) { return __builtin_logf(x); }
+__device__ __forceinline__ double log(double x) { return ::log(x); }
+__device__ __forceinline__ float exp(float x) { return __builtin_expf(x); }
+__device__ __forceinline__ double exp(double x) { return ::exp(x); }
+
 }  // namespace graphdot
 
-#ifndef __powf
-#define __powf(x, y) __builtin_powf((x), (y))
-#endif
-#ifndef __logf
-#define __logf(x) __builtin_logf((x))
-#endif
 #endif

@@ -51,6 +51,11 @@ int gd_init(int device) {
     return 0;
 }
 
+int gd_set_device(int device) {
+    GD_TRY(hipSetDevice(device));
+    return 0;
+}
+
 int gd_device_props(int device, gd_device_props_t *out) {
     if (!out) return fail("gd_device_props: null argument");
     hipDeviceProp_t p;

@@ -8,6 +8,7 @@ GPU box with the repo snapshot.
 """
 import hashlib
 import os
+import re
 import subprocess
 import tempfile
 from concurrent.futures import ThreadPoolExecutor
@@ -74,8 +75,13 @@ def compile_source(source, flags=(), keep_source=True):
     out = os.path.join(CACHE_DIR, key + '.hsaco')
     if os.path.exists(out) and os.path.getsize(out) > 0:
         return out
-    src_path = os.path.join(CACHE_DIR, key + '.hip')
-    with open(src_path, 'w') as f:
+    # Every rank of a multi-GPU run compiles the same keys at once on a cold
+    # cache: the source goes to a name of its own (a shared `<key>.hip` could
+    # be truncated by one rank while another rank's hipcc reads it), the
+    # code object is checked for its kernels and only then moved into place.
+    fd, src_path = tempfile.mkstemp(suffix='.hip', prefix=key + '.',
+                                    dir=CACHE_DIR)
+    with os.fdopen(fd, 'w') as f:
         f.write(source)
     fd, tmp = tempfile.mkstemp(suffix='.hsaco', dir=CACHE_DIR)
     os.close(fd)
@@ -84,12 +90,31 @@ def compile_source(source, flags=(), keep_source=True):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         os.unlink(tmp)
+        os.unlink(src_path)
         raise CompileError(
             f'hipcc failed ({" ".join(cmd)}):\n{r.stderr[-8000:]}')
+    with open(tmp, 'rb') as f:
+        image = f.read()
+    missing = [name for name in entry_points(source)
+               if name.encode() not in image]
+    if missing:
+        os.unlink(tmp)
+        os.unlink(src_path)
+        raise CompileError(f'code object of {key} lacks kernels {missing}')
     os.replace(tmp, out)          # atomic: concurrent ranks may race here
-    if not keep_source:
+    if keep_source:
+        os.replace(src_path, os.path.join(CACHE_DIR, key + '.hip'))
+    else:
         os.unlink(src_path)
     return out
+
+
+def entry_points(source):
+    """Names of the ``extern "C" __global__`` kernels a source defines."""
+    return re.findall(
+        r'extern\s+"C"\s+__global__(?:\s+__launch_bounds__\([^)]*\))?'
+        r'(?:\s+__attribute__\(\(.*?\)\)\))*\s+void\s+(\w+)\s*\(', source,
+        flags=re.S)
 
 
 def compile_many(sources, flags=(), max_workers=None):

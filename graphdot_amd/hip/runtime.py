@@ -14,6 +14,7 @@ INCLUDE = os.path.join(os.path.dirname(os.path.dirname(_here)), 'include')
 LIB_PATH = os.path.join(CSRC, 'libgdhip.so')
 
 _lock = threading.Lock()
+_thread = threading.local()      # .device: the device current in this thread
 _lib = None
 _device = None
 
@@ -38,6 +39,7 @@ _P = ctypes.POINTER
 SIGNATURES = {
     'gd_device_count': [_P(ctypes.c_int)],
     'gd_init': [ctypes.c_int],
+    'gd_set_device': [ctypes.c_int],
     'gd_device_props': [ctypes.c_int, _P(DeviceProps)],
     'gd_device_sync': [],
     'gd_malloc': [_P(_vp), _sz],
@@ -126,8 +128,12 @@ def check(rc):
 
 
 def ensure_device(device=None):
-    """Select (once) the HIP device of this process.  Honours LOCAL_RANK for
-    one-process-per-GPU launches."""
+    """Select the HIP device of this process (honours LOCAL_RANK for
+    one-process-per-GPU launches) and make it current for the calling
+    thread.  The choice is process-wide, but hipSetDevice is per host thread:
+    a kernel evaluation from a worker thread (thread pool, joblib threading)
+    would otherwise run with device 0 current while its buffers, modules and
+    streams belong to device LOCAL_RANK."""
     global _device
     if _device is None or (device is not None and device != _device):
         if device is None:
@@ -137,8 +143,13 @@ def ensure_device(device=None):
         check(lib().gd_device_count(ctypes.byref(n)))
         if n.value <= 0:
             raise HIPError('no HIP device')
-        check(lib().gd_init(device % n.value))
-        _device = device % n.value
+        if _device != device % n.value:
+            check(lib().gd_init(device % n.value))
+            _device = device % n.value
+            _thread.device = _device
+    if getattr(_thread, 'device', None) != _device:
+        check(lib().gd_set_device(_device))
+        _thread.device = _device
     return _device
 
 

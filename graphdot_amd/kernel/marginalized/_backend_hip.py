@@ -248,11 +248,13 @@ class HIPBackend(Backend):
         return self._props
 
     def _buffer(self, name, nbytes):
+        """Grow-only pool of per-call device buffers.  A buffer that is too
+        small is *dropped from the pool*, never freed here: earlier plans and
+        the zero-copy views handed out by `device_gram` (torch tensors alias
+        them) hold references, and `DeviceBuffer.__del__` releases the
+        allocation when the last of those is gone."""
         buf = self._pool.get(name)
         if buf is None or buf.nbytes < nbytes:
-            if buf is not None:
-                runtime.synchronize()
-                buf.free()
             buf = self._pool[name] = runtime.DeviceBuffer(
                 max(int(nbytes * 1.25), 256))
         return buf

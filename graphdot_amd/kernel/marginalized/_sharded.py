@@ -111,6 +111,178 @@ class ShardPlan:
         return out[:, :, 0] if n_cols == 1 else out
 
 
+def cuda_collective(group=None):
+    """Does the process group run its collectives on device memory through
+    RCCL?  Decided from the group's backend map (``cpu:gloo,cuda:nccl`` for a
+    composite group), not from string equality with "nccl"."""
+    import torch.distributed as dist
+    try:
+        cfg = str(dist.get_backend_config(group))
+    except Exception:                                  # older torch
+        cfg = str(dist.get_backend(group))
+    if ':' not in cfg:
+        return cfg == 'nccl'
+    parts = dict(item.split(':', 1) for item in cfg.split(',') if ':' in item)
+    return parts.get('cuda') == 'nccl'
+
+
+class ShardedStep:
+    """One rank's device-resident evaluation of a pair-sharded Gram matrix
+    (+ gradient planes): the single code path of ``bench.py --gpus N`` and of
+    ``distributed_backend()``.
+
+    * the solver kernels write this rank's packed slab
+      ``[capacity values | capacity * n_grad gradient entries]`` straight into
+      the tensor the collective reads (``HIPBackend.prepare(gramian_ptr=)``);
+    * one ``all_gather_into_tensor`` of equal-capacity slabs (RCCL over xGMI
+      when the group's CUDA backend is nccl; staged through host memory for a
+      gloo group -- CPU-only development boxes and tests);
+    * one gather + scatter on the device (``ShardPlan.reassembly_index``)
+      turns the gathered slabs into the column-major ``(nX, nY[, 1 + n_grad])``
+      result, mirrored entries included.
+
+    `enqueue()` issues all of that without a host synchronisation: every
+    solver stream waits (device-side event) for the previous step's join, the
+    null stream -- on which torch runs the collective and the reassembly --
+    waits for every solver stream.  The result stays on the device
+    (`values` / `gradient` tensors); `download()` copies it out once.
+    """
+
+    def __init__(self, backend, graphs, node_kernel, edge_kernel, p, q, eps,
+                 ftol, gtol, jobs, starts, nX, nY, nJ, traits, group=None,
+                 timer=None, shard_plan=None):
+        import torch
+        import torch.distributed as dist
+        from ...hip import runtime
+        self.backend, self.group = backend, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.on_device = cuda_collective(group)
+        device = runtime.ensure_device(backend.device)
+        # the tensors live on the device the *backend* runs on, whatever
+        # torch's current device is
+        self.device = torch.device('cuda', device)
+        self.nX, self.nY = int(nX), int(nY)
+        self.n_grad = int(nJ) if traits.eval_gradient is True else 0
+        n_cols = self.n_cols = 1 + self.n_grad
+        jobs = np.ascontiguousarray(jobs)
+        dgraphs = [backend._register_graph(g) for g in graphs]
+        if shard_plan is None:
+            n_node = np.array([g.n_node for g in dgraphs], np.int64)
+            n_nz = np.array([g.n_nz for g in dgraphs], np.int64)
+            shard_plan = ShardPlan(
+                jobs['i'].astype(np.int64), jobs['j'].astype(np.int64),
+                n_node, n_nz, self.nX, self.nY, bool(traits.symmetric),
+                self.rank, self.world)
+        self.shard = sp = shard_plan
+        cap = self.capacity = sp.capacity
+        rs = np.dtype(backend.real)
+        self.tdtype = torch.float32 if rs == np.float32 else torch.float64
+        with torch.cuda.device(self.device):
+            self.local_out = torch.zeros(max(cap * n_cols, 1),
+                                         dtype=self.tdtype, device=self.device)
+            self.gathered = torch.empty(self.world * max(cap * n_cols, 1),
+                                        dtype=self.tdtype, device=self.device)
+            self.result = torch.zeros(n_cols * self.nX * self.nY,
+                                      dtype=self.tdtype, device=self.device)
+            src, dst = sp.reassembly_index(self.n_grad)
+            self.t_src = torch.from_numpy(src).to(self.device)
+            self.t_dst = torch.from_numpy(dst).to(self.device)
+            torch.cuda.synchronize(self.device)
+        local_jobs = jobs[sp.local]
+        local_jobs.flags.writeable = False         # recognised by identity
+        self.local_jobs = local_jobs
+        self._args = (graphs, jobs, starts, nX, nY, nJ, traits)
+        self.streams, self._done = [], []
+        self._join = runtime.Event()
+        self._first = True
+        self.bind(node_kernel, edge_kernel, p, q, eps, ftol, gtol, timer)
+
+    def bind(self, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
+             timer=None):
+        """(Re)build the launch plan for the given hyperparameters: same
+        graphs, jobs, buffers and streams, new kernel arguments -- what a
+        repeated evaluation in a training loop costs."""
+        from ...hip import runtime
+        graphs, _, starts, nX, nY, nJ, traits = self._args
+        rs = np.dtype(self.backend.real)
+        self.plan = self.backend.prepare(
+            graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
+            self.local_jobs, starts, nX, nY, nJ, traits, timer, packed=True,
+            gramian_ptr=self.local_out.data_ptr(),
+            gradient_ptr=self.local_out.data_ptr()
+            + self.capacity * rs.itemsize)
+        while len(self.streams) < len(self.plan.launches):
+            self.streams.append(runtime.Stream())
+            self._done.append(runtime.Event())
+
+    def enqueue(self, events=None, serial=False):
+        """One step: solver launches, all-gather, reassembly -- all
+        asynchronous.  `events[k] = (start, stop)` are recorded around
+        launch k on the stream it runs on (bench.py's per-kernel timing)."""
+        import torch
+        import torch.distributed as dist
+        from ...hip import runtime
+        plan = self.plan
+        for k, L in enumerate(plan.launches):
+            s = None if serial else self.streams[k]
+            if s is not None and not self._first:
+                s.wait_event(self._join)
+            if events is not None:
+                events[k][0].record(s.h if s else None)
+            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                           stream=s.h if s else None,
+                           dynamic_lds=L['dynamic_lds'])
+            if events is not None:
+                events[k][1].record(s.h if s else None)
+            if s is not None:
+                self._done[k].record(s.h)
+                runtime.null_stream_wait_event(self._done[k])
+        with torch.cuda.device(self.device):
+            if self.on_device:
+                dist.all_gather_into_tensor(self.gathered, self.local_out,
+                                            group=self.group)
+            else:
+                h = self.local_out.cpu()           # waits for the solvers
+                g = torch.empty(self.world * h.numel(), dtype=h.dtype)
+                dist.all_gather_into_tensor(g, h, group=self.group)
+                self.gathered.copy_(g)
+            self.result.index_copy_(
+                0, self.t_dst, self.gathered.index_select(0, self.t_src))
+        self._join.record()
+        self._first = False
+
+    def synchronize(self):
+        import torch
+        from ...hip import runtime
+        runtime.synchronize()
+        torch.cuda.synchronize(self.device)
+
+    @property
+    def values(self):
+        """(nX, nY) column-major device tensor view of the matrix."""
+        return self.result[:self.nX * self.nY].view(self.nY, self.nX).t()
+
+    @property
+    def gradient(self):
+        """(nX, nY, n_grad) device view of the gradient planes."""
+        n = self.nX * self.nY
+        return self.result[n:].view(self.n_grad, self.nY, self.nX).permute(
+            2, 1, 0)
+
+    def download(self, gramian=None, gradient=None):
+        """Copy the reassembled result to the host (one D2H), into the
+        caller's flat column-major arrays when given."""
+        self.synchronize()
+        host = self.result.cpu().numpy()
+        n = self.nX * self.nY
+        if gramian is not None:
+            gramian[:] = host[:n].reshape(np.shape(gramian))
+        if gradient is not None and self.n_grad:
+            gradient[:] = host[n:].reshape(np.shape(gradient))
+        return host[:n], host[n:]
+
+
 def distributed_backend(**kwargs):
     """A HIPBackend that shards every graph-level evaluation over the ranks
     of the initialised ``torch.distributed`` process group (one process per
@@ -121,25 +293,29 @@ def distributed_backend(**kwargs):
         K = kernel(graphs)          # every rank gets the full matrix
 
     Pairs are independent, so each rank solves its cost-balanced share of the
-    job list into a packed slab (`ShardPlan`), one all-gather of equal-sized
-    slabs follows (RCCL for the "nccl" backend, host memory for "gloo"), and
-    every rank scatters the gathered values into the caller's arrays.  Nodal
-    and diagonal evaluations, and runs without a process group, take the
-    single-GPU path.  Keyword arguments as for HIPBackend."""
+    job list into a packed slab (`ShardPlan`) that is already the input of the
+    all-gather (RCCL for a group whose CUDA backend is nccl, host memory for
+    gloo), the gathered slabs are scattered into the matrix on the device and
+    downloaded once into the caller's arrays (`ShardedStep`, the code path of
+    ``bench.py --gpus N``).  Nodal and diagonal evaluations, and runs without
+    a process group, take the single-GPU path.  ``shard_single_rank=True``
+    routes a one-rank group through the sharded path too (tests).  Other
+    keyword arguments as for HIPBackend."""
     from ._backend_hip import HIPBackend
 
     class DistributedHIPBackend(HIPBackend):
 
-        def __init__(self, **kw):
+        def __init__(self, shard_single_rank=False, **kw):
             super().__init__(**kw)
+            self.shard_single_rank = shard_single_rank
             self._shard_plans = {}
+            self._steps = {}      # (shard plan, nJ, traits) -> ShardedStep
 
-        @staticmethod
-        def shards_over_ranks():
+        def shards_over_ranks(self):
             """True when a process group with more than one rank is up."""
             import torch.distributed as dist
             return (dist.is_available() and dist.is_initialized()
-                    and dist.get_world_size() > 1)
+                    and (dist.get_world_size() > 1 or self.shard_single_rank))
 
         def _shard_plan(self, dgraphs, jobs, nX, nY, symmetric, rank, world):
             key = (tuple(map(id, dgraphs)), id(jobs) if not
@@ -154,62 +330,43 @@ def distributed_backend(**kwargs):
                 sp = ShardPlan(jobs['i'].astype(np.int64),
                                jobs['j'].astype(np.int64), n_node, n_nz,
                                nX, nY, symmetric, rank, world)
-                hit = self._shard_plans[key] = (sp, jobs, list(dgraphs), {})
+                hit = self._shard_plans[key] = (sp, jobs, list(dgraphs))
             return hit
 
         def __call__(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol,
                      gtol, jobs, starts, gramian, gradient, nX, nY, nJ,
                      traits, timer):
-            import torch
-            import torch.distributed as dist
             graph_level = (traits.nodal is False and not traits.diagonal)
             if not (self.shards_over_ranks() and graph_level):
                 return super().__call__(
                     graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
                     jobs, starts, gramian, gradient, nX, nY, nJ, traits,
                     timer)
+            import torch.distributed as dist
             rank, world = dist.get_rank(), dist.get_world_size()
             jobs = np.ascontiguousarray(jobs)
             dgraphs = [self._register_graph(g) for g in graphs]
-            sp, _, _, index_cache = self._shard_plan(
+            sp, _, _ = self._shard_plan(
                 dgraphs, jobs, int(nX), int(nY), bool(traits.symmetric), rank,
                 world)
-            n_grad = int(nJ) if traits.eval_gradient is True else 0
-            n_cols = 1 + n_grad
+            key = (id(sp), int(nJ), traits)
+            step = self._steps.get(key)
+            if step is None:
+                if len(self._steps) > 4:
+                    self._steps.clear()
+                step = self._steps[key] = ShardedStep(
+                    self, graphs, node_kernel, edge_kernel, p, q, eps, ftol,
+                    gtol, jobs, starts, nX, nY, nJ, traits, timer=timer,
+                    shard_plan=sp)
+            else:
+                step.bind(node_kernel, edge_kernel, p, q, eps, ftol, gtol,
+                          timer)
             timer.tic('GPU kernel execution')
-            local_jobs = jobs[sp.local]
-            local_jobs.flags.writeable = True      # fresh array: by checksum
-            plan = self.prepare(graphs, node_kernel, edge_kernel, p, q, eps,
-                                ftol, gtol, local_jobs, starts, nX, nY, nJ,
-                                traits, timer, packed=True)
-            self.launch(plan)
-            values, grads = self.collect(plan)
+            step.enqueue()
+            step.synchronize()
             timer.toc('GPU kernel execution')
-
-            # slab of this rank: [capacity values | capacity * n_grad entries]
-            cap = sp.capacity
-            slab = np.zeros(cap * n_cols, dtype=values.dtype)
-            slab[:len(values)] = values
-            if n_grad:
-                slab[cap:cap + len(grads)] = grads
-            on_device = dist.get_backend() == 'nccl'
-            t_slab = torch.from_numpy(slab)
-            if on_device:
-                t_slab = t_slab.cuda()
-            gathered = torch.empty(world * len(slab), dtype=t_slab.dtype,
-                                   device=t_slab.device)
-            dist.all_gather_into_tensor(gathered, t_slab)
-            gathered = gathered.cpu().numpy()
-
-            if n_grad not in index_cache:
-                index_cache[n_grad] = sp.reassembly_index(n_grad)
-            src, dst = index_cache[n_grad]
-            n_out = int(nX) * int(nY)
-            gramian[:] = 0
-            gramian[dst[dst < n_out]] = gathered[src[dst < n_out]]
-            if n_grad:
-                sel = dst >= n_out
-                gradient[:] = 0
-                gradient[dst[sel] - n_out] = gathered[src[sel]]
+            step.download(gramian,
+                          gradient if traits.eval_gradient is True else None)
+            self.last_step = step
 
     return DistributedHIPBackend(**kwargs)

@@ -46,6 +46,10 @@ typedef struct {
 /* ---- context (ref: graphdot/cuda/__init__.py:3-7, pycuda.autoinit) ------ */
 int gd_device_count(int *count);
 int gd_init(int device);                       /* hipSetDevice + warm-up    */
+int gd_set_device(int device);                 /* make `device` current in the
+                                                  calling host thread (the HIP
+                                                  current device is per thread;
+                                                  PyCUDA: Context.push)       */
 int gd_device_props(int device, gd_device_props_t *out);
 int gd_device_sync(void);                      /* ref: ctx.synchronize(), _backend_cuda.py:367 */
 const char *gd_last_error(void);

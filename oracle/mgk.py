@@ -461,3 +461,25 @@ class TensorProductBatch:
         if rc:
             raise MemoryError('oracle allocation failed')
         return out, iters
+
+    def run_gradient(self, ji, jj, p=1.0, q=0.01, lmin=0, real='f64',
+                     omp=False):
+        """Value and analytic Jacobian per job (``mgk_gram_tp_grad_*``:
+        compute_duo + derivative).  Columns: [p, q, node hyperparameters...,
+        edge hyperparameters...] -- all of them, the caller masks."""
+        ji = np.ascontiguousarray(ji, dtype=np.int32)
+        jj = np.ascontiguousarray(jj, dtype=np.int32)
+        nJ = 2 + len(self.vtype) + len(self.etype)
+        out = np.zeros(len(ji))
+        grad = np.zeros((len(ji), nJ))
+        iters = np.zeros(len(ji), dtype=np.int32)
+        f = getattr(lib(omp), f'mgk_gram_tp_grad_{real}')
+        f.restype = ctypes.c_int
+        rc = f(len(ji), _ptr(ji), _ptr(jj), self.arr, len(self.vtype),
+               _ptr(self.vtype), _ptr(self.vparam), len(self.etype),
+               _ptr(self.etype), _ptr(self.eparam), ctypes.c_double(p),
+               ctypes.c_double(q), int(lmin), _ptr(out), _ptr(grad),
+               _ptr(iters))
+        if rc:
+            raise MemoryError('oracle allocation failed')
+        return out, grad, iters

@@ -68,3 +68,77 @@ def test_two_ranks_through_the_kernel_api(tmp_path):
     r0, r1 = (np.load(tmp_path / f'rank{r}.npz') for r in range(2))
     assert float(r0['lml']) == float(r1['lml']) == pytest.approx(lml, rel=1e-9)
     assert np.allclose(r0['glml'], glml, rtol=1e-7)
+
+
+def _rccl_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=rank, world_size=world,
+                            device_id=torch.device('cuda', 0))
+    import cases
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._sharded import (
+        distributed_backend, cuda_collective)
+    assert cuda_collective()
+    G = cases.config3_graphs(40, seed=6)
+    knode, kedge, q = cases.config3_kernels()
+    backend = distributed_backend(device=0, shard_single_rank=True)
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    K = k(G)
+    assert backend.last_step.on_device      # RCCL all-gather on device memory
+    K2, dK = k(G, eval_gradient=True)
+    # a second evaluation with other hyperparameters re-binds the cached step
+    k2 = k.clone_with_theta(k.theta + 0.1)
+    K3 = k2(G)
+    Kxy = k(G[:12], G[12:])
+    np.savez(os.path.join(tmp, 'rccl.npz'), K=K, K2=K2, dK=dK, Kxy=Kxy, K3=K3,
+             theta=k2.theta)
+    dist.destroy_process_group()
+
+
+def test_rccl_process_group_of_one_rank(tmp_path):
+    """The device-resident sharded step (`ShardedStep`: kernels write the
+    packed slab into the all-gather input, RCCL `all_gather_into_tensor` on
+    device memory, reassembly on the device, one download) on a "nccl"
+    process group of size 1 -- everything of the N-GPU path except a second
+    rank -- reproduces the single-GPU results bit for bit."""
+    import torch.multiprocessing as mp
+    import cases
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    port = 29950 + os.getpid() % 40
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / 'rccl.npz')
+    G = cases.config3_graphs(40, seed=6)
+    knode, kedge, q = cases.config3_kernels()
+    k = MarginalizedGraphKernel(knode, kedge, q=q)
+    K2, dK = k(G, eval_gradient=True)
+    assert np.array_equal(r['K'], k(G))
+    assert np.array_equal(r['K2'], K2) and np.array_equal(r['dK'], dK)
+    assert np.array_equal(r['Kxy'], k(G[:12], G[12:]))
+    k.theta = r['theta']
+    assert np.array_equal(r['K3'], k(G))
+
+
+def test_bench_sharded_step_single_rank():
+    """bench.py's multi-GPU step on one rank (`--sharded`: nccl group of
+    size 1): the JSON line carries the oracle check of the reassembled
+    matrix."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_PORT=str(29990 + os.getpid() % 9),
+               MASTER_ADDR='127.0.0.1')
+    r = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--sharded',
+         '--graphs', '150', '--steps', '3', '--warmup', '1',
+         '--no-cpu-baseline', '--dtype', 'f32', '--gradient'],
+        capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    chk = line['sharded_check']
+    assert chk['collective'] == 'nccl(RCCL)' and chk['symmetric']
+    assert chk['max_rel_diff_vs_oracle'] < 1e-5
+    assert line['config']['parallelism'] == 'pair-sharded x1'

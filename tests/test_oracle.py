@@ -138,3 +138,30 @@ def test_batched_tensorproduct_path_matches_generic():
     got32, it32 = batch.run(i, j, q=q, real='f32')
     assert np.allclose(got32, ref[i, j], rtol=1e-5)
     assert it32.min() >= 1 and it32.max() < 100
+
+
+def test_c_gradient_restatement_vs_dense_oracle():
+    """`mgk_gram_tp_grad_f64` (compute_duo + derivative in C, the full-size
+    gradient checker and CPU baseline of config 5) against the dense fp64
+    statement `pair_value(eval_gradient=True)`: both solve the same two
+    systems, the C one with the device's stopping rule (1e-10 * 2N)."""
+    import cases
+    for graphs, kernels in ((cases.config3_graphs(24, seed=3),
+                             cases.config3_kernels()),
+                            (cases.config2_graphs(6, nmin=6, nmax=12, seed=1),
+                             cases.config2b_kernels()),
+                            (cases.config2_graphs(6, nmin=6, nmax=12, seed=2),
+                             cases.config2a_kernels())):
+        knode, kedge, q = kernels
+        batch = mgk.TensorProductBatch(graphs, knode, kedge)
+        n = len(graphs)
+        ii, jj = np.triu_indices(n)
+        ii, jj = ii[::5], jj[::5]
+        v, g, it = batch.run_gradient(ii, jj, q=q, real='f64')
+        for t, (a, b) in enumerate(zip(ii, jj)):
+            R, J = mgk.pair_value(graphs[a], graphs[b], knode, kedge, q=q,
+                                  eval_gradient=True, tol=1e-13)
+            assert v[t] == pytest.approx(R, rel=1e-7)
+            assert np.allclose(g[t], J, rtol=1e-6, atol=1e-7 * np.abs(J).max())
+        v32, g32, _ = batch.run_gradient(ii, jj, q=q, real='f32')
+        assert np.allclose(v32, v, rtol=2e-5)
