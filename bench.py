@@ -566,7 +566,15 @@ def main():
         'cpu_baseline': cpu, 'api_inclusive': api,
         'sharded_check': sharded_check, 'other_arithmetic': other,
     }
-    print(json.dumps(line))
+    # RCCL announces itself on C stdio ("Librccl path : ..."), which a pipe
+    # would deliver after Python's buffer: flush it so that the JSON line is
+    # the last line of stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(line), flush=True)
     if sharded:
         dist.destroy_process_group()
 

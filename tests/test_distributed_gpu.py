@@ -137,7 +137,7 @@ def test_bench_sharded_step_single_rank():
          '--no-cpu-baseline', '--dtype', 'f32', '--gradient'],
         capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line = json.loads(r.stdout.strip().splitlines()[-1])   # JSON comes last
     chk = line['sharded_check']
     assert chk['collective'] == 'nccl(RCCL)' and chk['symmetric']
     assert chk['max_rel_diff_vs_oracle'] < 1e-5
