@@ -109,35 +109,17 @@ def algorithmic_lds_reals(n_node, n_nz, ji, jj, iters):
 
 
 class LocalStep:
-    """One rank, no collective: the plan's launches, one stream per solver
-    variant, ordered against the previous step by device-side events."""
+    """One rank, no collective: the plan's launches through a `LaunchSet`
+    (table kernel on the null stream, one stream per solver variant, ordered
+    against the previous step by device-side events)."""
 
     def __init__(self, backend, plan):
         from graphdot_amd.hip import runtime
-        self.rt = runtime
-        self.plan = plan
-        self.streams = [runtime.Stream() for _ in plan.launches]
-        self.done = [runtime.Event() for _ in plan.launches]
-        self.join = runtime.Event()
-        self.first = True
+        from graphdot_amd.kernel.marginalized._backend_hip import LaunchSet
+        self.rt, self.plan, self.set = runtime, plan, LaunchSet()
 
     def enqueue(self, events=None, serial=False):
-        rt = self.rt
-        for k, L in enumerate(self.plan.launches):
-            s = None if serial else self.streams[k]
-            if s is not None and not self.first:
-                s.wait_event(self.join)
-            if events is not None:
-                events[k][0].record(s.h if s else None)
-            rt.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                      stream=s.h if s else None, dynamic_lds=L['dynamic_lds'])
-            if events is not None:
-                events[k][1].record(s.h if s else None)
-            if s is not None:
-                self.done[k].record(s.h)
-                rt.null_stream_wait_event(self.done[k])
-        self.join.record()
-        self.first = False
+        self.set.enqueue(self.plan, events, serial)
 
     def synchronize(self):
         self.rt.synchronize()

@@ -1,0 +1,678 @@
+// Owner-computes pair solver for MI355X (gfx950, wave64): the product-graph
+// mat-vec of the marginalized graph kernel in ONE stage.
+//
+// Same system, iteration and stopping rules as pair_solver (mgk_solver.h;
+// reference: graphdot/cpp/marginalized_kernel.h:189-997,
+// graphdot/kernel/marginalized/template.cu:57-474), different work split.
+// pair_solver cuts the Kronecker sum of a row (i1, i2),
+//     (Wp)[i1,i2] = sum_{a in adj(i1)} sum_{b in adj(i2)} E[a,b] p[j1(a), j2(b)],
+// into tasks (a, i2) of deg2(i2) terms so that the 64 tasks of a wave
+// instruction have one trip count, and pays for it with a second stage: the
+// partial sums U[a, i2] go through LDS and every row re-reads and masks its
+// deg1(i1) entries (8 VALU + 4 LDS reads per row and iteration, a third of
+// the iteration's instructions, and the bank conflicts of those reads).
+//
+// Here the lane that owns row (i1, i2) computes the whole double sum,
+// deg1(i1) * deg2(i2) terms, and the trip counts are made uniform by the
+// ORDER of the rows instead: rows are dealt to lanes sorted by descending
+// deg1(i1) * deg2(i2), so the 64 rows of a wave instruction share (nearly)
+// one product and the wave-uniform maximum is that of its first row.  Nodes
+// are stored by descending degree (packer), so the rows of one degree pair
+// (d1, d2) form a rectangle of the (i1, i2) grid; the order of the
+// (DMAX + 1)^2 rectangles by product is a compile-time table, their sizes
+// come from two degree histograms (ballots), and the sorted position of a row
+// is  off[d1][d2] + (i1 - start1[d1]) * cnt2[d2] + (i2 - start2[d2]).
+//
+// Per CG iteration a lane then does: one LDS gather + one FMA per nonzero
+// slot, one lane-contiguous LDS store of the finished row sum per row batch
+// (the batch a slot belongs to is only known at run time, the row registers
+// are indexed at compile time: the sums take a lane-private round trip
+// through LDS, M0-relative stores/loads without address registers), the
+// fused vector updates, two wave reductions and one scattered store of p per
+// row.  No second stage, no U, no masks, one barrier less.  Padding is
+// higher than pair_solver's (24 slots against 17 on the QM7-like set, ideal
+// 15), the instruction count per iteration a third lower.
+//
+// Graphs whose largest degree exceeds DMAX take pair_solver.
+//
+// Microkernel tables (TAB): when the labels of a call fall into few classes
+// (GraphArena.classes: 19 atom x 3 bond classes on the QM7-like set) one tiny
+// launch per evaluation (`fill_tables`) evaluates the node and edge
+// microkernels -- and their Jacobians for the gradient solver -- once per
+// pair of classes into a global table (a few KB, cache resident), and the
+// pair solvers look the values up by the u8 class ids that are staged with
+// the graph images: nnz1 * nnz2 + n1 * n2 table reads per pair instead of as
+// many evaluations of the generated code.  (The reference evaluates the edge
+// kernel once per nonzero per CG iteration, marginalized_kernel.h:299-300,346.)
+#ifndef GRAPHDOT_HIP_MGK_OC_H_
+#define GRAPHDOT_HIP_MGK_OC_H_
+#include "mgk_solver.h"
+
+namespace graphdot {
+namespace mgk {
+
+// (d1, d2) for d1, d2 in [0, DMAX], sorted by descending d1 * d2 (ties in
+// row-major order): the order in which the degree-pair rectangles are laid
+// out in the sorted row space.
+template<int DMAX> struct class_order {
+    constexpr static int NC = DMAX + 1, NCP = NC * NC;
+    unsigned char d1[NCP], d2[NCP];
+    constexpr class_order() : d1{}, d2{} {
+        int n = 0;
+        for (int p = DMAX * DMAX; p >= 0; --p)
+            for (int a = 0; a <= DMAX; ++a)
+                for (int b = 0; b <= DMAX; ++b)
+                    if (a * b == p) {
+                        d1[n] = (unsigned char)a;
+                        d2[n] = (unsigned char)b;
+                        ++n;
+                    }
+    }
+};
+
+// Table layout (reals): [kv: nv^2][ke: ne^2], and for C == 2 behind them
+// [dkv_j: nv^2 for each node hyperparameter j][dke_j: ne^2 for each edge one].
+// The representatives of the edge classes carry weight 1: tables hold the
+// label part, weights are applied per nonzero.
+template<class real, int C, class Graph, class NodeK, class EdgeK, class PStart>
+__device__ __forceinline__ void fill_tables(params_t<real, Graph, NodeK, EdgeK, PStart> const &prm) {
+    using node_t = typename Graph::node_t;
+    using edge_t = typename Graph::edge_t;
+    node_t const *const vr = reinterpret_cast<node_t const *>(prm.arena + prm.vrep);
+    edge_t const *const er = reinterpret_cast<edge_t const *>(prm.arena + prm.erep);
+    const unsigned nv = prm.n_vclass, ne = prm.n_eclass;
+    const unsigned nvv = nv * nv, nee = ne * ne;
+    real *const kv = prm.tables, *const ke = kv + nvv;
+    real *const dkv = ke + nee, *const dke = dkv + (size_t)NodeK::jac_dims * nvv;
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < nvv + nee; k += gridDim.x * blockDim.x) {
+        if (k < nvv) {
+            const unsigned c1 = k / nv, c2 = k - c1 * nv;
+            kv[k] = real(prm.node_kernel(vr[c1], vr[c2]));
+            if constexpr (C == 2) {
+                auto d = prm.node_kernel._j_a_c_o_b_i_a_n_(vr[c1], vr[c2]);
+#pragma unroll
+                for (int j = 0; j < NodeK::jac_dims; ++j) dkv[(size_t)j * nvv + k] = real(d[j]);
+            }
+        } else {
+            const unsigned e = k - nvv, c1 = e / ne, c2 = e - c1 * ne;
+            ke[e] = real(prm.edge_kernel(er[c1], er[c2]));
+            if constexpr (C == 2) {
+                auto d = prm.edge_kernel._j_a_c_o_b_i_a_n_(er[c1], er[c2]);
+#pragma unroll
+                for (int j = 0; j < EdgeK::jac_dims; ++j) dke[(size_t)j * nee + e] = real(d[j]);
+            }
+        }
+    }
+}
+
+template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB, class Graph, class NodeK, class EdgeK, class PStart>
+struct oc_solver {
+    using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
+    using node_t = typename Graph::node_t;
+    using edge_t = typename Graph::edge_t;
+    constexpr static int T = 64 * W;            // threads per pair (= per workgroup)
+    constexpr static int NR = R * T;            // row capacity
+    constexpr static int NC = DMAX + 1;         // degree classes 0..DMAX
+    constexpr static int NCP = NC * NC;         // degree-pair rectangles
+    constexpr static int NTAB = ((NCP + 63) / 64) * 64;
+    constexpr static int NM = (S + 31) / 32;    // 32-bit flush-mask words
+    constexpr static int SETUP_CHUNK = 4;
+#ifndef GD_OC_GCH
+#define GD_OC_GCH 8
+#endif
+    constexpr static int GCH = GD_OC_GCH;       // gathers in flight
+    constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4;
+    constexpr static int n_jac = PStart::jac_dims + 1 + NodeK::jac_dims + EdgeK::jac_dims;
+    constexpr static int off_q = PStart::jac_dims;
+    constexpr static int off_v = off_q + 1;
+    constexpr static int off_e = off_v + NodeK::jac_dims;
+    constexpr static class_order<DMAX> ORD{};
+
+    struct lds_t {
+        real red[2 * W];
+        int tab_off[NTAB];      // sorted-row offset of rectangle d1 * NC + d2
+        int tab_cls[64];        // [0..NC) start1, [16..) cnt2, [32..) start2
+    };
+
+    __device__ static __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+    struct row_t {        // the row a lane is filling slots for
+        int i1, i2, rs1, rs2, d1, d2, prod;
+    };
+
+    __device__ static __forceinline__ void run(P const &prm, lds_t &lds, real *dyn) {
+        const int lane = wave::laneid();
+        const int tid = (W == 1) ? lane : (int)threadIdx.x;
+        const int wv = (W == 1) ? 0 : uni((int)(threadIdx.x / 64));
+        // dynamic LDS: [p: u_capacity * C reals][Y: NR * C reals][rowmap: NR u32][G1][G2]
+        real *const lp = dyn;
+        real *const lY = lp + (size_t)prm.u_capacity * C;
+        unsigned *const rowmap = reinterpret_cast<unsigned *>(lY + (size_t)NR * C);
+        char *const lG1 = reinterpret_cast<char *>(rowmap + NR);
+        char *const lG2 = lG1 + prm.g_capacity;
+        real *const red = lds.red;
+        const unsigned lY_off = uni((int)lds_offset(lY));
+        graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
+        const int dump = (int)prm.u_capacity - 1;   // cell that dead rows publish to
+
+        for (unsigned t = blockIdx.x; t < prm.n_launch_jobs; t += gridDim.x) {
+            const job_t job = prm.jobs[t];
+            const graph_header_t h1 = headers[job.i], h2 = headers[job.j];
+            const int n1 = h1.n_node, n2 = h2.n_node, N = n1 * n2;
+            const int ldp = n2 | 1;            // odd row stride of p: banks spread
+            const real q = prm.q, q0 = prm.q0;
+            const real inv1q2 = real(1) / ((real(1) - q) * (real(1) - q));
+            const real bscale = q * q / (q0 * q0);
+            // label-class section in front of each image (_devicegraph.class_bytes):
+            // u8 node classes [pad4(n)], u8 edge classes [pad4(nnz)], 16-aligned
+            const unsigned nzpad1 = ((unsigned)n1 + 3u) & ~3u, nzpad2 = ((unsigned)n2 + 3u) & ~3u;
+            const unsigned cb1 = TAB ? (nzpad1 + (((unsigned)h1.n_nz + 3u) & ~3u) + 15u) & ~15u : 0u;
+            const unsigned cb2 = TAB ? (nzpad2 + (((unsigned)h2.n_nz + 3u) & ~3u) + 15u) & ~15u : 0u;
+
+            // ---- stage both graph images in LDS: one global round trip --------
+            job_sync<W>();  // previous pair is done with the LDS regions
+            {
+                typedef unsigned v4 __attribute__((ext_vector_type(4)));
+                const unsigned w1 = (h1.perm + 2u * n1 - h1.degree + cb1 + 15u) / 16u;
+                const unsigned w2 = (h2.perm + 2u * n2 - h2.degree + cb2 + 15u) / 16u;
+                const v4 *const s1 = reinterpret_cast<const v4 *>(prm.arena + h1.degree - cb1);
+                const v4 *const s2 = reinterpret_cast<const v4 *>(prm.arena + h2.degree - cb2);
+                v4 *const d1 = reinterpret_cast<v4 *>(lG1);
+                v4 *const d2 = reinterpret_cast<v4 *>(lG2);
+                constexpr int K = 2;
+                const unsigned wmax = w1 > w2 ? w1 : w2;
+#pragma nounroll
+                for (unsigned base = 0; base < wmax; base += K * T) {
+                    v4 v1[K], v2[K];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const unsigned w = base + k * T + tid;
+                        v1[k] = w < w1 ? s1[w] : v4{0u, 0u, 0u, 0u};
+                        v2[k] = w < w2 ? s2[w] : v4{0u, 0u, 0u, 0u};
+                    }
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        const unsigned w = base + k * T + tid;
+                        if (w < w1) d1[w] = v1[k];
+                        if (w < w2) d2[w] = v2[k];
+                    }
+                }
+                // lane-private row sums: rows of batches that own no slots read 0
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) lY[(k * T + tid) * C + c] = 0;
+            }
+            const Graph g1(lG1 + cb1 - h1.degree, h1);
+            const Graph g2(lG2 + cb2 - h2.degree, h2);
+            std::uint8_t const *const ncls1 = reinterpret_cast<std::uint8_t const *>(lG1);
+            std::uint8_t const *const ncls2 = reinterpret_cast<std::uint8_t const *>(lG2);
+            std::uint8_t const *const ecls1 = ncls1 + nzpad1;
+            std::uint8_t const *const ecls2 = ncls2 + nzpad2;
+            const unsigned nvc = prm.n_vclass, nec = prm.n_eclass;
+            real const *const kvtab = prm.tables;
+            real const *const ketab = kvtab + nvc * nvc;
+            real const *const dkvtab = ketab + nec * nec;
+            real const *const dketab = dkvtab + (size_t)NodeK::jac_dims * nvc * nvc;
+            // microkernel value of a node pair: table or direct
+            auto kappa_v = [&](int i1, int i2, node_t const &v1, node_t const &v2) -> real {
+                if constexpr (TAB) return at32(kvtab, __umul24((unsigned)ncls1[i1], nvc) + ncls2[i2]);
+                else return real(prm.node_kernel(v1, v2));
+            };
+            std::uint16_t const *const lrp1 = g1.rowptr;
+            std::uint16_t const *const lrp2 = g2.rowptr;
+            job_sync<W>();
+
+            // ---- degree histograms -> offsets of the degree-pair rectangles ---
+            // (every wave computes the same wave-uniform numbers)
+            {
+                int cnt1[NC], cnt2[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) cnt1[c] = cnt2[c] = 0;
+#pragma nounroll
+                for (int base = 0; base < n1; base += 64) {
+                    const int i = base + lane;
+                    const int d = i < n1 ? (int)lrp1[i + 1] - (int)lrp1[i] : -1;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        cnt1[c] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d == c));
+                }
+#pragma nounroll
+                for (int base = 0; base < n2; base += 64) {
+                    const int i = base + lane;
+                    const int d = i < n2 ? (int)lrp2[i + 1] - (int)lrp2[i] : -1;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        cnt2[c] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d == c));
+                }
+                // nodes are stored by descending degree: class d starts after
+                // all classes of higher degree
+                int vcls = 0;
+                int voff[NTAB / 64];
+#pragma unroll
+                for (int w = 0; w < NTAB / 64; ++w) voff[w] = 0;
+                fill_classes(std::make_integer_sequence<int, NC>{}, vcls, cnt1, cnt2);
+                fill_offsets(std::make_integer_sequence<int, NCP>{}, voff, cnt1, cnt2);
+                if (wv == 0) {
+                    lds.tab_cls[lane] = vcls;
+#pragma unroll
+                    for (int w = 0; w < NTAB / 64; ++w) lds.tab_off[64 * w + lane] = voff[w];
+                }
+            }
+            job_sync<W>();
+
+            // ---- sorted position of every row: rowmap[position] = (i1, i2) ----
+            {
+                divmod_walk row(tid, T, n2);
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const bool ok = k * T + tid < N;
+                    const int i1 = ok ? row.hi : 0, i2 = ok ? row.lo : 0;
+                    row.next();
+                    const int d1 = (int)lrp1[i1 + 1] - (int)lrp1[i1];
+                    const int d2 = (int)lrp2[i2 + 1] - (int)lrp2[i2];
+                    const int pos = lds.tab_off[d1 * NC + d2] +
+                                    (i1 - lds.tab_cls[d1]) * lds.tab_cls[16 + d2] +
+                                    (i2 - lds.tab_cls[32 + d2]);
+                    if (ok) rowmap[pos] = ((unsigned)i1 << 16) | (unsigned)i2;
+                }
+            }
+            job_sync<W>();
+
+            auto open_row = [&](int kb) -> row_t {
+                row_t r;
+                const int pos = kb * T + tid;
+                const bool ok = pos < N;
+                const unsigned rm = rowmap[ok ? pos : 0];
+                r.i1 = (int)(rm >> 16);
+                r.i2 = (int)(rm & 0xFFFFu);
+                r.rs1 = lrp1[r.i1];
+                r.rs2 = lrp2[r.i2];
+                r.d1 = ok ? (int)lrp1[r.i1 + 1] - r.rs1 : 0;
+                r.d2 = ok ? (int)lrp2[r.i2 + 1] - r.rs2 : 0;
+                r.prod = r.d1 * r.d2;
+                return r;
+            };
+
+            // ---- nonzero slots owned by this thread ---------------------------
+            real val[S];
+            unsigned adr[S];   // pass 1: (a << 16) | b, or ~0u; pass 2: index into p
+            unsigned fm[NM];
+#pragma unroll
+            for (int w = 0; w < NM; ++w) fm[w] = 0;
+            int n_slots = 0;
+            {
+                // pass 0 (wave-uniform): trip count of every row batch of this
+                // wave = degree product of its first row -> flush mask
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int pos = k * T + 64 * wv;
+                    int trip = 0;
+                    if (pos < N) {
+                        const unsigned rm = (unsigned)uni((int)rowmap[pos]);
+                        const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
+                        trip = uni(((int)lrp1[i1 + 1] - (int)lrp1[i1]) * ((int)lrp2[i2 + 1] - (int)lrp2[i2]));
+                    }
+                    if (trip > 0) {
+                        n_slots += trip;
+                        const int last = n_slots - 1;      // < S (host guarantees)
+#pragma unroll
+                        for (int w = 0; w < NM; ++w)
+                            if (last / 32 == w) fm[w] |= 1u << (last % 32);
+                    }
+                }
+                n_slots = n_slots > S ? S : n_slots;
+                // pass 1 (unrolled): the nonzero pair (a, b) of every slot
+                int kb = 0, j = 0, ja = 0, jb = 0;
+                row_t cur = open_row(0);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    adr[s] = (s < n_slots && j < cur.prod)
+                        ? ((unsigned)(cur.rs1 + ja) << 16) | (unsigned)(cur.rs2 + jb) : ~0u;
+                    asm volatile("" : "+v"(adr[s]));
+                    ++j;
+                    ++jb;
+                    if (jb >= cur.d2) {
+                        jb = 0;
+                        ++ja;
+                    }
+                    if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
+                        ++kb;
+                        j = ja = jb = 0;
+                        cur = open_row(kb);
+                    }
+                }
+                // pass 2: labels -> edge-kernel value and gather index
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
+                    const bool ok = adr[s] != ~0u;
+                    const unsigned a = ok ? (adr[s] >> 16) : 0u, b = ok ? (adr[s] & 0xFFFFu) : 0u;
+                    const nz_t z1 = at32(g1.nz, a), z2 = at32(g2.nz, b);
+                    real e;
+                    if constexpr (TAB) {
+                        e = at32(ketab, __umul24((unsigned)ecls1[a], nec) + ecls2[b]);
+                        if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                            e *= real(edge_weight<edge_t>::get(at32(g1.edge, a))) *
+                                 real(edge_weight<edge_t>::get(at32(g2.edge, b)));
+                    } else {
+                        const edge_t e1 = at32(g1.edge, a), e2 = at32(g2.edge, b);
+                        e = prm.edge_kernel(e1, e2);
+                    }
+                    val[s] = ok ? e : real(0);
+                    unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
+                    asm volatile("" : "+v"(val[s]), "+v"(col));
+                    adr[s] = col;
+                }
+            }
+
+            // ---- rows owned by this thread (sorted order) ----------------------
+            real dg[R], mi[R], x[C][R], r[C][R], p[C][R];
+            int paddr[R];
+            real rTz = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int pos = k * T + tid;
+                const bool ok = pos < N;
+                const unsigned rm = rowmap[ok ? pos : 0];
+                const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
+                const node_t v1 = at32(g1.node, (unsigned)i1), v2 = at32(g2.node, (unsigned)i2);
+                const real dx = real(at32(g1.degree, (unsigned)i1)) *
+                                real(at32(g2.degree, (unsigned)i2)) * inv1q2;
+                const real vx = kappa_v(i1, i2, v1, v2);
+                dg[k] = ok ? dx / vx : real(0);
+                mi[k] = ok ? vx / dx : real(0);
+                paddr[k] = ok ? (int)__umul24((unsigned)i1, (unsigned)ldp) + i2 : dump;
+                const real b = ok ? dx * bscale : real(0);
+                x[0][k] = 0;
+                r[0][k] = b;
+                p[0][k] = b * mi[k];
+                rTz += r[0][k] * p[0][k];
+                if constexpr (C == 2) {
+                    const real bx = ok ? real(prm.p_start(v1)) * real(prm.p_start(v2)) : real(0);
+                    x[1][k] = 0;
+                    r[1][k] = bx;
+                    p[1][k] = bx * mi[k];
+                    rTz += r[1][k] * p[1][k];
+                }
+            }
+
+            auto publish = [&](real const (&v)[C][R]) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    real e[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) e[c] = v[c][k];
+                    store_elem<C>(lp, (unsigned)paddr[k], e);
+                }
+            };
+            publish(p);
+            rTz = block_reduce<real, W>::sum(rTz, red);
+
+            const real tol = (C == 2) ? real(1e-10) * real(2 * N) : prm.ftol * real(N);
+            const real tol2 = tol * tol;
+            unsigned it = 0;
+            for (; it < (unsigned)N && rTz != real(0); ++it) {
+                job_sync<W>();   // p published
+                // row sums: sum over the slots of a batch, flushed to the
+                // lane-private cell Y[batch][lane] at wave-uniform positions
+                {
+                    real acc[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] = 0;
+                    int kb = 0;
+                    unsigned fmv[NM];
+#pragma unroll
+                    for (int w = 0; w < NM; ++w) {
+                        fmv[w] = fm[w];
+                        asm volatile("" : "+s"(fmv[w]));
+                    }
+#pragma unroll
+                    for (int s0 = 0; s0 < S; s0 += GCH) {
+                        if (s0 >= n_slots) break;   // wave-uniform: no slots left
+                        real g[C][GCH];
+#pragma unroll
+                        for (int jj = 0; jj < GCH; ++jj) {
+                            real e[C];
+#pragma unroll
+                            for (int c = 0; c < C; ++c) e[c] = 0;
+                            if (s0 + jj < S) load_elem<C>(lp, adr[s0 + jj], e);
+#pragma unroll
+                            for (int c = 0; c < C; ++c) g[c][jj] = e[c];
+                        }
+#pragma unroll
+                        for (int jj = 0; jj < GCH; ++jj) {
+                            const int s = s0 + jj;
+                            if (s < S) {
+#pragma unroll
+                                for (int c = 0; c < C; ++c) acc[c] += val[s] * g[c][jj];
+                                if ((fmv[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
+                                    if constexpr (ADDTID) {
+                                        store_lane_contiguous<0>(lY_off + kb * (T * 4), (float)acc[0]);
+                                        acc[0] = 0;
+                                    } else {
+                                        store_elem<C>(lY, kb * T + tid, acc);
+#pragma unroll
+                                        for (int c = 0; c < C; ++c) acc[c] = 0;
+                                    }
+                                    ++kb;
+                                }
+                            }
+                        }
+                    }
+                }
+                // (no barrier: a lane reads back what it wrote itself, and the
+                // LDS operations of one wave execute in order)
+                real Ap[C][R];
+                real pAp = 0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    real y[C];
+                    load_elem<C>(lY, k * T + tid, y);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        Ap[c][k] = dg[k] * p[c][k] - y[c];
+                        pAp += p[c][k] * Ap[c][k];
+                    }
+                }
+                pAp = block_reduce<real, W>::sum(pAp, red);
+                if (pAp == real(0)) break;
+                const real alpha = rTz / pAp;
+                real rTr = 0, rTz_next = 0;
+                real z[C][R];
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        x[c][k] += alpha * p[c][k];
+                        r[c][k] -= alpha * Ap[c][k];
+                        z[c][k] = mi[k] * r[c][k];
+                        rTr += r[c][k] * r[c][k];
+                        rTz_next += r[c][k] * z[c][k];
+                    }
+                block_reduce<real, W>::sum2(rTr, rTz_next, red);
+                if (rTr < tol2) {   // sqrt(rTr) < tol
+                    ++it;
+                    break;
+                }
+                const real beta = rTz_next / rTz;
+#pragma unroll
+                for (int k = 0; k < R; ++k)
+#pragma unroll
+                    for (int c = 0; c < C; ++c) p[c][k] = z[c][k] + beta * p[c][k];
+                // (W > 1: the barriers inside the reductions above are behind
+                // every wave's gathers of the old p)
+                publish(p);
+                rTz = rTz_next;
+            }
+            if (prm.iters != nullptr && tid == 0) prm.iters[prm.order[t]] = it;
+
+            // ---- output ------------------------------------------------------
+            const unsigned flags = prm.flags;
+            const unsigned I1 = prm.starts[job.i], I2 = prm.starts[job.j];
+            const bool mirror = (flags & F_SYMMETRIC) && job.i != job.j;
+            real ksum = 0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int pos = k * T + tid;
+                const bool ok = pos < N;
+                const unsigned rm = rowmap[ok ? pos : 0];
+                const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
+                const node_t v1 = g1.node[i1], v2 = g2.node[i2];
+                real xi = x[0][k];
+                if (flags & F_LMIN1) xi -= kappa_v(i1, i2, v1, v2) * bscale;
+                const real pp = real(prm.p_start(v1)) * real(prm.p_start(v2));
+                const real rv = ok ? xi * pp : real(0);
+                ksum += rv;
+                if constexpr (NODAL) if ((flags & F_NODAL) && ok) {
+                    const unsigned o1 = g1.perm[i1], o2 = g2.perm[i2];
+                    if (flags & F_BLOCK) {
+                        prm.gramian[I1 + o1 + o2 * n2] = rv;
+                    } else if (flags & F_DIAGONAL) {
+                        if (o1 == o2) prm.gramian[I1 + o1] = rv;
+                    } else {
+                        prm.gramian[(size_t)(I1 + o1) + (size_t)prm.nX * (I2 + o2)] = rv;
+                        if (mirror) prm.gramian[(size_t)(I2 + o2) + (size_t)prm.nX * (I1 + o1)] = rv;
+                    }
+                }
+            }
+            if (!NODAL || !(flags & F_NODAL)) {
+                ksum = block_reduce<real, W>::sum(ksum, red);
+                if (tid == 0) {
+                    if (flags & F_PACKED) {
+                        prm.gramian[prm.order[t]] = ksum;
+                    } else if (flags & F_DIAGONAL) {
+                        prm.gramian[I1] = ksum;
+                    } else {
+                        prm.gramian[(size_t)I1 + (size_t)prm.nX * I2] = ksum;
+                        if (mirror) prm.gramian[(size_t)I2 + (size_t)prm.nX * I1] = ksum;
+                    }
+                }
+            }
+
+            // ---- analytic gradient (graph-level), marginalized_kernel.h:806-997
+            if constexpr (C == 2) {
+                job_sync<W>();
+                publish(x);   // lp[2i] = YDq_i, lp[2i+1] = Yp_i
+                real jac[n_jac];
+#pragma unroll
+                for (int j = 0; j < n_jac; ++j) jac[j] = 0;
+                const real Q = real(1) / (real(1) - q), Q3 = Q * Q * Q;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int pos = k * T + tid;
+                    const bool ok = pos < N;
+                    const unsigned rm = rowmap[ok ? pos : 0];
+                    const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
+                    const node_t v1 = g1.node[i1], v2 = g2.node[i2];
+                    const real p1 = prm.p_start(v1), p2 = prm.p_start(v2);
+                    const real dox = real(g1.degree[i1]) * real(g2.degree[i2]);
+                    const real dx = dox * inv1q2;
+                    const real v = kappa_v(i1, i2, v1, v2);
+                    const real YDq = ok ? x[0][k] : real(0), Yp = ok ? x[1][k] : real(0);
+                    auto dp1 = prm.p_start._j_a_c_o_b_i_a_n_(v1);
+                    auto dp2 = prm.p_start._j_a_c_o_b_i_a_n_(v2);
+#pragma unroll
+                    for (int j = 0; j < PStart::jac_dims; ++j)
+                        jac[j] += (real(dp1[j]) * p2 + p1 * real(dp2[j])) * YDq;
+                    jac[off_q] += real(2) * Q * p1 * p2 * YDq - real(2) * Q3 * Yp * dox / v * YDq;
+                    const real wv_ = dx * Yp * YDq / (v * v);
+                    if constexpr (TAB) {
+                        const unsigned cidx = __umul24((unsigned)ncls1[i1], nvc) + ncls2[i2];
+#pragma unroll
+                        for (int j = 0; j < NodeK::jac_dims; ++j)
+                            jac[off_v + j] += wv_ * at32(dkvtab, (unsigned)j * nvc * nvc + cidx);
+                    } else {
+                        auto dv = prm.node_kernel._j_a_c_o_b_i_a_n_(v1, v2);
+#pragma unroll
+                        for (int j = 0; j < NodeK::jac_dims; ++j) jac[off_v + j] += wv_ * real(dv[j]);
+                    }
+                }
+                job_sync<W>();
+                if constexpr (EdgeK::jac_dims > 0) {
+                    // walk the slots again: row = the batch's row, col = adr
+                    int kb = 0, j = 0, ja = 0, jb = 0;
+                    row_t cur = open_row(0);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        if (s < n_slots) {   // wave-uniform
+                            const bool ok = j < cur.prod;
+                            const int a = ok ? cur.rs1 + ja : 0, b = ok ? cur.rs2 + jb : 0;
+                            const int row = cur.i1 * ldp + cur.i2;
+                            real w = ok ? lp[row * 2 + 1] * lp[adr[s] * 2 + 0] : real(0);
+                            if constexpr (TAB) {
+                                const unsigned cidx = __umul24((unsigned)ecls1[a], nec) + ecls2[b];
+                                if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                                    w *= real(edge_weight<edge_t>::get(g1.edge[a])) *
+                                         real(edge_weight<edge_t>::get(g2.edge[b]));
+#pragma unroll
+                                for (int jj = 0; jj < EdgeK::jac_dims; ++jj)
+                                    jac[off_e + jj] += w * at32(dketab, (unsigned)jj * nec * nec + cidx);
+                            } else {
+                                const edge_t e1 = g1.edge[a], e2 = g2.edge[b];
+                                auto de = prm.edge_kernel._j_a_c_o_b_i_a_n_(e1, e2);
+#pragma unroll
+                                for (int jj = 0; jj < EdgeK::jac_dims; ++jj) jac[off_e + jj] += w * real(de[jj]);
+                            }
+                            ++j;
+                            ++jb;
+                            if (jb >= cur.d2) {
+                                jb = 0;
+                                ++ja;
+                            }
+                            if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
+                                ++kb;
+                                j = ja = jb = 0;
+                                cur = open_row(kb);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < n_jac; ++j) {
+                    const real g = block_reduce<real, W>::sum(jac[j], red);
+                    if (tid == 0) {
+                        if (flags & F_PACKED) {
+                            prm.gradient[(size_t)prm.order[t] * n_jac + j] = g;
+                        } else if (flags & F_DIAGONAL) {
+                            prm.gradient[(size_t)I1 + (size_t)prm.nX * j] = g;
+                        } else {
+                            const size_t plane = (size_t)prm.nX * prm.nY;
+                            prm.gradient[(size_t)I1 + (size_t)prm.nX * I2 + plane * j] = g;
+                            if (mirror) prm.gradient[(size_t)I2 + (size_t)prm.nX * I1 + plane * j] = g;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // lane LANE of v = s (s wave-uniform)
+    template<int LANE> __device__ static __forceinline__ void writelane(int &v, int s) {
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
+    }
+    // class tables in the lanes of one register: lane c = first node of degree
+    // class c in graph 1, lane 16 + c = nodes of class c in graph 2, lane
+    // 32 + c = its first node (classes in descending degree: class DMAX first)
+    template<int... Cs> __device__ static __forceinline__ void
+    fill_classes(std::integer_sequence<int, Cs...>, int &vcls, const int (&cnt1)[NC], const int (&cnt2)[NC]) {
+        int s1 = 0, s2 = 0;
+        ((writelane<DMAX - Cs>(vcls, s1), writelane<16 + DMAX - Cs>(vcls, cnt2[DMAX - Cs]),
+          writelane<32 + DMAX - Cs>(vcls, s2), s1 += cnt1[DMAX - Cs], s2 += cnt2[DMAX - Cs]), ...);
+    }
+    // sorted-row offset of rectangle (d1, d2) in lane (d1 * NC + d2) % 64 of
+    // voff[(d1 * NC + d2) / 64]: a running sum in the compile-time order ORD
+    template<int K, int NW> __device__ static __forceinline__ void write_offset(int (&voff)[NW], int off) {
+        constexpr int idx = ORD.d1[K] * NC + ORD.d2[K];
+        writelane<idx % 64>(voff[idx / 64], off);
+    }
+    template<int... Ks, int NW> __device__ static __forceinline__ void
+    fill_offsets(std::integer_sequence<int, Ks...>, int (&voff)[NW], const int (&cnt1)[NC], const int (&cnt2)[NC]) {
+        int off = 0;
+        ((write_offset<Ks>(voff, off), off += cnt1[ORD.d1[Ks]] * cnt2[ORD.d2[Ks]]), ...);
+    }
+};
+
+}  // namespace mgk
+}  // namespace graphdot
+#endif

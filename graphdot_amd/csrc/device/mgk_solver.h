@@ -74,6 +74,7 @@ template<class real, class Graph, class NodeK, class EdgeK, class PStart> struct
     real *gradient;
     std::uint32_t *iters;        // optional per-job CG iteration counts
     real *scratch;               // general solver only: per-workgroup CG scratch
+    real *tables;                // microkernel values over label-class pairs (mgk_oc.h)
     std::uint32_t n_launch_jobs;
     std::uint32_t nX, nY, nJ;
     std::uint32_t flags;

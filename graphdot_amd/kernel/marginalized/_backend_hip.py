@@ -32,6 +32,9 @@ F_NODAL, F_DIAGONAL, F_SYMMETRIC, F_LMIN1, F_BLOCK, F_PACKED = \
     1, 2, 4, 8, 16, 32
 
 Variant = namedtuple('Variant', 'W S R')
+#: owner-computes solver (csrc/device/mgk_oc.h): S nonzero slots and R rows
+#: per lane, for pairs of graphs whose largest degree is at most D
+OCVariant = namedtuple('OCVariant', 'W S R D')
 
 #: register-resident solver menu, cheapest first.  A pair fits a variant if
 #: its stage-1 walk needs <= S slots per lane and N = n1*n2 <= 64*W*R.
@@ -43,8 +46,16 @@ VARIANTS = [
     Variant(16, 16, 2), Variant(16, 32, 4), Variant(16, 64, 8),
     Variant(16, 128, 16),
 ]
+#: owner-computes menu (molecular graphs: every degree <= 4), cheapest first
+OC_VARIANTS = [
+    OCVariant(1, 12, 2, 4), OCVariant(1, 16, 3, 4), OCVariant(1, 20, 3, 4),
+    OCVariant(1, 20, 4, 4), OCVariant(1, 24, 4, 4), OCVariant(1, 28, 5, 4),
+    OCVariant(1, 28, 6, 4), OCVariant(1, 32, 7, 4), OCVariant(1, 36, 9, 4),
+]
 #: sentinel: the global-memory general solver (any pair size)
 GENERAL = Variant(0, 0, 0)
+#: sentinel: the kernel that fills the global microkernel tables
+TABLES = Variant(-1, 0, 0)
 GENERAL_THREADS = 1024
 LDS_LIMIT = 160 * 1024
 #: independent pairs (waves) per workgroup of the one-wave variants;
@@ -53,6 +64,8 @@ WPB1 = int(os.environ.get('GD_WPB', 1))
 #: microkernel value tables (label classes) are used when they fit this much
 #: LDS per workgroup: (n_node_classes^2 + n_edge_classes^2) reals
 TABLE_LDS_LIMIT = 8 * 1024
+#: class pairs (node + edge) up to which the global tables are used
+GLOBAL_TABLE_LIMIT = 1 << 16
 
 
 def _real_name(real):
@@ -152,6 +165,55 @@ class Layout:
     pass
 
 
+class LaunchSet:
+    """The streams and events that run the launches of a plan, step after
+    step, without a host synchronisation: the launches every solver depends
+    on (the table kernel) go to the null stream, every solver variant to a
+    non-blocking stream of its own (longest first), ordered device-side --
+    the solver streams wait for the `start` event of the step (recorded on
+    the null stream behind the table kernel and behind everything the caller
+    enqueued there before, e.g. the previous step's collective), the null
+    stream waits for every solver stream.  `events[k] = (begin, end)` are
+    recorded around solver launch k on the stream it runs on."""
+
+    def __init__(self):
+        self.streams, self.done = [], []
+        self.start = runtime.Event()
+
+    def enqueue(self, plan, events=None, serial=False):
+        for L in plan.pre_launches:
+            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                           dynamic_lds=L['dynamic_lds'])
+        n = len(plan.launches)
+        if serial:
+            for k, L in enumerate(plan.launches):
+                if events is not None:
+                    events[k][0].record()
+                runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                               dynamic_lds=L['dynamic_lds'])
+                if events is not None:
+                    events[k][1].record()
+            return
+        while len(self.streams) < n:
+            self.streams.append(runtime.Stream())
+            self.done.append(runtime.Event())
+        self.start.record()
+        order = sorted(range(n), key=lambda k: -plan.launches[k]['count']
+                       * (plan.launches[k]['variant'].S + 8))
+        for slot, k in enumerate(order):
+            L, s = plan.launches[k], self.streams[slot]
+            s.wait_event(self.start)
+            if events is not None:
+                events[k][0].record(s.h)
+            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                           stream=s.h, dynamic_lds=L['dynamic_lds'])
+            if events is not None:
+                events[k][1].record(s.h)
+            self.done[slot].record(s.h)
+        for slot in range(n):
+            runtime.null_stream_wait_event(self.done[slot])
+
+
 class HIPBackend(Backend):
     """MI355X backend.
 
@@ -199,24 +261,39 @@ class HIPBackend(Backend):
             'jobs_per_unit', os.environ.get('GD_JOBS_PER_UNIT', 1)))
         self.hipcc_extra = list(kwargs.pop('hipcc_extra', [])) + \
             os.environ.get('GD_HIPCC_EXTRA', '').split()
-        self.variants = list(kwargs.pop('variants', VARIANTS + [GENERAL]))
-        if os.environ.get('GD_VARIANTS'):     # experiments: "W:S:R,W:S:R,..."
-            self.variants = [Variant(*map(int, item.split(':'))) for item in
+        self.variants = list(kwargs.pop(
+            'variants', OC_VARIANTS + VARIANTS + [GENERAL]))
+        if os.environ.get('GD_OC') == '0':        # experiments: two-stage only
+            self.variants = [v for v in self.variants
+                             if not isinstance(v, OCVariant)]
+        if os.environ.get('GD_VARIANTS'):     # experiments: "W:S:R[:D],..."
+            def parse(item):
+                f = list(map(int, item.split(':')))
+                return OCVariant(*f) if len(f) == 4 else Variant(*f)
+            self.variants = [parse(item) for item in
                              os.environ['GD_VARIANTS'].split(',')] + [GENERAL]
         self.record_iterations = kwargs.pop('record_iterations', False)
         self.occupancy = kwargs.pop('occupancy', None)
         self.concurrent = kwargs.pop('concurrent', True)
         # microkernel value tables over label classes (GraphArena.classes):
-        # opt-in.  They remove 16 % of the fp64 VALU instructions per pair,
-        # but the table is rebuilt per workgroup, and with one pair per
-        # workgroup (the fastest geometry) direct evaluation wins: fp64
-        # 79.1 M pairs/s without against 74.0 M with tables (77.6 M at two
-        # pairs per workgroup); fp32 loses 4 % in any geometry.
-        tables = kwargs.pop('tables', False)
+        #   'global' (default): one tiny launch per evaluation fills a global
+        #       table per pair of classes, the owner-computes solvers look
+        #       values up (mgk_oc.h) -- whenever the labels can be numbered;
+        #   'lds' (or True): the two-stage solvers rebuild the tables per
+        #       workgroup in LDS (round 1; slower than direct evaluation with
+        #       one pair per workgroup, kept for microkernels much more
+        #       expensive than a Gaussian); the owner-computes menu is off;
+        #   False: every microkernel value is evaluated where it is used.
+        tables = kwargs.pop('tables', 'global')
         if os.environ.get('GD_TABLES'):           # experiments
-            tables = os.environ['GD_TABLES'] == '1'
-        self.tables = bool(tables)
-        self._streams = []
+            tables = {'0': False, '1': 'lds'}.get(os.environ['GD_TABLES'],
+                                                  os.environ['GD_TABLES'])
+        if tables is True:
+            tables = 'lds'
+        if tables not in (False, 'lds', 'global'):
+            raise ValueError(f'tables={tables!r}: False, "lds" or "global"')
+        self.tables = tables
+        self._launch_set = None
         if self.occupancy is None and os.environ.get('GD_OCCUPANCY'):
             # e.g. GD_OCCUPANCY="1:16:5,1:24:4"  (W:S:waves)
             self.occupancy = {
@@ -290,18 +367,27 @@ class HIPBackend(Backend):
         return None if bare else tuple(sorted(names))
 
     def _table_bytes(self, arena):
-        """LDS bytes of the microkernel tables of `arena`'s label classes, or
-        0 if this call evaluates the microkernels directly (tables disabled,
-        labels not numberable, or tables beyond TABLE_LDS_LIMIT)."""
+        """LDS bytes of the per-workgroup microkernel tables (tables='lds')
+        of `arena`'s label classes, or 0 if this call evaluates the
+        microkernels directly (other modes, labels not numberable, or tables
+        beyond TABLE_LDS_LIMIT)."""
         c = arena.classes
-        if not self.tables or c is None:
+        if self.tables != 'lds' or c is None:
             return 0
         b = (c['nv']**2 + c['ne']**2) * np.dtype(self.real).itemsize
         return int(-(-b // 16) * 16) if b <= TABLE_LDS_LIMIT else 0
 
+    def _global_tables(self, arena):
+        """Do the owner-computes solvers of this call read the microkernels
+        from the per-evaluation global tables (tables='global' and the labels
+        fall into classes)?"""
+        c = arena.classes
+        return (self.tables == 'global' and c is not None
+                and c['nv']**2 + c['ne']**2 <= GLOBAL_TABLE_LIMIT)
+
     def _host_arena(self, dgraphs, fields):
         # (label classes are only numbered when the tables are in use)
-        return GraphArena(dgraphs, *fields, classes=self.tables)
+        return GraphArena(dgraphs, *fields, classes=bool(self.tables))
 
     def _arena(self, dgraphs, fields=(None, None)):
         key = (tuple(id(g) for g in dgraphs), fields if self.tables else None)
@@ -405,6 +491,7 @@ struct ${name}_t : ${name}_theta_t {
         return np.dtype([
             ('arena', P), ('jobs', P), ('order', P), ('starts', P),
             ('gramian', P), ('gradient', P), ('iters', P), ('scratch', P),
+            ('tables', P),
             ('n_launch_jobs', np.uint32), ('nX', np.uint32),
             ('nY', np.uint32), ('nJ', np.uint32), ('flags', np.uint32),
             ('order_offset', np.uint32), ('u_capacity', np.uint32),
@@ -423,6 +510,11 @@ struct ${name}_t : ${name}_theta_t {
         f = 'f64' if np.dtype(self.real) == np.float64 else 'f32'
         if v == GENERAL:
             return f'mgk_{f}_general_T{GENERAL_THREADS}_C{C}'
+        if v == TABLES:
+            return f'mgk_{f}_tables_C{C}'
+        if isinstance(v, OCVariant):
+            return f'mgk_{f}_oc{v.D}_W{v.W}_S{v.S}_R{v.R}_C{C}' + \
+                ('_nodal' if nodal else '') + ('_tab' if tab else '')
         return f'mgk_{f}_W{v.W}_S{v.S}_R{v.R}_C{C}' + \
             ('_nodal' if nodal else '') + ('_tab' if tab else '')
 
@@ -452,6 +544,8 @@ struct ${name}_t : ${name}_theta_t {
         floor = -(-64 * v.W * (WPB1 if v.W == 1 else 1) // 256)  # block must fit
         if self.occupancy is not None and (v.W, v.S) in self.occupancy:
             return max(self.occupancy[(v.W, v.S)], floor)
+        if isinstance(v, OCVariant):
+            return max(self._oc_waves(v, C), -(-64 * v.W // 256))
         if v.W == 1:
             f64 = np.dtype(self.real) == np.float64
             table = {(1, False): self._WAVES_F32_VALUE,
@@ -478,7 +572,50 @@ struct ${name}_t : ${name}_theta_t {
                 return max(n, floor)
         return max(1, floor)
 
+    #: measured occupancy targets of the owner-computes variants
+    #: (real, C) -> {(S, R): waves per SIMD}
+    _OC_WAVES = {}
+
+    def _oc_waves(self, v, C):
+        """Occupancy target of an owner-computes variant: per lane S values +
+        S gather indices, 6 registers per row (x, r, p, diagonal, its inverse,
+        the publish address), the gathers in flight and ~24 others; a double
+        takes two registers."""
+        f64 = np.dtype(self.real) == np.float64
+        hit = self._OC_WAVES.get((f64, C), {}).get((v.S, v.R))
+        if hit:
+            return hit
+        w = 2 if f64 else 1
+        need = (w * C + 1) * 0 + v.S * (w + 1) + v.R * (5 * w * C + 1) \
+            + 8 * w * C + 24
+        for n in (8, 6, 5, 4, 3, 2):
+            if need <= (512 // n) // 8 * 8:
+                return n
+        return 1
+
     def _entry_point(self, v, C, nodal=False, tab=False):
+        if v == TABLES:
+            return Template(r'''
+extern "C" __global__ __launch_bounds__(256)
+void ${name}(params_t prm) {
+    graphdot::mgk::fill_tables<real_t, ${C}>(prm);
+}
+''').render(name=self.kernel_name(v, C), C=C)
+        if isinstance(v, OCVariant):
+            return Template(r'''
+extern "C" __global__ __launch_bounds__(${threads})
+__attribute__((amdgpu_waves_per_eu(${waves})))
+void ${name}(params_t prm) {
+    using solver = graphdot::mgk::oc_solver<real_t, ${S}, ${R}, ${W}, ${C},
+        ${nodal}, ${D}, ${tab}, graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
+    __shared__ typename solver::lds_t lds;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    solver::run(prm, lds, reinterpret_cast<real_t *>(dyn_lds));
+}
+''').render(threads=64 * v.W, name=self.kernel_name(v, C, nodal, tab),
+            S=v.S, R=v.R, W=v.W, C=C, D=v.D, waves=self.waves_per_eu(v, C),
+            nodal='true' if nodal else 'false',
+            tab='true' if tab else 'false')
         if v == GENERAL:
             return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
@@ -539,6 +676,14 @@ void ${name}(params_t prm) {
     def lds_bytes(self, v, C, ntask=0, gbytes=0, tab_bytes=0):
         """LDS bytes of one workgroup: static p + scratch, dynamic U, the two
         staged graph images per pair slot and the microkernel tables."""
+        if isinstance(v, OCVariant):
+            # p (rows with the odd stride + the dump cell), the lane-private
+            # row sums, the row map, both images; static: tables + scratch
+            rs = np.dtype(self.real).itemsize
+            NR = 64 * v.W * v.R
+            pcap = -(-(np.asarray(ntask) + 1) // 4) * 4
+            return (pcap + NR) * C * rs + 4 * NR + 2 * np.asarray(gbytes) \
+                + 2 * v.W * rs + 4 * (128 if v.D > 6 else 64) + 256
         wpb = WPB1 if v.W == 1 else 1
         T = 64 * v.W
         ucap = -(-np.asarray(ntask) // 64) * 64 + 64
@@ -570,7 +715,36 @@ void ${name}(params_t prm) {
             worst = np.maximum(worst, total)
         return worst
 
-    def classify(self, ji, jj, dgraphs, C, tab_bytes=0):
+    @staticmethod
+    def oc_slots_needed(hist1, hist2, W, D):
+        """Slots per lane of the owner-computes walk (mgk_oc.h): rows are
+        sorted by descending degree product -- rectangle (d1, d2) holds
+        hist1[d1] * hist2[d2] rows -- and dealt in batches of T = 64 W; wave w
+        of batch k walks the product of its first row.  `hist*`: (n_jobs,
+        D + 1) degree histograms of the two graphs.  Returns the maximum over
+        the waves."""
+        order = sorted(((a, b) for a in range(D + 1) for b in range(D + 1)),
+                       key=lambda t: -t[0] * t[1])    # stable: row-major ties
+        prods = np.array([a * b for a, b in order] + [0], dtype=np.int64)
+        sizes = np.stack([hist1[:, a] * hist2[:, b] for a, b in order], axis=1)
+        cum = np.cumsum(sizes, axis=1)
+        N = cum[:, -1]
+        T = 64 * W
+        nb = int(-(-N.max() // T)) if len(N) else 0
+        worst = np.zeros(len(N), dtype=np.int64)
+        for w in range(W):
+            total = np.zeros(len(N), dtype=np.int64)
+            for k in range(nb):
+                first = k * T + 64 * w
+                live = first < N
+                if not live.any():
+                    break
+                c = (cum <= first).sum(axis=1)     # rectangle of that row
+                total += np.where(live, prods[np.minimum(c, len(order))], 0)
+            worst = np.maximum(worst, total)
+        return worst
+
+    def classify(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False):
         """Assign every job the cheapest solver variant it fits.
         Returns (variant_index[n_jobs], cost[n_jobs])."""
         n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
@@ -593,11 +767,43 @@ void ${name}(params_t prm) {
         if tab_bytes:      # the label-class section is staged with the image
             image = image + class_bytes(n_node, n_nz)
         gbytes = np.maximum(image[ji], image[jj])
+        # the owner-computes solvers with global tables stage the class ids
+        image_oc = image + class_bytes(n_node, n_nz) if gtab else image
+        gbytes_oc = np.maximum(image_oc[ji], image_oc[jj])
+        maxdeg = np.array([int(g.adjacency_count.max()) if g.n_node else 0
+                           for g in dgraphs], dtype=np.int64)
+        pair_maxdeg = np.maximum(maxdeg[ji], maxdeg[jj])
+        oc_slots, hists = {}, {}
         for k, v in enumerate(self.variants):
             todo = choice < 0
             if not todo.any():
                 break
             if v == GENERAL:
+                continue
+            if isinstance(v, OCVariant):
+                if tab_bytes:           # the table kernels are two-stage only
+                    continue
+                fits = (todo & (pair_maxdeg <= v.D) & (N <= 64 * v.W * v.R)
+                        & (NP < 0xFFFF)
+                        & (self.lds_bytes(v, C, NP, gbytes_oc) <= LDS_LIMIT))
+                if not fits.any():
+                    continue
+                if (v.W, v.D) not in oc_slots:
+                    if v.D not in hists:
+                        h = np.zeros((len(dgraphs), v.D + 1), dtype=np.int64)
+                        for g_, dg_ in enumerate(dgraphs):
+                            if maxdeg[g_] <= v.D:
+                                h[g_] = np.bincount(dg_.adjacency_count,
+                                                    minlength=v.D + 1)
+                        hists[v.D] = h
+                    idx = np.flatnonzero(todo & (pair_maxdeg <= v.D))
+                    sl = np.full(len(ji), np.iinfo(np.int64).max,
+                                 dtype=np.int64)
+                    sl[idx] = self.oc_slots_needed(
+                        hists[v.D][ji[idx]], hists[v.D][jj[idx]], v.W, v.D)
+                    oc_slots[(v.W, v.D)] = sl
+                fits &= oc_slots[(v.W, v.D)] <= v.S
+                choice[fits] = k
                 continue
             fits = (todo & (NP <= 64 * v.W * v.R) & (NP <= 0xFFFF)
                     & (self.lds_bytes(v, C, ntask, gbytes, tab_bytes)
@@ -622,7 +828,7 @@ void ${name}(params_t prm) {
                     'register-resident solver variant and the general '
                     'solver is disabled')
             choice[choice < 0] = self.variants.index(GENERAL)
-        return choice, cost, ntask, gbytes
+        return choice, cost, ntask, gbytes, NP, gbytes_oc
 
     # -- the three phases -----------------------------------------------------------
     def _graphs_and_kernels(self, graphs, node_kernel, edge_kernel, traits,
@@ -653,14 +859,14 @@ void ${name}(params_t prm) {
             edge_kernel = TensorProduct(weight=Product(), label=edge_kernel)
         return dgraphs, edge_kernel, C, fields
 
-    def _partition(self, dgraphs, jobs, C, tab_bytes=0):
+    def _partition(self, dgraphs, jobs, C, tab_bytes=0, gtab=False):
         """Host half of a layout: solver variant per job, launch order (by
         variant, then descending cost) and launch geometry.  No device."""
         jobs = np.ascontiguousarray(jobs)
         ji = jobs['i'].astype(np.int64)
         jj = jobs['j'].astype(np.int64)
-        choice, cost, ntask, gbytes = self.classify(ji, jj, dgraphs, C,
-                                                    tab_bytes)
+        choice, cost, ntask, gbytes, NP, gbytes_oc = self.classify(
+            ji, jj, dgraphs, C, tab_bytes, gtab)
         used = sorted(set(choice.tolist()))
         rsize = np.dtype(self.real).itemsize
         n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
@@ -679,6 +885,20 @@ void ${name}(params_t prm) {
                     variant=v, k=k, offset=cursor, ucap=per_wg, gcap=0,
                     dynamic_lds=0, count=len(idx), grid=None,
                     threads=GENERAL_THREADS, per_wg=per_wg))
+                cursor += len(idx)
+                continue
+            if isinstance(v, OCVariant):
+                # one pair per workgroup; dynamic LDS: p | row sums | row map
+                # | two images (mgk_oc.h)
+                pcap = int(-(-(NP[idx].max() + 1) // 4) * 4)
+                gcap = int(-(-gbytes_oc[idx].max() // 16) * 16)
+                NR = 64 * v.W * v.R
+                dyn = (pcap + NR) * C * rsize + 4 * NR + 2 * gcap
+                launches.append(dict(
+                    variant=v, k=k, offset=cursor, ucap=pcap, gcap=gcap,
+                    dynamic_lds=dyn, count=len(idx),
+                    grid=int(max(1, -(-len(idx) // self.jobs_per_unit))),
+                    threads=64 * v.W, tab=gtab))
                 cursor += len(idx)
                 continue
             wpb = WPB1 if v.W == 1 else 1
@@ -701,23 +921,29 @@ void ${name}(params_t prm) {
         return jobs, used, order_all, launches
 
     def _sources(self, used, node_kernel, edge_kernel, p, dgraphs, C, nodal,
-                 tab=False):
-        """One translation unit per solver variant in use.  The node / edge /
-        start-probability code is shared text; only the entry point differs."""
+                 tab=False, gtab=False):
+        """One translation unit per solver variant in use (+ the one of the
+        table kernel, key 'tables', when the owner-computes solvers read
+        global tables).  The node / edge / start-probability code is shared
+        text; only the entry point differs."""
         # rendering is pure text work on hyperparameter-independent inputs:
         # memoised on the generated expressions and the record types
         sig = (node_kernel.gen_expr('x1', 'x2')[0], str(node_kernel.dtype),
                edge_kernel.gen_expr('x1', 'x2')[0], str(edge_kernel.dtype),
                p.gen_expr()[0], str(np.dtype(p.dtype)), dgraphs[0].signature,
-               C, nodal, tab)
+               C, nodal, tab, gtab)
         out = {}
-        for k in used:
+        todo = [(k, self.variants[k]) for k in used]
+        if gtab and any(isinstance(v, OCVariant) for _, v in todo):
+            todo.append(('tables', TABLES))
+        for k, v in todo:
             key = (sig, k)
             if key not in self._source_cache:
                 self._source_cache[key] = self.render_source(
                     node_kernel, edge_kernel, p, dgraphs[0].node_t,
-                    dgraphs[0].edge_t, [self.variants[k]], C, nodal,
-                    tab=tab and self.variants[k] != GENERAL,
+                    dgraphs[0].edge_t, [v], C, nodal,
+                    tab=gtab if isinstance(v, OCVariant)
+                    else (tab and v not in (GENERAL, TABLES)),
                     weighted=dgraphs[0].weighted)
             out[k] = self._source_cache[key]
         return out
@@ -729,11 +955,14 @@ void ${name}(params_t prm) {
         in use."""
         dgraphs, edge_kernel, C, fields = self._graphs_and_kernels(
             graphs, node_kernel, edge_kernel, traits, timer)
-        tab_bytes = self._table_bytes(self._host_arena(dgraphs, fields))
+        arena = self._host_arena(dgraphs, fields)
+        tab_bytes = self._table_bytes(arena)
+        gtab = self._global_tables(arena)
         jobs, used, order_all, launches = self._partition(dgraphs, jobs, C,
-                                                          tab_bytes)
+                                                          tab_bytes, gtab)
         sources = self._sources(used, node_kernel, edge_kernel, p, dgraphs, C,
-                                traits.nodal is not False, tab_bytes > 0)
+                                traits.nodal is not False, tab_bytes > 0,
+                                gtab)
         return dgraphs, edge_kernel, jobs, C, used, order_all, launches, \
             sources
 
@@ -773,8 +1002,9 @@ void ${name}(params_t prm) {
         lay.jobs_host = jobs
         lay.arena, lay.arena_buf, _ = self._arena(dgraphs, fields)
         lay.tab_bytes = self._table_bytes(lay.arena)
+        lay.gtab = self._global_tables(lay.arena)
         jobs, lay.used, lay.order_host, lay.launches = self._partition(
-            dgraphs, jobs, C, lay.tab_bytes)
+            dgraphs, jobs, C, lay.tab_bytes, lay.gtab)
         lay.n_jobs = len(jobs)
         lay.b_jobs = runtime.DeviceBuffer(max(jobs.nbytes, 8))
         lay.b_order = runtime.DeviceBuffer(max(lay.order_host.nbytes, 4))
@@ -811,7 +1041,7 @@ void ${name}(params_t prm) {
         tic('code generation')
         nodal = traits.nodal is not False
         sources = self._sources(lay.used, node_kernel, edge_kernel, p,
-                                dgraphs, C, nodal, tab)
+                                dgraphs, C, nodal, tab, lay.gtab)
         toc('code generation')
         tic('JIT')
         missing = [s for s in sources.values()
@@ -850,7 +1080,9 @@ void ${name}(params_t prm) {
         for G in lay.launches:
             L = dict(G)
             L['module'] = modules[L['k']]
-            L['tab'] = tab and L['variant'] != GENERAL
+            L['tab'] = L.get('tab', False) \
+                if isinstance(L['variant'], OCVariant) \
+                else tab and L['variant'] != GENERAL
             L['fn'] = fn = L['module'].function(
                 self.kernel_name(L['variant'], C, nodal, L['tab']))
             if L['variant'] == GENERAL:
@@ -872,9 +1104,19 @@ void ${name}(params_t prm) {
                             + [0])
         b_scratch = self._buffer('scratch', scratch_bytes) \
             if scratch_bytes else None
+        # global microkernel tables of this evaluation: values (and, for the
+        # gradient solvers, one plane per hyperparameter) per pair of classes
+        b_tables = None
+        if 'tables' in modules:
+            c = lay.arena.classes
+            planes = 1 + (len(node_kernel.gen_expr('x1', 'x2')[1]) +
+                          len(edge_kernel.gen_expr('x1', 'x2')[1])
+                          if C == 2 else 0)
+            n_tab = (c['nv']**2 + c['ne']**2) * planes
+            b_tables = self._buffer('tables', n_tab * rsize)
         plan.buffers = dict(jobs=lay.b_jobs, order=lay.b_order,
                             starts=lay.b_starts, gramian=b_out,
-                            gradient=b_grad, iters=b_iters)
+                            gradient=b_grad, iters=b_iters, tables=b_tables)
 
         # kernel argument blocks
         pd = self._params_dtype(node_kernel, edge_kernel, p)
@@ -887,9 +1129,10 @@ void ${name}(params_t prm) {
             b_grad.ptr if b_grad is not None else 0)
         base['iters'] = b_iters.ptr if b_iters is not None else 0
         base['scratch'] = b_scratch.ptr if b_scratch is not None else 0
+        base['tables'] = b_tables.ptr if b_tables is not None else 0
         base['nX'], base['nY'], base['nJ'] = plan.nX, plan.nY, plan.nJ
         base['flags'] = flags
-        if tab:
+        if tab or b_tables is not None:
             c = lay.arena.classes
             base['n_vclass'], base['n_eclass'] = c['nv'], c['ne']
             base['vrep'], base['erep'] = c['vrep'], c['erep']
@@ -910,32 +1153,34 @@ void ${name}(params_t prm) {
             a['order_offset'] = L['offset']
             a['u_capacity'] = L['ucap']
             L['args'] = a.tobytes()
+        # launches that every solver launch depends on: the table kernel
+        plan.pre_launches = []
+        if b_tables is not None:
+            c = lay.arena.classes
+            plan.pre_launches.append(dict(
+                variant=TABLES, module=modules['tables'],
+                fn=modules['tables'].function(self.kernel_name(TABLES, C)),
+                grid=int(-(-(c['nv']**2 + c['ne']**2) // 256)), threads=256,
+                args=base.tobytes(), dynamic_lds=0))
         plan.params_dtype = pd
         self.last_plan = plan
         return plan
 
     def launch(self, plan, stream=None, concurrent=None):
-        """Enqueue every solver launch of `plan` (asynchronous).  With
-        `concurrent` (default: the backend's setting) each solver variant
-        goes to its own HIP stream so that the short launches fill the tails
-        of the long ones; `synchronize()` / `collect()` wait for all of them."""
+        """Enqueue every launch of `plan` (asynchronous).  With `concurrent`
+        (default: the backend's setting) each solver variant goes to its own
+        HIP stream so that the short launches fill the tails of the long
+        ones; `synchronize()` / `collect()` wait for all of them."""
         concurrent = self.concurrent if concurrent is None else concurrent
-        if not concurrent or len(plan.launches) < 2:
-            for L in plan.launches:
+        if stream is not None:
+            for L in plan.pre_launches + plan.launches:
                 runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
                                stream=stream, dynamic_lds=L['dynamic_lds'])
             return
-        while len(self._streams) < len(plan.launches):
-            self._streams.append(runtime.Stream())
-        # longest first
-        order = sorted(range(len(plan.launches)),
-                       key=lambda k: -plan.launches[k]['count']
-                       * (plan.launches[k]['variant'].S + 8))
-        for slot, k in enumerate(order):
-            L = plan.launches[k]
-            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                           stream=self._streams[slot].h,
-                           dynamic_lds=L['dynamic_lds'])
+        if self._launch_set is None:
+            self._launch_set = LaunchSet()
+        self._launch_set.enqueue(
+            plan, serial=not concurrent or len(plan.launches) < 2)
 
     def synchronize(self):
         runtime.synchronize()

@@ -142,9 +142,9 @@ class ShardedStep:
       result, mirrored entries included.
 
     `enqueue()` issues all of that without a host synchronisation: every
-    solver stream waits (device-side event) for the previous step's join, the
-    null stream -- on which torch runs the collective and the reassembly --
-    waits for every solver stream.  The result stays on the device
+    solver stream waits (device-side event) for the null stream's position at
+    the start of the step, the null stream -- on which torch runs the
+    collective and the reassembly -- waits for every solver stream.  The result stays on the device
     (`values` / `gradient` tensors); `download()` copies it out once.
     """
 
@@ -193,9 +193,8 @@ class ShardedStep:
         local_jobs.flags.writeable = False         # recognised by identity
         self.local_jobs = local_jobs
         self._args = (graphs, jobs, starts, nX, nY, nJ, traits)
-        self.streams, self._done = [], []
-        self._join = runtime.Event()
-        self._first = True
+        from ._backend_hip import LaunchSet
+        self.launch_set = LaunchSet()
         self.bind(node_kernel, edge_kernel, p, q, eps, ftol, gtol, timer)
 
     def bind(self, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
@@ -212,32 +211,16 @@ class ShardedStep:
             gramian_ptr=self.local_out.data_ptr(),
             gradient_ptr=self.local_out.data_ptr()
             + self.capacity * rs.itemsize)
-        while len(self.streams) < len(self.plan.launches):
-            self.streams.append(runtime.Stream())
-            self._done.append(runtime.Event())
 
     def enqueue(self, events=None, serial=False):
         """One step: solver launches, all-gather, reassembly -- all
-        asynchronous.  `events[k] = (start, stop)` are recorded around
-        launch k on the stream it runs on (bench.py's per-kernel timing)."""
+        asynchronous (`LaunchSet` orders the solver streams against the null
+        stream, on which torch runs the collective and the reassembly).
+        `events[k] = (start, stop)` are recorded around launch k on the
+        stream it runs on (bench.py's per-kernel timing)."""
         import torch
         import torch.distributed as dist
-        from ...hip import runtime
-        plan = self.plan
-        for k, L in enumerate(plan.launches):
-            s = None if serial else self.streams[k]
-            if s is not None and not self._first:
-                s.wait_event(self._join)
-            if events is not None:
-                events[k][0].record(s.h if s else None)
-            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                           stream=s.h if s else None,
-                           dynamic_lds=L['dynamic_lds'])
-            if events is not None:
-                events[k][1].record(s.h if s else None)
-            if s is not None:
-                self._done[k].record(s.h)
-                runtime.null_stream_wait_event(self._done[k])
+        self.launch_set.enqueue(self.plan, events, serial)
         with torch.cuda.device(self.device):
             if self.on_device:
                 dist.all_gather_into_tensor(self.gathered, self.local_out,
@@ -249,8 +232,6 @@ class ShardedStep:
                 self.gathered.copy_(g)
             self.result.index_copy_(
                 0, self.t_dst, self.gathered.index_select(0, self.t_src))
-        self._join.record()
-        self._first = False
 
     def synchronize(self):
         import torch

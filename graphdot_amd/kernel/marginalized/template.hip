@@ -15,6 +15,7 @@
 #include <graph.h>
 #include <wave.h>
 #include <mgk_solver.h>
+#include <mgk_oc.h>
 
 using namespace graphdot::numpy_type;
 using namespace graphdot::basekernel;

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Occupancy sweep of the owner-computes variants on the benchmark set:
+isolated launch time of every variant for every amdgpu_waves_per_eu target.
+    python scripts/oc_sweep.py [--f64] [--grad]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tests'))
+import numpy as np
+import cases
+from graphdot_amd.hip import runtime
+from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend, OC_VARIANTS
+
+real = np.float64 if '--f64' in sys.argv else np.float32
+grad = '--grad' in sys.argv
+n = 1000
+G = cases.config3_graphs(n)
+kn, ke, q = cases.config3_kernels()
+job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
+i, j = np.triu_indices(n)
+jobs = np.column_stack((i, j)).astype(np.uint32).ravel().view(job_t)
+starts = np.arange(n + 1, dtype=np.uint32)
+table = {}
+for waves in (1, 2, 3, 4, 5, 6, 8):
+    b = HIPBackend(real=real, occupancy={(1, v.S): waves for v in OC_VARIANTS})
+    k = MarginalizedGraphKernel(kn, ke, q=q, backend=b)
+    plan = b.prepare(G, kn, ke, k.p, k.q, k.eps, k.ftol, k.gtol, jobs, starts,
+                     n, n, k.n_dims, k.traits(symmetric=True, eval_gradient=grad))
+    for L in plan.launches:
+        for _ in range(2):
+            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                           dynamic_lds=L['dynamic_lds'])
+        runtime.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                           dynamic_lds=L['dynamic_lds'])
+        runtime.synchronize()
+        table.setdefault(b.kernel_name(L['variant'], plan.C), {})[waves] = \
+            1e3 * (time.perf_counter() - t0) / 5
+for name, row in table.items():
+    best = min(row, key=row.get)
+    print(f'{name:34s} ' + ' '.join(f'{w}:{t:7.3f}' for w, t in row.items())
+          + f'   best {best}')
+print('sum of best', sum(min(r.values()) for r in table.values()))

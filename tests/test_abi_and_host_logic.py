@@ -107,7 +107,7 @@ def test_job_classification_respects_variant_capacity():
     backend = HIPBackend()
     dgs = [backend._register_graph(g) for g in G]
     i, j = np.triu_indices(len(G))
-    choice, cost, ntask, gbytes = backend.classify(i, j, dgs, 1)
+    choice, cost, ntask, gbytes, NP, _ = backend.classify(i, j, dgs, 1)
     n = np.array([d.n_node for d in dgs])
     nz = np.array([d.n_nz for d in dgs])
     assert np.all(choice >= 0)
@@ -134,6 +134,37 @@ def test_job_classification_respects_variant_capacity():
     small = HIPBackend(variants=[Variant(1, 8, 2)])
     with pytest.raises(NotImplementedError):
         small.classify(i, j, dgs, 1)
+
+
+def test_owner_computes_classification():
+    """Molecular graphs (every degree <= 4) go to the owner-computes variants
+    (mgk_oc.h); the slot count the host assigns by is the walk of the device
+    code: rows sorted by descending degree product, dealt in batches of 64,
+    a batch walks the product of its first row."""
+    from graphdot_amd.kernel.marginalized._backend_hip import OCVariant
+    G = cases.config3_graphs(40, seed=5)
+    backend = HIPBackend()
+    dgs = [backend._register_graph(g) for g in G]
+    i, j = np.triu_indices(len(G))
+    choice, cost, ntask, gbytes, NP, gb_oc = backend.classify(i, j, dgs, 1)
+    assert np.all(choice >= 0)
+    for k, (a, b) in enumerate(zip(i, j)):
+        v = backend.variants[choice[k]]
+        assert isinstance(v, OCVariant) and v.W == 1
+        d1, d2 = dgs[a].adjacency_count, dgs[b].adjacency_count
+        assert max(d1.max(), d2.max()) <= v.D
+        # brute force: stable sort of the rows by descending product with
+        # ties in the rectangle order (d1, d2) ascending, then row-major
+        rows = sorted(((-int(x) * int(y), int(x), int(y))
+                       for x in d1 for y in d2))
+        need = sum(-rows[t][0] for t in range(0, len(rows), 64))
+        assert need <= v.S and len(rows) <= 64 * v.R
+        assert backend.lds_bytes(v, 1, NP[k], gb_oc[k]) <= 160 * 1024
+    # a graph with a node of degree 5 takes the two-stage solver
+    G2 = cases.config2_graphs(4, seed=1)
+    dg2 = [backend._register_graph(g) for g in G2]
+    c2, *_ = backend.classify(np.array([0, 1]), np.array([2, 3]), dg2, 1)
+    assert all(not isinstance(backend.variants[c], OCVariant) for c in c2)
 
 
 def test_partition_is_balanced_and_complete():
