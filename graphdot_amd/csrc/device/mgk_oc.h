@@ -122,6 +122,12 @@ struct oc_solver {
 #endif
     constexpr static int GCH = GD_OC_GCH;       // gathers in flight
     constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4;
+    // The graph-level value K = sum_i pp_i x_i, pp = p1 (x) p2, needs no x:
+    // x = sum_k alpha_k p_k, so K = sum_k alpha_k (pp . p_k) is accumulated
+    // per lane.  Saves the R solution registers (2 R in double) -- for the
+    // uniform starting probability pp is one constant.  Nodal outputs and the
+    // gradient need the solution itself.
+    constexpr static bool KEEP_X = NODAL || C == 2;
     constexpr static int n_jac = PStart::jac_dims + 1 + NodeK::jac_dims + EdgeK::jac_dims;
     constexpr static int off_q = PStart::jac_dims;
     constexpr static int off_v = off_q + 1;
@@ -367,7 +373,9 @@ struct oc_solver {
             }
 
             // ---- rows owned by this thread (sorted order) ----------------------
-            real dg[R], mi[R], x[C][R], r[C][R], p[C][R];
+            real dg[R], mi[R], x[C][KEEP_X ? R : 1], r[C][R], p[C][R];
+            real pp[KEEP_X ? 1 : R];   // p1(i1) p2(i2) of the rows
+            real xs = 0;               // this lane's share of sum_i pp_i x_i
             int paddr[R];
             real rTz = 0;
 #pragma unroll
@@ -384,7 +392,8 @@ struct oc_solver {
                 mi[k] = ok ? vx / dx : real(0);
                 paddr[k] = ok ? (int)__umul24((unsigned)i1, (unsigned)ldp) + i2 : dump;
                 const real b = ok ? dx * bscale : real(0);
-                x[0][k] = 0;
+                if constexpr (KEEP_X) x[0][k] = 0;
+                else pp[k] = real(prm.p_start(v1)) * real(prm.p_start(v2));
                 r[0][k] = b;
                 p[0][k] = b * mi[k];
                 rTz += r[0][k] * p[0][k];
@@ -480,11 +489,17 @@ struct oc_solver {
                 const real alpha = rTz / pAp;
                 real rTr = 0, rTz_next = 0;
                 real z[C][R];
+                if constexpr (!KEEP_X) {
+                    real pdot = 0;   // (dead rows carry p = 0)
+#pragma unroll
+                    for (int k = 0; k < R; ++k) pdot += pp[k] * p[0][k];
+                    xs += alpha * pdot;
+                }
 #pragma unroll
                 for (int k = 0; k < R; ++k)
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
-                        x[c][k] += alpha * p[c][k];
+                        if constexpr (KEEP_X) x[c][k] += alpha * p[c][k];
                         r[c][k] -= alpha * Ap[c][k];
                         z[c][k] = mi[k] * r[c][k];
                         rTr += r[c][k] * r[c][k];
@@ -512,6 +527,20 @@ struct oc_solver {
             const unsigned I1 = prm.starts[job.i], I2 = prm.starts[job.j];
             const bool mirror = (flags & F_SYMMETRIC) && job.i != job.j;
             real ksum = 0;
+            if constexpr (!KEEP_X) {
+                ksum = xs;
+                if (flags & F_LMIN1) {   // minus sum_i pp_i kappa_v(i) q^2/q0^2
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const int pos = k * T + tid;
+                        const bool ok = pos < N;
+                        const unsigned rm = rowmap[ok ? pos : 0];
+                        const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
+                        const node_t v1 = g1.node[i1], v2 = g2.node[i2];
+                        if (ok) ksum -= kappa_v(i1, i2, v1, v2) * bscale * pp[k];
+                    }
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int pos = k * T + tid;
@@ -521,8 +550,8 @@ struct oc_solver {
                 const node_t v1 = g1.node[i1], v2 = g2.node[i2];
                 real xi = x[0][k];
                 if (flags & F_LMIN1) xi -= kappa_v(i1, i2, v1, v2) * bscale;
-                const real pp = real(prm.p_start(v1)) * real(prm.p_start(v2));
-                const real rv = ok ? xi * pp : real(0);
+                const real pp_ = real(prm.p_start(v1)) * real(prm.p_start(v2));
+                const real rv = ok ? xi * pp_ : real(0);
                 ksum += rv;
                 if constexpr (NODAL) if ((flags & F_NODAL) && ok) {
                     const unsigned o1 = g1.perm[i1], o2 = g2.perm[i2];
@@ -535,6 +564,7 @@ struct oc_solver {
                         if (mirror) prm.gramian[(size_t)(I2 + o2) + (size_t)prm.nX * (I1 + o1)] = rv;
                     }
                 }
+            }
             }
             if (!NODAL || !(flags & F_NODAL)) {
                 ksum = block_reduce<real, W>::sum(ksum, red);

@@ -13,16 +13,21 @@ from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend, OC_VARIANT
 
 real = np.float64 if '--f64' in sys.argv else np.float32
 grad = '--grad' in sys.argv
-n = 1000
-G = cases.config3_graphs(n)
-kn, ke, q = cases.config3_kernels()
+if '--config2' in sys.argv:
+    n = 256
+    G = cases.config2_graphs(n, seed=0)
+    kn, ke, q = cases.config2b_kernels()
+else:
+    n = 1000
+    G = cases.config3_graphs(n)
+    kn, ke, q = cases.config3_kernels()
 job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
 i, j = np.triu_indices(n)
 jobs = np.column_stack((i, j)).astype(np.uint32).ravel().view(job_t)
 starts = np.arange(n + 1, dtype=np.uint32)
 table = {}
-for waves in (1, 2, 3, 4, 5, 6, 8):
-    b = HIPBackend(real=real, occupancy={(1, v.S): waves for v in OC_VARIANTS})
+for waves in ((1, 2, 3, 4) if '--config2' in sys.argv else (2, 3, 4, 5, 6)):
+    b = HIPBackend(real=real, occupancy={(v.W, v.S): waves for v in OC_VARIANTS})
     k = MarginalizedGraphKernel(kn, ke, q=q, backend=b)
     plan = b.prepare(G, kn, ke, k.p, k.q, k.eps, k.ftol, k.gtol, jobs, starts,
                      n, n, k.n_dims, k.traits(symmetric=True, eval_gradient=grad))
@@ -36,7 +41,7 @@ for waves in (1, 2, 3, 4, 5, 6, 8):
             runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
                            dynamic_lds=L['dynamic_lds'])
         runtime.synchronize()
-        table.setdefault(b.kernel_name(L['variant'], plan.C), {})[waves] = \
+        table.setdefault(b.kernel_name(L['variant'], plan.C, False, L['tab']), {})[waves] = \
             1e3 * (time.perf_counter() - t0) / 5
 for name, row in table.items():
     best = min(row, key=row.get)
