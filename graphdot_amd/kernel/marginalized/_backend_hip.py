@@ -49,16 +49,16 @@ VARIANTS = [
 #: owner-computes menu, cheapest first: molecular graphs (every degree <= 4)
 #: take the D = 4 kernels, graphs with degrees up to 8 (the Newman-Watts-
 #: Strogatz graphs of configuration 2: 4..7) the D = 8 kernels with 1, 4, 8
-#: or 16 waves per pair
+#: or 16 waves per pair.  S <= 64: larger slot arrays are not promoted to
+#: registers by the compiler (they would live in scratch memory).
 OC_VARIANTS = [
     OCVariant(1, 12, 2, 4), OCVariant(1, 16, 3, 4), OCVariant(1, 20, 3, 4),
     OCVariant(1, 20, 4, 4), OCVariant(1, 24, 4, 4), OCVariant(1, 28, 5, 4),
     OCVariant(1, 28, 6, 4), OCVariant(1, 32, 7, 4), OCVariant(1, 36, 9, 4),
     OCVariant(1, 32, 3, 8), OCVariant(1, 48, 5, 8), OCVariant(1, 64, 9, 8),
     OCVariant(4, 32, 3, 8), OCVariant(4, 48, 4, 8), OCVariant(4, 64, 5, 8),
-    OCVariant(4, 96, 8, 8),
-    OCVariant(8, 64, 4, 8), OCVariant(8, 96, 5, 8),
-    OCVariant(16, 48, 3, 8), OCVariant(16, 64, 4, 8), OCVariant(16, 96, 5, 8),
+    OCVariant(8, 48, 3, 8), OCVariant(8, 64, 4, 8),
+    OCVariant(16, 32, 2, 8), OCVariant(16, 48, 3, 8), OCVariant(16, 64, 3, 8),
 ]
 #: sentinel: the global-memory general solver (any pair size)
 GENERAL = Variant(0, 0, 0)

@@ -31,6 +31,9 @@ for waves in ((1, 2, 3, 4) if '--config2' in sys.argv else (2, 3, 4, 5, 6)):
     k = MarginalizedGraphKernel(kn, ke, q=q, backend=b)
     plan = b.prepare(G, kn, ke, k.p, k.q, k.eps, k.ftol, k.gtol, jobs, starts,
                      n, n, k.n_dims, k.traits(symmetric=True, eval_gradient=grad))
+    for L in plan.pre_launches:        # the table kernel
+        runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
+                       dynamic_lds=L['dynamic_lds'])
     for L in plan.launches:
         for _ in range(2):
             runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],

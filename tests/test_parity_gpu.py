@@ -767,10 +767,13 @@ def test_full_size_gram_matrix_properties(real):
                        rtol=1e-5 if real is np.float32 else 1e-7)
 
 
-def _feature_graphs(seed=12, n_graphs=5):
+def _feature_graphs(seed=12, n_graphs=5, real=np.float32):
     """Small weighted graphs whose nodes carry a scalar `radius`, a category
     and a fixed-length non-negative feature vector `fp` (variable-length
-    attribute on the device), edges a `length`."""
+    attribute on the device), edges a `length`.  With real = float64 the float
+    attributes are stored as float64 columns, so that the Python microkernels
+    of the oracle see the numbers the double build computes on (a float32
+    column makes numpy evaluate `x - y` in float32)."""
     import networkx as nx
     rng = np.random.default_rng(seed)
     out = []
@@ -781,12 +784,17 @@ def _feature_graphs(seed=12, n_graphs=5):
         for v in g.nodes:
             g.nodes[v]['radius'] = float(rng.choice([1.0, 1.5, 2.0, 2.5]))
             g.nodes[v]['category'] = int(rng.integers(1, 4))
-            g.nodes[v]['fp'] = tuple(float(x) for x in
-                                     rng.uniform(0.2, 1.0, size=4))
+            g.nodes[v]['fp'] = np.round(rng.uniform(0.2, 1.0, size=4),
+                                        3).astype(real)
         for e in g.edges:
             g.edges[e]['w'] = float(rng.choice([0.5, 1.0, 2.0]))
             g.edges[e]['length'] = float(rng.uniform(0.5, 2.5))
         out.append(Graph.from_networkx(g, weight='w'))
+    if real is np.float64:
+        for g in out:
+            g.nodes['radius'] = np.asarray(g.nodes['radius'], dtype=real)
+            g.edges['length'] = np.asarray(g.edges['length'], dtype=real)
+            g.edges['!w'] = np.asarray(g.edges['!w'], dtype=real)
     return Graph.unify_datatype(out)
 
 
@@ -802,7 +810,7 @@ def test_rational_quadratic_dotproduct_and_power_microkernels(real):
     from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
     from graphdot_amd.microkernel import (
         RationalQuadratic, DotProduct, Normalize)
-    G = _feature_graphs()
+    G = _feature_graphs(real=real)
     combos = [
         (TensorProduct(radius=RationalQuadratic(1.0, 1.5),
                        category=KroneckerDelta(0.5)),
