@@ -24,7 +24,16 @@ template<int E, class F> __host__ __device__ constexpr inline F ripow(F base) {
 }
 
 __device__ __forceinline__ float rsqrt(float x) { return __frsqrt_rn(x); }
-__device__ __forceinline__ double rsqrt(double x) { return 1.0 / sqrt(x); }
+// (double: under -ffast-math `1.0 / sqrt(x)` becomes a bare v_rsq_f64, good
+// to ~1e-8 only; two Newton steps on the hardware estimate restore double
+// precision)
+__device__ __forceinline__ double rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
 
 // pow / log / exp in the arithmetic of their arguments.  The code generator
 // prints the reference's fast-math float spellings (__powf, __logf, __expf:

@@ -23,7 +23,7 @@ from ...hip import jit, runtime
 from ...microkernel import TensorProduct, Product
 from ...util.iterable import flatten, fold_like
 from ._backend import Backend
-from ._devicegraph import DeviceGraph, GraphArena, class_bytes
+from ._devicegraph import DeviceGraph, GraphArena, class_bytes, pack_many
 
 _TEMPLATE = os.path.join(os.path.dirname(__file__), 'template.hip')
 
@@ -580,9 +580,27 @@ struct ${name}_t : ${name}_theta_t {
                 return max(n, floor)
         return max(1, floor)
 
-    #: measured occupancy targets of the owner-computes variants
-    #: (real, C) -> {(S, R): waves per SIMD}
-    _OC_WAVES = {}
+    #: occupancy targets of the owner-computes variants, the fastest of a
+    #: per-variant sweep on MI355X (scripts/oc_sweep.py: QM7-like set for
+    #: D = 4, configuration 2 for D = 8): (double?, C) -> {(W, S, R, D): waves}
+    _OC_WAVES = {
+        (False, 1): {(1, 12, 2, 4): 6, (1, 16, 3, 4): 6, (1, 20, 3, 4): 6,
+                     (1, 20, 4, 4): 4, (1, 24, 4, 4): 5, (1, 28, 5, 4): 5,
+                     (1, 28, 6, 4): 4, (1, 32, 7, 4): 4, (1, 36, 9, 4): 2,
+                     (1, 32, 3, 8): 2, (1, 48, 5, 8): 2, (1, 64, 9, 8): 2,
+                     (4, 32, 3, 8): 3, (4, 48, 4, 8): 2, (4, 64, 5, 8): 3,
+                     (8, 48, 3, 8): 4, (8, 64, 4, 8): 2, (16, 48, 3, 8): 4,
+                     (16, 64, 3, 8): 4},
+        (True, 1): {(1, 12, 2, 4): 4, (1, 16, 3, 4): 4, (1, 20, 3, 4): 4,
+                    (1, 20, 4, 4): 3, (1, 24, 4, 4): 3, (1, 28, 5, 4): 3,
+                    (1, 28, 6, 4): 3, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2},
+        (False, 2): {(1, 12, 2, 4): 4, (1, 16, 3, 4): 4, (1, 20, 3, 4): 3,
+                     (1, 20, 4, 4): 2, (1, 24, 4, 4): 3, (1, 28, 5, 4): 3,
+                     (1, 28, 6, 4): 2, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2},
+        (True, 2): {(1, 12, 2, 4): 3, (1, 16, 3, 4): 3, (1, 20, 3, 4): 3,
+                    (1, 20, 4, 4): 2, (1, 24, 4, 4): 2, (1, 28, 5, 4): 2,
+                    (1, 28, 6, 4): 2, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2},
+    }
 
     def _oc_waves(self, v, C):
         """Occupancy target of an owner-computes variant: per lane S values +
@@ -590,7 +608,7 @@ struct ${name}_t : ${name}_theta_t {
         the publish address), the gathers in flight and ~24 others; a double
         takes two registers."""
         f64 = np.dtype(self.real) == np.float64
-        hit = self._OC_WAVES.get((f64, C), {}).get((v.S, v.R))
+        hit = self._OC_WAVES.get((f64, C), {}).get(tuple(v))
         if hit:
             return hit
         w = 2 if f64 else 1
@@ -782,20 +800,23 @@ void ${name}(params_t prm) {
                            for g in dgraphs], dtype=np.int64)
         pair_maxdeg = np.maximum(maxdeg[ji], maxdeg[jj])
         oc_slots, hists = {}, {}
+        # `rem`: the jobs without a variant yet -- every test below runs on
+        # that shrinking subset only (most jobs leave in the first variants)
+        rem = np.arange(len(ji))
         for k, v in enumerate(self.variants):
-            todo = choice < 0
-            if not todo.any():
+            if not len(rem):
                 break
             if v == GENERAL:
                 continue
             if isinstance(v, OCVariant):
                 if tab_bytes:           # the table kernels are two-stage only
                     continue
-                fits = (todo & (pair_maxdeg <= v.D) & (N <= 64 * v.W * v.R)
-                        & (NP < 0xFFFF)
-                        & (self.lds_bytes(v, C, NP, gbytes_oc) <= LDS_LIMIT))
+                fits = ((pair_maxdeg[rem] <= v.D) & (N[rem] <= 64 * v.W * v.R)
+                        & (NP[rem] < 0xFFFF))
                 if not fits.any():
                     continue
+                fits &= self.lds_bytes(v, C, NP[rem], gbytes_oc[rem]) \
+                    <= LDS_LIMIT
                 if (v.W, v.D) not in oc_slots:
                     if v.D not in hists:
                         h = np.zeros((len(dgraphs), v.D + 1), dtype=np.int64)
@@ -803,29 +824,41 @@ void ${name}(params_t prm) {
                             if maxdeg[g_] <= v.D:
                                 h[g_] = np.bincount(dg_.adjacency_count,
                                                     minlength=v.D + 1)
-                        hists[v.D] = h
-                    idx = np.flatnonzero(todo & (pair_maxdeg <= v.D))
+                        # the walk depends on the two degree histograms only,
+                        # and a set of graphs has few distinct ones: it is
+                        # evaluated once per pair of distinct histograms
+                        hists[v.D] = np.unique(h, axis=0, return_inverse=True)
+                    H, hid = hists[v.D]
+                    hid = hid.reshape(-1)
+                    idx = rem[pair_maxdeg[rem] <= v.D]
+                    pk = hid[ji[idx]] * len(H) + hid[jj[idx]]
+                    seen = np.zeros(len(H) * len(H), dtype=bool)
+                    seen[pk] = True
+                    upk = np.flatnonzero(seen)
+                    lut = np.zeros(len(H) * len(H), dtype=np.int64)
+                    lut[upk] = self.oc_slots_needed(
+                        H[upk // len(H)], H[upk % len(H)], v.W, v.D)
                     sl = np.full(len(ji), np.iinfo(np.int64).max,
                                  dtype=np.int64)
-                    sl[idx] = self.oc_slots_needed(
-                        hists[v.D][ji[idx]], hists[v.D][jj[idx]], v.W, v.D)
+                    sl[idx] = lut[pk]
                     oc_slots[(v.W, v.D)] = sl
-                fits &= oc_slots[(v.W, v.D)] <= v.S
-                choice[fits] = k
+                fits &= oc_slots[(v.W, v.D)][rem] <= v.S
+                choice[rem[fits]] = k
+                rem = rem[~fits]
                 continue
-            fits = (todo & (NP <= 64 * v.W * v.R) & (NP <= 0xFFFF)
-                    & (self.lds_bytes(v, C, ntask, gbytes, tab_bytes)
-                       <= LDS_LIMIT))
+            fits = (NP[rem] <= 64 * v.W * v.R) & (NP[rem] <= 0xFFFF)
             if not fits.any():
                 continue
+            fits &= self.lds_bytes(v, C, ntask[rem], gbytes[rem], tab_bytes) \
+                <= LDS_LIMIT
             if v.W not in slots:
-                idx = np.flatnonzero(todo)
                 sl = np.full(len(ji), np.iinfo(np.int64).max, dtype=np.int64)
-                sl[idx] = self.slots_needed(nnz1[idx], n2[idx], jj[idx],
+                sl[rem] = self.slots_needed(nnz1[rem], n2[rem], jj[rem],
                                             deg_sorted, v.W)
                 slots[v.W] = sl
-            fits &= slots[v.W] <= v.S
-            choice[fits] = k
+            fits &= slots[v.W][rem] <= v.S
+            choice[rem[fits]] = k
+            rem = rem[~fits]
         if np.any(choice < 0):
             if GENERAL not in self.variants:
                 bad = int(np.argmax(choice < 0))
@@ -846,12 +879,18 @@ void ${name}(params_t prm) {
         tic = timer.tic if timer else (lambda *_: None)
         toc = timer.toc if timer else (lambda *_: None)
         tic('transferring graphs to GPU')
-        dgraphs = []
-        for i, g in enumerate(graphs):
-            dg = self._register_graph(g)
-            if i > 0 and dg.signature != dgraphs[0].signature:
+        # graphs seen for the first time are packed together in one
+        # vectorised pass (_devicegraph.pack_many)
+        key = (self.uuid, np.dtype(self.real).str)
+        new = [g for g in graphs if key not in g.cookie]
+        if new:
+            for g, dg in zip(new, pack_many(new, real=self.real)):
+                g.cookie[key] = dg
+        dgraphs = [g.cookie[key] for g in graphs]
+        sig0 = dgraphs[0].signature
+        for dg in dgraphs:
+            if dg.signature != sig0:
                 self._assert_homogeneous(dgraphs[0], dg)
-            dgraphs.append(dg)
         toc('transferring graphs to GPU')
         if traits.eval_gradient is True and traits.nodal is not False:
             raise NotImplementedError(

@@ -515,17 +515,33 @@ def _label_classes(dgraphs, vfields=None, efields=None, max_classes=255):
             return np.zeros(len(records), np.int64), records[:1]
         raw = np.ascontiguousarray(keys).view(np.uint8).reshape(
             len(keys), keys.dtype.itemsize)
-        _, first, inv = np.unique(raw, axis=0, return_index=True,
-                                  return_inverse=True)
-        return inv.reshape(-1), records[first]
+        if raw.shape[1] <= 8:
+            # keys of up to 8 bytes are numbered as integers (a sort of
+            # 64-bit words instead of a lexicographic sort of byte rows)
+            wide = np.zeros((len(raw), 8), dtype=np.uint8)
+            wide[:, :raw.shape[1]] = raw
+            _, first, inv = np.unique(wide.view(np.uint64).reshape(-1),
+                                      return_index=True, return_inverse=True)
+        else:
+            _, first, inv = np.unique(raw, axis=0, return_index=True,
+                                      return_inverse=True)
+        # representatives as byte rows: fancy indexing of a structured array
+        # copies field by field and leaves its padding bytes undefined
+        rec = np.ascontiguousarray(records).view(np.uint8).reshape(
+            len(records), dt.itemsize)[first]
+        return inv.reshape(-1), np.ascontiguousarray(rec).view(dt).reshape(-1)
 
-    nodes = np.concatenate([
-        g.blob[g.offsets['node']:g.offsets['node']
-               + g.n_node * node_t.itemsize].view(node_t) for g in dgraphs])
-    edges = np.concatenate([
-        g.blob[g.offsets['edge']:g.offsets['edge']
-               + g.n_nz * edge_t.itemsize].view(edge_t)
-        if edge_t.itemsize else np.zeros(g.n_nz, edge_t) for g in dgraphs])
+    def gather(section, count, dt):
+        """all records of one section of every graph, as one array"""
+        if dt.itemsize == 0:
+            return np.zeros(int(sum(count)), dt)
+        raw = np.concatenate([
+            g.blob[g.offsets[section]:g.offsets[section] + c * dt.itemsize]
+            for g, c in zip(dgraphs, count)])
+        return raw.view(dt)
+
+    nodes = gather('node', [g.n_node for g in dgraphs], node_t)
+    edges = gather('edge', [g.n_nz for g in dgraphs], edge_t)
     numbered = number(nodes, vfields)
     if numbered is None:
         return None

@@ -160,11 +160,20 @@ def test_owner_computes_classification():
         need = sum(-rows[t][0] for t in range(0, len(rows), 64))
         assert need <= v.S and len(rows) <= 64 * v.R
         assert backend.lds_bytes(v, 1, NP[k], gb_oc[k]) <= 160 * 1024
-    # a graph with a node of degree 5 takes the two-stage solver
-    G2 = cases.config2_graphs(4, seed=1)
+    # graphs with nodes of degree 5..8 take the D = 8 kernels, and the
+    # two-stage solver when the owner-computes menu is switched off
+    G2 = cases.config2_graphs(4, nmin=8, nmax=24, seed=1)
     dg2 = [backend._register_graph(g) for g in G2]
+    assert max(int(d.adjacency_count.max()) for d in dg2) > 4
+    md = [int(d.adjacency_count.max()) for d in dg2]
     c2, *_ = backend.classify(np.array([0, 1]), np.array([2, 3]), dg2, 1)
-    assert all(not isinstance(backend.variants[c], OCVariant) for c in c2)
+    for c, (a, b) in zip(c2, ((0, 2), (1, 3))):
+        v = backend.variants[c]
+        assert isinstance(v, OCVariant)
+        assert v.D == (8 if max(md[a], md[b]) > 4 else 4)
+    two_stage = HIPBackend(variants=VARIANTS)
+    c3, *_ = two_stage.classify(np.array([0, 1]), np.array([2, 3]), dg2, 1)
+    assert all(not isinstance(two_stage.variants[c], OCVariant) for c in c3)
 
 
 def test_partition_is_balanced_and_complete():

@@ -287,3 +287,40 @@ def test_row_type_cache_follows_graph_mutation():
     assert Graph.has_unified_types([ua, ub]) is True
     Graph.unify_datatype([ga, gb], inplace=True)      # clears the cookies
     assert Graph.has_unified_types([ga, gb]) is True
+
+
+def test_batch_packer_is_byte_identical_to_the_per_graph_packer():
+    """`pack_many` (one vectorised pass over all graphs of a call, SURVEY 8f
+    rank 1; reference: _octilegraph.py:37-177 once per graph) produces the
+    very blobs, permutations and CSR arrays of `DeviceGraph(graph)`, for
+    labeled / weighted / unlabeled graphs, self loops, both arithmetics, and
+    falls back to the per-graph packer for variable-length attributes; the
+    arenas built from them (headers, label classes) are equal byte for
+    byte."""
+    import cases
+    from _fixtures import load, graphs_from
+    from graphdot_amd.kernel.marginalized._devicegraph import (
+        DeviceGraph, GraphArena, pack_many)
+    sets = [cases.config3_graphs(60), cases.config2_graphs(12, seed=3),
+            cases.config1_graphs(), cases.nlw_example_graphs()]
+    M = load('mlgk_cases.json')
+    sets += [graphs_from(M[name]['graphs']) for name in
+             ('unlabeled', 'labeled', 'weighted', 'vario-features')]
+    for G in sets:
+        for real in (np.float32, np.float64):
+            a = pack_many(G, real)
+            b = [DeviceGraph(g, real) for g in G]
+            for x, y in zip(a, b):
+                assert x.signature == y.signature
+                assert x.offsets == y.offsets
+                assert (x.n_node, x.n_nz, x.image_bytes, x.weighted) == \
+                    (y.n_node, y.n_nz, y.image_bytes, y.weighted)
+                assert np.array_equal(x.blob, y.blob)
+                assert np.array_equal(x.perm, y.perm)
+                assert np.array_equal(x.rank, y.rank)
+                assert np.array_equal(x.adjacency_count, y.adjacency_count)
+                assert np.array_equal(x.edge_index, y.edge_index)
+                assert np.array_equal(x.relocs, y.relocs)
+            A, B = GraphArena(a), GraphArena(b)
+            assert np.array_equal(A.relocated(1 << 20), B.relocated(1 << 20))
+            assert (A.classes is None) == (B.classes is None)
