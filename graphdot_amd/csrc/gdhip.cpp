@@ -5,6 +5,8 @@
 // through hipModuleLoadData.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -228,4 +230,85 @@ int gd_event_elapsed_ms(gd_event_t start, gd_event_t stop, float *ms) {
     return 0;
 }
 
+
+// ---- collectives: RCCL, bound at run time ------------------------------------
+// librccl is opened with dlopen on first use (a process that already holds a
+// copy -- PyTorch-ROCm ships one under the same SONAME -- gets that copy), so
+// that the library itself has no link-time dependency on it and single-GPU
+// use never loads it.
+namespace {
+struct rccl_unique_id { char internal[128]; };   // ncclUniqueId (rccl.h)
+struct rccl_api {
+    void *handle = nullptr;
+    int (*get_unique_id)(rccl_unique_id *) = nullptr;
+    int (*comm_init_rank)(void **, int, rccl_unique_id, int) = nullptr;
+    int (*comm_destroy)(void *) = nullptr;
+    int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    const char *(*error_string)(int) = nullptr;
+};
+rccl_api g_rccl;
+
+int rccl_load() {
+    if (g_rccl.handle) return 0;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return fail("gd_comm: librccl.so not found (dlopen)");
+    rccl_api a;
+    a.handle = h;
+    a.get_unique_id = reinterpret_cast<decltype(a.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
+    a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
+    a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    a.all_gather = reinterpret_cast<decltype(a.all_gather)>(dlsym(h, "ncclAllGather"));
+    a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_gather)
+        return fail("gd_comm: librccl.so lacks the ncclAllGather entry points");
+    g_rccl = a;
+    return 0;
+}
+int rccl_fail(int rc, const char *what) {
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "%s: %s (%d)", what,
+                  g_rccl.error_string ? g_rccl.error_string(rc) : "RCCL error", rc);
+    g_err = buf;
+    return rc ? rc : -1;
+}
+}  // namespace
+
+int gd_comm_unique_id(void *id128) {
+    if (!id128) return fail("gd_comm_unique_id: null argument");
+    if (int rc = rccl_load()) return rc;
+    rccl_unique_id id;
+    if (int rc = g_rccl.get_unique_id(&id)) return rccl_fail(rc, "ncclGetUniqueId");
+    std::memcpy(id128, id.internal, sizeof id.internal);
+    return 0;
+}
+
+int gd_comm_init_rank(gd_comm_t *out, int n_ranks, const void *id128, int rank) {
+    if (!out || !id128) return fail("gd_comm_init_rank: null argument");
+    if (int rc = rccl_load()) return rc;
+    rccl_unique_id id;
+    std::memcpy(id.internal, id128, sizeof id.internal);
+    void *comm = nullptr;
+    if (int rc = g_rccl.comm_init_rank(&comm, n_ranks, id, rank)) return rccl_fail(rc, "ncclCommInitRank");
+    *out = reinterpret_cast<gd_comm_t>(comm);
+    return 0;
+}
+
+int gd_comm_destroy(gd_comm_t c) {
+    if (!c || !g_rccl.handle) return 0;
+    if (int rc = g_rccl.comm_destroy(c)) return rccl_fail(rc, "ncclCommDestroy");
+    return 0;
+}
+
+int gd_all_gather(const void *send, void *recv, size_t count, int dtype, gd_comm_t c, gd_stream_t s) {
+    if (!c) return fail("gd_all_gather: null communicator");
+    if (int rc = rccl_load()) return rc;
+    // ncclDataType_t: ncclFloat32 = 7, ncclFloat64 = 8, ncclUint8 = 1 (rccl.h)
+    const int nccl_type = dtype == GD_F64 ? 8 : dtype == GD_F32 ? 7 : dtype == GD_U8 ? 1 : -1;
+    if (nccl_type < 0) return fail("gd_all_gather: dtype must be GD_F32, GD_F64 or GD_U8");
+    if (int rc = g_rccl.all_gather(send, recv, count, nccl_type, c, S(s))) return rccl_fail(rc, "ncclAllGather");
+    return 0;
+}
 }  // extern "C"

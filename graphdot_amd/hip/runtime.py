@@ -67,6 +67,10 @@ SIGNATURES = {
     'gd_event_sync': [_vp],
     'gd_stream_wait_event': [_vp, _vp],
     'gd_event_elapsed_ms': [_vp, _vp, _P(ctypes.c_float)],
+    'gd_comm_unique_id': [_vp],
+    'gd_comm_init_rank': [_P(_vp), ctypes.c_int, _vp, ctypes.c_int],
+    'gd_comm_destroy': [_vp],
+    'gd_all_gather': [_vp, _vp, _sz, ctypes.c_int, _vp, _vp],
 }
 
 
@@ -80,7 +84,7 @@ def build_library(force=False):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '-O2', '-fPIC', '-shared', '-std=c++17', f'-I{INCLUDE}',
-           src, '-o', LIB_PATH]
+           src, '-o', LIB_PATH, '-ldl']
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise HIPError(f'building libgdhip.so failed:\n{r.stderr}')
@@ -333,3 +337,42 @@ def synchronize(stream=None):
         check(lib().gd_device_sync())
     else:
         check(lib().gd_stream_sync(stream))
+
+
+class Communicator:
+    """RCCL communicator of this process (one process per GPU), bound through
+    the C ABI (`gd_comm_*`, include/gdhip.h).  The 128-byte unique id is made
+    by rank 0 (`Communicator.unique_id()`) and handed to every rank out of
+    band; `all_gather` is asynchronous on the given stream."""
+    DTYPES = {'float32': 0, 'float64': 1, 'uint8': 2}
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        check(lib().gd_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, n_ranks, unique_id, rank):
+        ensure_device()
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+        c = ctypes.c_void_p()
+        check(lib().gd_comm_init_rank(ctypes.byref(c), self.n_ranks,
+                                      ctypes.c_char_p(unique_id), self.rank))
+        self.h = c.value
+
+    def all_gather(self, send_ptr, recv_ptr, count, dtype, stream=None):
+        import numpy as np
+        check(lib().gd_all_gather(send_ptr, recv_ptr, int(count),
+                                  self.DTYPES[np.dtype(dtype).name], self.h,
+                                  stream))
+
+    def destroy(self):
+        if getattr(self, 'h', None) and _lib is not None:
+            _lib.gd_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

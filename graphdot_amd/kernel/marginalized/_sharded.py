@@ -126,6 +126,24 @@ def cuda_collective(group=None):
     return parts.get('cuda') == 'nccl'
 
 
+_communicators = {}
+
+
+def _abi_communicator(group, runtime):
+    """The RCCL communicator of this process for `group`, created through the
+    C ABI (one per group, cached): rank 0 makes the unique id, the process
+    group broadcasts it."""
+    import torch.distributed as dist
+    key = id(group) if group is not None else None
+    if key not in _communicators:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [runtime.Communicator.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0)
+                                   if group is not None else 0, group=group)
+        _communicators[key] = runtime.Communicator(world, box[0], rank)
+    return _communicators[key]
+
+
 class ShardedStep:
     """One rank's device-resident evaluation of a pair-sharded Gram matrix
     (+ gradient planes): the single code path of ``bench.py --gpus N`` and of
@@ -150,7 +168,7 @@ class ShardedStep:
 
     def __init__(self, backend, graphs, node_kernel, edge_kernel, p, q, eps,
                  ftol, gtol, jobs, starts, nX, nY, nJ, traits, group=None,
-                 timer=None, shard_plan=None):
+                 timer=None, shard_plan=None, collective='torch'):
         import torch
         import torch.distributed as dist
         from ...hip import runtime
@@ -158,6 +176,15 @@ class ShardedStep:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.on_device = cuda_collective(group)
+        # collective='rccl': the all-gather goes through the C ABI
+        # (gd_all_gather, include/gdhip.h) on a communicator of its own; the
+        # process group only carries the 128-byte unique id to the ranks
+        self.comm = None
+        if collective == 'rccl':
+            self.comm = _abi_communicator(group, runtime)
+            self.on_device = True
+        elif collective != 'torch':
+            raise ValueError(f'collective={collective!r}: "torch" or "rccl"')
         device = runtime.ensure_device(backend.device)
         # the tensors live on the device the *backend* runs on, whatever
         # torch's current device is
@@ -222,7 +249,13 @@ class ShardedStep:
         import torch.distributed as dist
         self.launch_set.enqueue(self.plan, events, serial)
         with torch.cuda.device(self.device):
-            if self.on_device:
+            if self.comm is not None:
+                # null stream: behind the solvers (LaunchSet) and in front of
+                # the reassembly torch enqueues there
+                self.comm.all_gather(
+                    self.local_out.data_ptr(), self.gathered.data_ptr(),
+                    self.local_out.numel(), self.backend.real)
+            elif self.on_device:
                 dist.all_gather_into_tensor(self.gathered, self.local_out,
                                             group=self.group)
             else:
@@ -280,15 +313,18 @@ def distributed_backend(**kwargs):
     downloaded once into the caller's arrays (`ShardedStep`, the code path of
     ``bench.py --gpus N``).  Nodal and diagonal evaluations, and runs without
     a process group, take the single-GPU path.  ``shard_single_rank=True``
-    routes a one-rank group through the sharded path too (tests).  Other
-    keyword arguments as for HIPBackend."""
+    routes a one-rank group through the sharded path too (tests).
+    ``collective='rccl'`` runs the all-gather through the C ABI
+    (``gd_all_gather``) instead of ``torch.distributed``.  Other keyword
+    arguments as for HIPBackend."""
     from ._backend_hip import HIPBackend
 
     class DistributedHIPBackend(HIPBackend):
 
-        def __init__(self, shard_single_rank=False, **kw):
+        def __init__(self, shard_single_rank=False, collective='torch', **kw):
             super().__init__(**kw)
             self.shard_single_rank = shard_single_rank
+            self.collective = collective
             self._shard_plans = {}
             self._steps = {}      # (shard plan, nJ, traits) -> ShardedStep
 
@@ -338,7 +374,7 @@ def distributed_backend(**kwargs):
                 step = self._steps[key] = ShardedStep(
                     self, graphs, node_kernel, edge_kernel, p, q, eps, ftol,
                     gtol, jobs, starts, nX, nY, nJ, traits, timer=timer,
-                    shard_plan=sp)
+                    shard_plan=sp, collective=self.collective)
             else:
                 step.bind(node_kernel, edge_kernel, p, q, eps, ftol, gtol,
                           timer)

@@ -102,6 +102,27 @@ int gd_event_sync(gd_event_t e);
 int gd_stream_wait_event(gd_stream_t s, gd_event_t e);
 int gd_event_elapsed_ms(gd_event_t start, gd_event_t stop, float *ms);
 
+/* ---- collectives: RCCL over xGMI, one process per GPU ---------------------
+ * New capability: the reference has no multi-GPU code.
+ * Pairs are independent, so the only collective of the path is the
+ * all-gather of equal-sized packed result slabs that reassembles the Gram
+ * matrix (graphdot_amd/kernel/marginalized/_sharded.py).  librccl is bound at
+ * run time (dlopen on first use): single-GPU users never load it.
+ *   rank 0:     gd_comm_unique_id(id)  -> broadcast the 128 bytes out of band
+ *               (a file, an environment store, MPI, a torch.distributed store)
+ *   every rank: gd_init(local device); gd_comm_init_rank(&c, n, id, rank)
+ *   per step:   gd_all_gather(slab, gathered, count, GD_F32 | GD_F64, c, stream)
+ * `count` is the number of elements each rank contributes; `recv` holds
+ * n_ranks * count elements, rank r's contribution at offset r * count.  The
+ * call is asynchronous on `s`. */
+typedef struct gd_comm_s *gd_comm_t;         /* ncclComm_t                   */
+enum { GD_F32 = 0, GD_F64 = 1, GD_U8 = 2 };
+int gd_comm_unique_id(void *id128);
+int gd_comm_init_rank(gd_comm_t *out, int n_ranks, const void *id128, int rank);
+int gd_comm_destroy(gd_comm_t c);
+int gd_all_gather(const void *send, void *recv, size_t count, int dtype,
+                  gd_comm_t c, gd_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,12 +97,15 @@ def config2b_kernels():
 _VALENCE = {6: 4, 7: 3, 8: 2, 16: 2}
 
 
-def qm7_like_molecule(rng):
+def qm7_like_molecule(rng, ring_list=False):
     """A random molecule-like graph in the size range of QM7: up to 7 heavy
     atoms (C, N, O, S) joined as a random tree respecting valence, 0-2 ring
     closures, some double/aromatic bonds, then hydrogens on every free
     valence (at most 23 atoms in total).  Node and edge attributes follow the
-    reference's Graph.from_rdkit (graph/_from_rdkit.py:219-243)."""
+    reference's Graph.from_rdkit (graph/_from_rdkit.py:219-243); with
+    `ring_list` every atom also carries the variable-length attribute
+    `ring_list`: the sorted sizes of the rings it lies on, or (0,)
+    (_from_rdkit.py:207-212,228-230)."""
     n_heavy = int(np.clip(round(rng.normal(6.3, 1.0)), 1, 7))
     Z = rng.choice([6, 7, 8, 16], size=n_heavy, p=[0.72, 0.12, 0.14, 0.02])
     Z[0] = 6
@@ -160,13 +163,22 @@ def qm7_like_molecule(rng):
                    hybridization=1, aromatic=False, chiral=0)
         g.add_edge(0, n_heavy, order=1.0, aromatic=False, conjugated=False,
                    stereo=0, ring_stereo=0.0)
+    if ring_list:
+        rings = {v: [] for v in g.nodes}
+        for cycle in nx.cycle_basis(g):
+            for v in cycle:
+                rings[v].append(len(cycle))
+        for v in g.nodes:
+            g.nodes[v]['ring_list'] = tuple(sorted(rings[v])) or (0,)
     return g
 
 
-def config3_graphs(n_graphs=1000, seed=7165):
+def config3_graphs(n_graphs=1000, seed=7165, ring_list=False):
+    """The benchmark set (ring_list=False: scalar attributes only; the same
+    molecules with the variable-length `ring_list` attribute otherwise)."""
     rng = np.random.default_rng(seed)
     return Graph.unify_datatype(
-        [Graph.from_networkx(qm7_like_molecule(rng))
+        [Graph.from_networkx(qm7_like_molecule(rng, ring_list))
          for _ in range(n_graphs)])
 
 

@@ -95,8 +95,15 @@ def _rccl_worker(rank, world, port, tmp):
     k2 = k.clone_with_theta(k.theta + 0.1)
     K3 = k2(G)
     Kxy = k(G[:12], G[12:])
+    # the same all-gather through the C ABI (gd_comm_* / gd_all_gather):
+    # the process group only carries the unique id
+    abi = distributed_backend(device=0, shard_single_rank=True,
+                              collective='rccl')
+    k4 = MarginalizedGraphKernel(knode, kedge, q=q, backend=abi)
+    K4, dK4 = k4(G, eval_gradient=True)
+    assert abi.last_step.comm is not None
     np.savez(os.path.join(tmp, 'rccl.npz'), K=K, K2=K2, dK=dK, Kxy=Kxy, K3=K3,
-             theta=k2.theta)
+             theta=k2.theta, K4=K4, dK4=dK4)
     dist.destroy_process_group()
 
 
@@ -119,6 +126,7 @@ def test_rccl_process_group_of_one_rank(tmp_path):
     assert np.array_equal(r['K'], k(G))
     assert np.array_equal(r['K2'], K2) and np.array_equal(r['dK'], dK)
     assert np.array_equal(r['Kxy'], k(G[:12], G[12:]))
+    assert np.array_equal(r['K4'], K2) and np.array_equal(r['dK4'], dK)
     k.theta = r['theta']
     assert np.array_equal(r['K3'], k(G))
 

@@ -300,3 +300,44 @@ def test_molecular_kernel_normalised_in_a_gpr():
         assert v1 == pytest.approx(v2, rel=1e-5)
         assert np.allclose(g1, g2, rtol=2e-3, atol=1e-4 * np.abs(g2).max())
     assert np.abs(gpr.predict(G) - y).max() < 1.0
+
+
+def test_against_the_reference_regressor():
+    """Objectives, their gradients and the predictions of the reference's own
+    GaussianProcessRegressor (recorded by tests/golden/make_golden_gpr.py from
+    graphdot/model/gaussian_process/gpr.py:62-315 on the same kernel and
+    data): additive / multiplicative regularisation, normalised targets,
+    masked targets.  Tolerance 1e-8 relative (both sides are float64 dense
+    algebra; the reference inverts by Cholesky like this class)."""
+    from _fixtures import load
+    ref = load('gpr_reference.json')
+    X, y = np.array(ref['X']), ref['y']
+    Z, z = np.array(ref['Z']), np.array(ref['z'])
+    theta = np.array(ref['theta'])
+    for c in ref['cases']:
+        yy = list(y)
+        if c['masked']:
+            yy[3] = None
+            yy[17] = None
+        kw = dict(alpha=c['alpha'], normalize_y=c['normalize_y'],
+                  regularization=c['regularization'], device='cpu')
+        g = GaussianProcessRegressor(RBF(1.3, 0.8), **kw)
+        g.X, g.y = X, yy
+        lml, dlml = g.log_marginal_likelihood(theta, eval_gradient=True)
+        loo, dloo = g.squared_loocv_error(theta, eval_gradient=True)
+        assert lml == pytest.approx(c['lml'], rel=1e-8)
+        assert np.allclose(dlml, c['dlml'], rtol=1e-7, atol=1e-9)
+        assert loo == pytest.approx(c['loo'], rel=1e-8)
+        assert np.allclose(dloo, c['dloo'], rtol=1e-7, atol=1e-9)
+        g2 = GaussianProcessRegressor(RBF(1.3, 0.8), **kw)
+        g2.fit(X, yy)
+        mean, std = g2.predict(Z, return_std=True)
+        _, cov = g2.predict(Z, return_cov=True)
+        assert np.allclose(mean, c['mean'], rtol=1e-8, atol=1e-10)
+        assert np.allclose(std, c['std'], rtol=1e-6, atol=1e-9)
+        assert np.allclose(cov, c['cov'], rtol=1e-6, atol=1e-9)
+        g3 = GaussianProcessRegressor(RBF(1.3, 0.8), **kw)
+        g3.fit_loocv(X, yy)
+        lmean, lstd = g3.predict_loocv(Z, z, return_std=True)
+        assert np.allclose(lmean, c['loocv_mean'], rtol=1e-8, atol=1e-10)
+        assert np.allclose(lstd, c['loocv_std'], rtol=1e-6, atol=1e-9)
