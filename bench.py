@@ -184,12 +184,15 @@ def measure_api(graphs, knode, kedge, q, real, device, gradient, n_pairs):
     from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
     from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
     for g in graphs:                      # forget earlier packings
-        g.cookie.clear()
+        for key in [k_ for k_ in g.cookie if k_ != 'rowtypes']:
+            del g.cookie[key]
     backend = HIPBackend(device=device, real=real)
     kernel = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
     t0 = time.perf_counter()
     kernel(graphs, eval_gradient=gradient)
     first = time.perf_counter() - t0
+    # (the code objects of this workload are already loaded in this process:
+    # `first` is graph packing + job layout + uploads + solve + download)
     reps = 5
     t0 = time.perf_counter()
     for _ in range(reps):

@@ -122,6 +122,11 @@ def compile_many(sources, flags=(), max_workers=None):
     sources = list(sources)
     if not sources:
         return []
+    # everything cached (the usual case): no thread pool
+    paths = [os.path.join(CACHE_DIR, cache_key(s, flags) + '.hsaco')
+             for s in sources]
+    if all(os.path.exists(p) and os.path.getsize(p) > 0 for p in paths):
+        return paths
     max_workers = max_workers or min(len(sources), os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=max_workers) as ex:
         return list(ex.map(lambda s: compile_source(s, flags), sources))

@@ -173,6 +173,13 @@ class Layout:
     pass
 
 
+#: code objects loaded in this process, by JIT cache key (shared by backends)
+_MODULES = {}
+#: HIP streams / events are expensive to create (milliseconds each): every
+#: LaunchSet draws from this process-wide pool, in order
+_STREAM_POOL, _EVENT_POOL = [], []
+
+
 class LaunchSet:
     """The streams and events that run the launches of a plan, step after
     step, without a host synchronisation: the launches every solver depends
@@ -203,8 +210,12 @@ class LaunchSet:
                     events[k][1].record()
             return
         while len(self.streams) < n:
-            self.streams.append(runtime.Stream())
-            self.done.append(runtime.Event())
+            k = len(self.streams)
+            if len(_STREAM_POOL) <= k:
+                _STREAM_POOL.append(runtime.Stream())
+                _EVENT_POOL.append(runtime.Event())
+            self.streams.append(_STREAM_POOL[k])
+            self.done.append(_EVENT_POOL[k])
         self.start.record()
         order = sorted(range(n), key=lambda k: -plan.launches[k]['count']
                        * (plan.launches[k]['variant'].S + 8))
@@ -311,7 +322,7 @@ class HIPBackend(Backend):
         if kwargs:
             raise TypeError(f'unknown HIPBackend options {sorted(kwargs)}')
         runtime.lib()                      # fail loudly if the library is absent
-        self._modules = {}                 # (tu key) -> runtime.Module
+        self._modules = _MODULES           # (tu key) -> runtime.Module
         self._arenas = OrderedDict()       # tuple(id(DeviceGraph)) -> (arena, buf)
         self._pool = {}                    # name -> DeviceBuffer (grow-only)
         self._layouts = OrderedDict()      # job-list key -> Layout (LRU)
@@ -691,6 +702,7 @@ void ${name}(params_t prm) {
         )
 
     def _module(self, source):
+        # loaded code objects are shared by every backend of the process
         key = jit.cache_key(source, self.hipcc_extra)
         mod = self._modules.get(key)
         if mod is None:
@@ -751,28 +763,66 @@ void ${name}(params_t prm) {
         the waves."""
         order = sorted(((a, b) for a in range(D + 1) for b in range(D + 1)),
                        key=lambda t: -t[0] * t[1])    # stable: row-major ties
+        ncp = len(order)
         prods = np.array([a * b for a, b in order] + [0], dtype=np.int64)
-        sizes = np.stack([hist1[:, a] * hist2[:, b] for a, b in order], axis=1)
+        sizes = hist1[:, [a for a, _ in order]] * hist2[:, [b for _, b in order]]
         cum = np.cumsum(sizes, axis=1)
+        n = len(cum)
+        if n == 0:
+            return np.zeros(0, dtype=np.int64)
         N = cum[:, -1]
         T = 64 * W
-        nb = int(-(-N.max() // T)) if len(N) else 0
-        worst = np.zeros(len(N), dtype=np.int64)
+        nb = int(-(-N.max() // T))
+        # rectangle of the first row of every (wave, batch): one sorted search
+        # over all jobs at once (row r of `cum` shifted by r * stride)
+        stride = int(max(N.max(), nb * T)) + 1
+        shift = np.arange(n, dtype=np.int64) * stride
+        flat = (cum + shift[:, None]).ravel()
+        worst = np.zeros(n, dtype=np.int64)
         for w in range(W):
-            total = np.zeros(len(N), dtype=np.int64)
-            for k in range(nb):
-                first = k * T + 64 * w
-                live = first < N
-                if not live.any():
-                    break
-                c = (cum <= first).sum(axis=1)     # rectangle of that row
-                total += np.where(live, prods[np.minimum(c, len(order))], 0)
-            worst = np.maximum(worst, total)
+            first = np.arange(nb, dtype=np.int64) * T + 64 * w
+            c = np.searchsorted(flat, (first[None, :] + shift[:, None]).ravel(),
+                                side='right').reshape(n, nb) \
+                - (np.arange(n, dtype=np.int64) * ncp)[:, None]
+            live = first[None, :] < N[:, None]
+            trip = np.where(live, prods[np.minimum(c, ncp)], 0)
+            worst = np.maximum(worst, trip.sum(axis=1))
         return worst
 
     def classify(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False):
-        """Assign every job the cheapest solver variant it fits.
-        Returns (variant_index[n_jobs], cost[n_jobs])."""
+        """Assign every job the cheapest solver variant it fits.  Returns
+        (variant index, cost, stage-1 tasks, image bytes, padded rows, image
+        bytes incl. class ids) per job.
+
+        Everything the assignment looks at -- node and nonzero counts, image
+        sizes, the slot walks -- is a function of the two graphs' degree
+        histograms (nodes are stored by descending degree) and image sizes,
+        and a set of graphs has few distinct ones (about 150 among the 1000
+        QM7-like molecules): large job lists are classified once per pair of
+        graph classes and looked up."""
+        ji, jj = np.asarray(ji, dtype=np.int64), np.asarray(jj, dtype=np.int64)
+        if len(ji) < 4096:
+            return self._classify_pairs(ji, jj, dgraphs, C, tab_bytes, gtab)
+        width = max(g.max_degree for g in dgraphs) + 1
+        key = np.zeros((len(dgraphs), width + 1), dtype=np.int64)
+        for k, g in enumerate(dgraphs):
+            key[k, :width] = np.bincount(g.adjacency_count, minlength=width)
+            key[k, width] = g.image_bytes
+        _, rep, cid = np.unique(key, axis=0, return_index=True,
+                                return_inverse=True)
+        cid, nc = cid.reshape(-1), len(rep)
+        pk = cid[ji] * nc + cid[jj]
+        seen = np.zeros(nc * nc, dtype=bool)
+        seen[pk] = True
+        upk = np.flatnonzero(seen)
+        out = self._classify_pairs(rep[upk // nc], rep[upk % nc], dgraphs, C,
+                                   tab_bytes, gtab)
+        pos = np.zeros(nc * nc, dtype=np.int64)
+        pos[upk] = np.arange(len(upk))
+        sel = pos[pk]
+        return tuple(a[sel] for a in out)
+
+    def _classify_pairs(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False):
         n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
         n_nz = np.array([g.n_nz for g in dgraphs], dtype=np.int64)
         width = int(n_node.max())
@@ -796,8 +846,7 @@ void ${name}(params_t prm) {
         # the owner-computes solvers with global tables stage the class ids
         image_oc = image + class_bytes(n_node, n_nz) if gtab else image
         gbytes_oc = np.maximum(image_oc[ji], image_oc[jj])
-        maxdeg = np.array([int(g.adjacency_count.max()) if g.n_node else 0
-                           for g in dgraphs], dtype=np.int64)
+        maxdeg = np.array([g.max_degree for g in dgraphs], dtype=np.int64)
         pair_maxdeg = np.maximum(maxdeg[ji], maxdeg[jj])
         oc_slots, hists = {}, {}
         # `rem`: the jobs without a variant yet -- every test below runs on

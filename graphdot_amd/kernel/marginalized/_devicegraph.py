@@ -272,6 +272,16 @@ class DeviceGraph:
 
     # -- reference-compatible read-only views ---------------------------------
     @property
+    def max_degree(self):
+        """Largest adjacency count of a node (cached)."""
+        try:
+            return self._max_degree
+        except AttributeError:
+            self._max_degree = int(self.adjacency_count.max()) \
+                if self.n_node else 0
+            return self._max_degree
+
+    @property
     def state(self):
         raise AttributeError(
             'DeviceGraph has no absolute-address state; headers are produced '
@@ -457,6 +467,8 @@ def pack_many(graphs, real=np.float32):
     signature = (weighted, str(node_t), str(edge_t))
     names = SECTIONS
     edge0 = np.concatenate(([0], np.cumsum(m)))
+    maxdeg = np.maximum.reduceat(count_s, node0[:-1]).tolist() \
+        if Nn else [0] * G
     offs_l = [o.tolist() for o in offs]
     for b_, k in enumerate(batch):
         dg = DeviceGraph.__new__(DeviceGraph)
@@ -474,6 +486,7 @@ def pack_many(graphs, real=np.float32):
         dg.offsets = {name: offs_l[s_][b_] for s_, name in enumerate(names)}
         dg.image_bytes = _pad(dg.offsets['perm'] + 2 * dg.n_node)
         dg.relocs = np.zeros(0, dtype=np.int64)
+        dg._max_degree = int(maxdeg[b_])
         dg.blob = buf[int(blob0[b_]):int(blob0[b_ + 1])]
         out[k] = dg
     return out
