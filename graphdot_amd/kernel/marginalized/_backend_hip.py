@@ -800,9 +800,16 @@ void ${name}(params_t prm) {
         and a set of graphs has few distinct ones (about 150 among the 1000
         QM7-like molecules): large job lists are classified once per pair of
         graph classes and looked up."""
+        sel, out = self._classify_classes(ji, jj, dgraphs, C, tab_bytes, gtab)
+        return out if sel is None else tuple(a[sel] for a in out)
+
+    def _classify_classes(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False):
+        """(sel, per-class-pair results): job t has the results of class pair
+        sel[t]; sel is None for short job lists (results are per job)."""
         ji, jj = np.asarray(ji, dtype=np.int64), np.asarray(jj, dtype=np.int64)
         if len(ji) < 4096:
-            return self._classify_pairs(ji, jj, dgraphs, C, tab_bytes, gtab)
+            return None, self._classify_pairs(ji, jj, dgraphs, C, tab_bytes,
+                                              gtab)
         width = max(g.max_degree for g in dgraphs) + 1
         key = np.zeros((len(dgraphs), width + 1), dtype=np.int64)
         for k, g in enumerate(dgraphs):
@@ -810,17 +817,16 @@ void ${name}(params_t prm) {
             key[k, width] = g.image_bytes
         _, rep, cid = np.unique(key, axis=0, return_index=True,
                                 return_inverse=True)
-        cid, nc = cid.reshape(-1), len(rep)
-        pk = cid[ji] * nc + cid[jj]
+        cid, nc = cid.reshape(-1).astype(np.int32), len(rep)
+        pk = cid[ji] * np.int32(nc) + cid[jj]
         seen = np.zeros(nc * nc, dtype=bool)
         seen[pk] = True
         upk = np.flatnonzero(seen)
         out = self._classify_pairs(rep[upk // nc], rep[upk % nc], dgraphs, C,
                                    tab_bytes, gtab)
-        pos = np.zeros(nc * nc, dtype=np.int64)
-        pos[upk] = np.arange(len(upk))
-        sel = pos[pk]
-        return tuple(a[sel] for a in out)
+        pos = np.zeros(nc * nc, dtype=np.int32)
+        pos[upk] = np.arange(len(upk), dtype=np.int32)
+        return pos[pk], out
 
     def _classify_pairs(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False):
         n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
@@ -961,27 +967,47 @@ void ${name}(params_t prm) {
         jobs = np.ascontiguousarray(jobs)
         ji = jobs['i'].astype(np.int64)
         jj = jobs['j'].astype(np.int64)
-        choice, cost, ntask, gbytes, NP, gbytes_oc = self.classify(
-            ji, jj, dgraphs, C, tab_bytes, gtab)
+        sel, (choice, cost, ntask, gbytes, NP, gbytes_oc) = \
+            self._classify_classes(ji, jj, dgraphs, C, tab_bytes, gtab)
+        # Launch order: by variant, then descending cost, then job index.
+        # `choice` ... `gbytes_oc` are per class pair (or per job when sel is
+        # None); the jobs are ordered by the rank of their class pair with one
+        # stable sort of small integers, and every per-launch maximum is taken
+        # over class pairs.
+        rank_of = np.empty(len(choice), dtype=np.int64)
+        by_rank = np.lexsort((-cost, choice))
+        # class pairs of equal (variant, cost) share a rank: their jobs stay
+        # in job order, as if every job had been sorted by itself
+        step = np.ones(len(choice), dtype=np.int64)
+        step[1:] = (choice[by_rank[1:]] != choice[by_rank[:-1]]) | \
+            (cost[by_rank[1:]] != cost[by_rank[:-1]])
+        rank_of[by_rank] = np.cumsum(step) - 1
+        if sel is None:
+            order_all = by_rank.astype(np.uint32)   # (lexsort is stable)
+            members = np.ones(len(choice), dtype=np.int64)
+        else:
+            rank = rank_of[sel]
+            rank = rank.astype(np.uint16 if len(choice) <= 0xFFFF
+                               else np.uint32)
+            order_all = np.argsort(rank, kind='stable').astype(np.uint32)
+            members = np.bincount(sel, minlength=len(choice))
         used = sorted(set(choice.tolist()))
         rsize = np.dtype(self.real).itemsize
         n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
-        order_all = np.empty(len(jobs), dtype=np.uint32)
         launches, cursor = [], 0
         for k in used:
             v = self.variants[k]
-            idx = np.flatnonzero(choice == k)
-            idx = idx[np.argsort(-cost[idx], kind='stable')]
-            order_all[cursor:cursor + len(idx)] = idx.astype(np.uint32)
+            idx = np.flatnonzero(choice == k)      # class pairs (or jobs)
+            count = int(members[idx].sum())
             if v == GENERAL:
                 # one workgroup per pair, CG vectors + U in global scratch
-                N_ = n_node[ji[idx]] * n_node[jj[idx]]
-                per_wg = int(((3 * N_ + ntask[idx]) * C).max())
+                # (rows N <= padded rows NP)
+                per_wg = int(((3 * NP[idx] + ntask[idx]) * C).max())
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=per_wg, gcap=0,
-                    dynamic_lds=0, count=len(idx), grid=None,
+                    dynamic_lds=0, count=count, grid=None,
                     threads=GENERAL_THREADS, per_wg=per_wg))
-                cursor += len(idx)
+                cursor += count
                 continue
             if isinstance(v, OCVariant):
                 # one pair per workgroup; dynamic LDS: p | row sums | row map
@@ -992,10 +1018,10 @@ void ${name}(params_t prm) {
                 dyn = (pcap + NR) * C * rsize + 4 * NR + 2 * gcap
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=pcap, gcap=gcap,
-                    dynamic_lds=dyn, count=len(idx),
-                    grid=int(max(1, -(-len(idx) // self.jobs_per_unit))),
+                    dynamic_lds=dyn, count=count,
+                    grid=int(max(1, -(-count // self.jobs_per_unit))),
                     threads=64 * v.W, tab=gtab))
-                cursor += len(idx)
+                cursor += count
                 continue
             wpb = WPB1 if v.W == 1 else 1
             threads = 64 * v.W * wpb
@@ -1006,14 +1032,14 @@ void ${name}(params_t prm) {
             # multi-GPU run) still covers the chip.  Measured: 1 pair per wave
             # = 8 per wave + 1 % on 500 500 pairs, + 28 % on 61 000.
             per_unit = self.jobs_per_unit
-            grid = int(max(1, -(-len(idx) // (wpb * per_unit))))
+            grid = int(max(1, -(-count // (wpb * per_unit))))
             ucap = int(-(-ntask[idx].max() // 64) * 64) + 64   # + zero pad
             gcap = int(-(-gbytes[idx].max() // 16) * 16)
             dyn = (ucap * C * rsize + 2 * gcap) * wpb + tab_bytes
             launches.append(dict(variant=v, k=k, offset=cursor, ucap=ucap,
-                                 gcap=gcap, dynamic_lds=dyn, count=len(idx),
+                                 gcap=gcap, dynamic_lds=dyn, count=count,
                                  grid=grid, threads=threads))
-            cursor += len(idx)
+            cursor += count
         return jobs, used, order_all, launches
 
     def _sources(self, used, node_kernel, edge_kernel, p, dgraphs, C, nodal,
