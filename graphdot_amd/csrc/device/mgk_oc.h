@@ -105,9 +105,36 @@ __device__ __forceinline__ void fill_tables(params_t<real, Graph, NodeK, EdgeK, 
     }
 }
 
-template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB, class Graph, class NodeK, class EdgeK, class PStart>
+// Kernel parameters of the nodal finite-difference gradient solver (NGRAD):
+// the common block plus the perturbed hyperparameter sets
+// state(theta_j e^{+eps}), state(theta_j e^{-eps}) of every node / edge
+// hyperparameter, their unperturbed values and q e^{+-eps} -- the reference's
+// node_kernel_diff_grid / edge_kernel_diff_grid / *_flat_theta __constant__
+// symbols (template.cu:17-27, _backend_cuda.py:230-245,318-340) as kernel
+// arguments.
+template<class real, class Graph, class NodeK, class EdgeK, class PStart>
+struct params_fd_t {
+    params_t<real, Graph, NodeK, EdgeK, PStart> base;
+    real q_plus, q_minus;
+    real node_theta[NodeK::jac_dims > 0 ? NodeK::jac_dims : 1];
+    real edge_theta[EdgeK::jac_dims > 0 ? EdgeK::jac_dims : 1];
+    NodeK node_diff[NodeK::jac_dims > 0 ? 2 * NodeK::jac_dims : 1];
+    EdgeK edge_diff[EdgeK::jac_dims > 0 ? 2 * EdgeK::jac_dims : 1];
+};
+
+// NGRAD: nodal outputs with their Jacobian as the reference defines it
+// (template.cu:226-418): d/dp analytic, d/dq, d/d(node theta), d/d(edge theta)
+// by central differences of re-solves at exp(log(theta) +- eps), every
+// re-solve warm-started from the unperturbed solution and stopped at
+// sqrt(rTr) < gtol N -- here in the same launch, right after the solve of the
+// pair, instead of 2 (n_theta + 1) further launches.
+template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB, bool NGRAD, class Graph, class NodeK, class EdgeK, class PStart>
 struct oc_solver {
     using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
+    using PF = std::conditional_t<NGRAD, params_fd_t<real, Graph, NodeK, EdgeK, PStart>, P>;
+    __device__ static __forceinline__ P const &common(P const &p) { return p; }
+    __device__ static __forceinline__ P const &common(params_fd_t<real, Graph, NodeK, EdgeK, PStart> const &p) { return p.base; }
+    static_assert(!NGRAD || (C == 1 && NODAL && !TAB), "the nodal gradient solver is a value solver with nodal output and direct microkernel evaluation");
     using node_t = typename Graph::node_t;
     using edge_t = typename Graph::edge_t;
     constexpr static int T = 64 * W;            // threads per pair (= per workgroup)
@@ -146,7 +173,8 @@ struct oc_solver {
         int i1, i2, rs1, rs2, d1, d2, prod;
     };
 
-    __device__ static __forceinline__ void run(P const &prm, lds_t &lds, real *dyn) {
+    __device__ static __forceinline__ void run(PF const &full, lds_t &lds, real *dyn) {
+        P const &prm = common(full);
         const int lane = wave::laneid();
         const int tid = (W == 1) ? lane : (int)threadIdx.x;
         const int wv = (W == 1) ? 0 : uni((int)(threadIdx.x / 64));
@@ -578,6 +606,211 @@ struct oc_solver {
                         if (mirror) prm.gramian[(size_t)I2 + (size_t)prm.nX * I1] = ksum;
                     }
                 }
+            }
+
+            // ---- nodal Jacobian by warm-started finite differences -------------
+            if constexpr (NGRAD) {
+                const size_t plane = (flags & F_DIAGONAL) ? (size_t)prm.nX
+                                                          : (size_t)prm.nX * prm.nY;
+                // J[row of the output, column col] = v for the rows of this lane
+                auto write_column = [&](int col, real const (&v)[R]) {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const int pos = k * T + tid;
+                        if (pos < N) {
+                            const unsigned rm = rowmap[pos];
+                            const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
+                            const unsigned o1 = g1.perm[i1], o2 = g2.perm[i2];
+                            if (flags & F_DIAGONAL) {
+                                if (o1 == o2) prm.gradient[(size_t)(I1 + o1) + plane * col] = v[k];
+                            } else {
+                                prm.gradient[(size_t)(I1 + o1) + (size_t)prm.nX * (I2 + o2) + plane * col] = v[k];
+                                if (mirror)
+                                    prm.gradient[(size_t)(I2 + o2) + (size_t)prm.nX * (I1 + o1) + plane * col] = v[k];
+                            }
+                        }
+                    }
+                };
+                // start-probability columns: analytic, on the (lmin-corrected)
+                // output like the reference (template.cu:258-284 after :134-142)
+                real ppr[R];
+                {
+                    real col[PStart::jac_dims > 0 ? PStart::jac_dims : 1][R];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const int pos = k * T + tid;
+                        const bool ok = pos < N;
+                        const unsigned rm = rowmap[ok ? pos : 0];
+                        const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
+                        const node_t v1 = g1.node[i1], v2 = g2.node[i2];
+                        const real p1 = prm.p_start(v1), p2 = prm.p_start(v2);
+                        ppr[k] = ok ? p1 * p2 : real(0);
+                        real xi = x[0][k];
+                        if (flags & F_LMIN1) xi -= kappa_v(i1, i2, v1, v2) * bscale;
+                        auto dp1 = prm.p_start._j_a_c_o_b_i_a_n_(v1);
+                        auto dp2 = prm.p_start._j_a_c_o_b_i_a_n_(v2);
+#pragma unroll
+                        for (int j = 0; j < PStart::jac_dims; ++j)
+                            col[j][k] = xi * (p1 * real(dp2[j]) + p2 * real(dp1[j]));
+                    }
+#pragma unroll
+                    for (int j = 0; j < PStart::jac_dims; ++j) write_column(j, col[j]);
+                }
+                real x0[R], bv[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) x0[k] = x[0][k];
+
+                // y[k] = sum over the slots of row batch k of val * (vector in lp)
+                auto matvec = [&](real (&y)[R]) {
+                    real acc = 0;
+                    int kb = 0;
+#pragma unroll
+                    for (int s0 = 0; s0 < S; s0 += GCH) {
+                        if (s0 >= n_slots) break;
+                        real g[GCH];
+#pragma unroll
+                        for (int jj = 0; jj < GCH; ++jj)
+                            g[jj] = (s0 + jj < S) ? lp[adr[s0 + jj < S ? s0 + jj : 0]] : real(0);
+#pragma unroll
+                        for (int jj = 0; jj < GCH; ++jj) {
+                            const int s = s0 + jj;
+                            if (s < S) {
+                                acc += val[s] * g[jj];
+                                if ((fm[s / 32] >> (s % 32)) & 1u) {
+                                    lY[kb * T + tid] = acc;
+                                    acc = 0;
+                                    ++kb;
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < R; ++k) y[k] = lY[k * T + tid];
+                };
+                auto publish1 = [&](real const (&v)[R]) {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) lp[paddr[k]] = v[k];
+                };
+                // rows of the system for node microkernel `nk` and stopping
+                // probability qv: diagonal, its inverse, right-hand side
+                // (q0 moves with q: b = Dx, template.cu:292-300)
+                auto set_rows = [&](auto const &nk, real qv) {
+                    const real s = real(1) / ((real(1) - qv) * (real(1) - qv));
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const int pos = k * T + tid;
+                        const bool ok = pos < N;
+                        const unsigned rm = rowmap[ok ? pos : 0];
+                        const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
+                        const real dx = real(g1.degree[i1]) * real(g2.degree[i2]) * s;
+                        const real vx = real(nk(g1.node[i1], g2.node[i2]));
+                        dg[k] = ok ? dx / vx : real(0);
+                        mi[k] = ok ? vx / dx : real(0);
+                        bv[k] = ok ? dx * bscale : real(0);
+                    }
+                };
+                // slot values for edge microkernel `ek`
+                auto set_vals = [&](auto const &ek) {
+                    int kb = 0, j = 0, ja = 0, jb = 0;
+                    row_t cur = open_row(0);
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        if (s < n_slots) {
+                            const bool ok = j < cur.prod;
+                            const int a = ok ? cur.rs1 + ja : 0, b = ok ? cur.rs2 + jb : 0;
+                            const real e = ek(g1.edge[a], g2.edge[b]);
+                            val[s] = ok ? e : real(0);
+                            ++j;
+                            ++jb;
+                            if (jb >= cur.d2) {
+                                jb = 0;
+                                ++ja;
+                            }
+                            if ((fm[s / 32] >> (s % 32)) & 1u) {
+                                ++kb;
+                                j = ja = jb = 0;
+                                cur = open_row(kb);
+                            }
+                        }
+                    }
+                };
+                // PCG on the current (dg, mi, val, bv), warm-started from xw
+                const real gt = prm.gtol * real(N), gt2 = gt * gt;
+                auto pcg_warm = [&](real (&xw)[R]) {
+                    real rr[R], pv[R], y[R];
+                    job_sync<W>();
+                    publish1(xw);
+                    job_sync<W>();
+                    matvec(y);
+                    real rz = 0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        rr[k] = bv[k] - (dg[k] * xw[k] - y[k]);
+                        pv[k] = mi[k] * rr[k];
+                        rz += rr[k] * pv[k];
+                    }
+                    rz = block_reduce<real, W>::sum(rz, red);
+                    for (unsigned itw = 0; itw < (unsigned)N && rz != real(0); ++itw) {
+                        job_sync<W>();
+                        publish1(pv);
+                        job_sync<W>();
+                        matvec(y);
+                        real pAp = 0;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            y[k] = dg[k] * pv[k] - y[k];
+                            pAp += pv[k] * y[k];
+                        }
+                        pAp = block_reduce<real, W>::sum(pAp, red);
+                        if (pAp == real(0)) break;
+                        const real alpha = rz / pAp;
+                        real rTr = 0, rz_next = 0;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            xw[k] += alpha * pv[k];
+                            rr[k] -= alpha * y[k];
+                            rTr += rr[k] * rr[k];
+                            rz_next += rr[k] * rr[k] * mi[k];
+                        }
+                        block_reduce<real, W>::sum2(rTr, rz_next, red);
+                        if (rTr < gt2) break;
+                        const real beta = rz_next / rz;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) pv[k] = mi[k] * rr[k] + beta * pv[k];
+                        rz = rz_next;
+                    }
+                };
+                // one central difference: solve(+), solve(-), write the column
+                auto difference = [&](int col, real denom, auto &&perturb_plus, auto &&perturb_minus) {
+                    real xa[R], xb[R];
+                    perturb_plus();
+#pragma unroll
+                    for (int k = 0; k < R; ++k) xa[k] = x0[k];
+                    pcg_warm(xa);
+                    perturb_minus();
+#pragma unroll
+                    for (int k = 0; k < R; ++k) xb[k] = x0[k];
+                    pcg_warm(xb);
+                    const real inv = real(1) / denom;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) xa[k] = (xa[k] - xb[k]) * inv * ppr[k];
+                    write_column(col, xa);
+                };
+                // d/dq
+                difference(off_q, real(2) * prm.eps * q,
+                           [&] { set_rows(prm.node_kernel, full.q_plus); },
+                           [&] { set_rows(prm.node_kernel, full.q_minus); });
+                // d/d(node hyperparameters)
+                for (int j = 0; j < NodeK::jac_dims; ++j)
+                    difference(off_v + j, real(2) * prm.eps * full.node_theta[j],
+                               [&] { set_rows(full.node_diff[2 * j], q); },
+                               [&] { set_rows(full.node_diff[2 * j + 1], q); });
+                // d/d(edge hyperparameters)
+                if constexpr (EdgeK::jac_dims > 0) set_rows(prm.node_kernel, q);
+                for (int j = 0; j < EdgeK::jac_dims; ++j)
+                    difference(off_e + j, real(2) * prm.eps * full.edge_theta[j],
+                               [&] { set_vals(full.edge_diff[2 * j]); },
+                               [&] { set_vals(full.edge_diff[2 * j + 1]); });
             }
 
             // ---- analytic gradient (graph-level), marginalized_kernel.h:806-997

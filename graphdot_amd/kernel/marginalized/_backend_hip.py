@@ -163,6 +163,11 @@ def pack_theta(obj, real):
 # --------------------------------------------------------------------------
 # backend
 # --------------------------------------------------------------------------
+class NotOwnerComputes(Exception):
+    """Some pair of the call does not fit an owner-computes solver variant
+    (raised when a feature only those solvers have was asked for)."""
+
+
 class Plan:
     """Everything resident on the device for one kernel evaluation."""
     pass
@@ -313,6 +318,8 @@ class HIPBackend(Backend):
             raise ValueError(f'tables={tables!r}: False, "lds" or "global"')
         self.tables = tables
         self._launch_set = None
+        self.nodal_gradient_in_kernel = bool(kwargs.pop(
+            'nodal_gradient_in_kernel', True))
         if self.occupancy is None and os.environ.get('GD_OCCUPANCY'):
             # e.g. GD_OCCUPANCY="1:16:5,1:24:4"  (W:S:waves)
             self.occupancy = {
@@ -524,7 +531,24 @@ struct ${name}_t : ${name}_theta_t {
             ('p_start', theta(p)),
         ], align=True)
 
-    def kernel_name(self, v, C, nodal=False, tab=False):
+    def _params_fd_dtype(self, node_kernel, edge_kernel, p):
+        """Kernel arguments of the nodal finite-difference gradient solver:
+        graphdot::mgk::params_fd_t (mgk_oc.h)."""
+        def theta(obj):
+            dt = widen_theta(obj.dtype, self.real)
+            return dt if dt.itemsize else np.dtype(np.uint8)
+        nv = len(node_kernel.gen_expr('x1', 'x2')[1])
+        ne = len(edge_kernel.gen_expr('x1', 'x2')[1])
+        return np.dtype([
+            ('base', self._params_dtype(node_kernel, edge_kernel, p)),
+            ('q_plus', self.real), ('q_minus', self.real),
+            ('node_theta', self.real, (max(nv, 1),)),
+            ('edge_theta', self.real, (max(ne, 1),)),
+            ('node_diff', theta(node_kernel), (max(2 * nv, 1),)),
+            ('edge_diff', theta(edge_kernel), (max(2 * ne, 1),)),
+        ], align=True)
+
+    def kernel_name(self, v, C, nodal=False, tab=False, ngrad=False):
         """Entry point name: arithmetic, solver variant, flavour."""
         f = 'f64' if np.dtype(self.real) == np.float64 else 'f32'
         if v == GENERAL:
@@ -533,7 +557,8 @@ struct ${name}_t : ${name}_theta_t {
             return f'mgk_{f}_tables_C{C}'
         if isinstance(v, OCVariant):
             return f'mgk_{f}_oc{v.D}_W{v.W}_S{v.S}_R{v.R}_C{C}' + \
-                ('_nodal' if nodal else '') + ('_tab' if tab else '')
+                ('_nodal' if nodal else '') + ('_tab' if tab else '') + \
+                ('_ngrad' if ngrad else '')
         return f'mgk_{f}_W{v.W}_S{v.S}_R{v.R}_C{C}' + \
             ('_nodal' if nodal else '') + ('_tab' if tab else '')
 
@@ -613,24 +638,24 @@ struct ${name}_t : ${name}_theta_t {
                     (1, 28, 6, 4): 2, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2},
     }
 
-    def _oc_waves(self, v, C):
+    def _oc_waves(self, v, C, ngrad=False):
         """Occupancy target of an owner-computes variant: per lane S values +
         S gather indices, 6 registers per row (x, r, p, diagonal, its inverse,
         the publish address), the gathers in flight and ~24 others; a double
         takes two registers."""
         f64 = np.dtype(self.real) == np.float64
         hit = self._OC_WAVES.get((f64, C), {}).get(tuple(v))
-        if hit:
+        if hit and not ngrad:
             return hit
         w = 2 if f64 else 1
         need = (w * C + 1) * 0 + v.S * (w + 1) + v.R * (5 * w * C + 1) \
-            + 8 * w * C + 24
+            + 8 * w * C + 24 + (6 * w * v.R if ngrad else 0)
         for n in (8, 6, 5, 4, 3, 2):
             if need <= (512 // n) // 8 * 8:
                 return n
         return 1
 
-    def _entry_point(self, v, C, nodal=False, tab=False):
+    def _entry_point(self, v, C, nodal=False, tab=False, ngrad=False):
         if v == TABLES:
             return Template(r'''
 extern "C" __global__ __launch_bounds__(256)
@@ -642,17 +667,23 @@ void ${name}(params_t prm) {
             return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
 __attribute__((amdgpu_waves_per_eu(${waves})))
-void ${name}(params_t prm) {
+void ${name}(${params} prm) {
     using solver = graphdot::mgk::oc_solver<real_t, ${S}, ${R}, ${W}, ${C},
-        ${nodal}, ${D}, ${tab}, graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
+        ${nodal}, ${D}, ${tab}, ${ngrad}, graph_t, node_kernel_t, edge_kernel_t,
+        p_start_t>;
     __shared__ typename solver::lds_t lds;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     solver::run(prm, lds, reinterpret_cast<real_t *>(dyn_lds));
 }
-''').render(threads=64 * v.W, name=self.kernel_name(v, C, nodal, tab),
-            S=v.S, R=v.R, W=v.W, C=C, D=v.D, waves=self.waves_per_eu(v, C),
+''').render(threads=64 * v.W,
+            name=self.kernel_name(v, C, nodal, tab, ngrad),
+            S=v.S, R=v.R, W=v.W, C=C, D=v.D,
+            waves=self._oc_waves(v, C, ngrad) if ngrad
+            else self.waves_per_eu(v, C),
             nodal='true' if nodal else 'false',
-            tab='true' if tab else 'false')
+            tab='true' if tab else 'false',
+            ngrad='true' if ngrad else 'false',
+            params='params_fd_t' if ngrad else 'params_t')
         if v == GENERAL:
             return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
@@ -680,9 +711,11 @@ void ${name}(params_t prm) {
             tab='true' if tab else 'false')
 
     def render_source(self, node_kernel, edge_kernel, p, node_t, edge_t,
-                      variants, C, nodal=False, tab=False, weighted=False):
+                      variants, C, nodal=False, tab=False, weighted=False,
+                      ngrad=False):
         """Full translation unit for the given solver variants."""
         pd = self._params_dtype(node_kernel, edge_kernel, p)
+        pfd = self._params_fd_dtype(node_kernel, edge_kernel, p)
         return Template(_TEMPLATE).render(
             real=_real_name(self.real),
             weighted='1' if weighted else '0',
@@ -696,8 +729,8 @@ void ${name}(params_t prm) {
             p_start=self.gencode_probability(p, 'p_start', self.real),
             node_size=np.dtype(node_t).itemsize,
             edge_size=max(np.dtype(edge_t).itemsize, 1),
-            params_size=pd.itemsize,
-            entry_points=[self._entry_point(v, C, nodal, tab)
+            params_size=pd.itemsize, params_fd_size=pfd.itemsize,
+            entry_points=[self._entry_point(v, C, nodal, tab, ngrad)
                           for v in variants] + [''],
         )
 
@@ -789,7 +822,8 @@ void ${name}(params_t prm) {
             worst = np.maximum(worst, trip.sum(axis=1))
         return worst
 
-    def classify(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False):
+    def classify(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
+                 oc_only=False):
         """Assign every job the cheapest solver variant it fits.  Returns
         (variant index, cost, stage-1 tasks, image bytes, padded rows, image
         bytes incl. class ids) per job.
@@ -800,16 +834,18 @@ void ${name}(params_t prm) {
         and a set of graphs has few distinct ones (about 150 among the 1000
         QM7-like molecules): large job lists are classified once per pair of
         graph classes and looked up."""
-        sel, out = self._classify_classes(ji, jj, dgraphs, C, tab_bytes, gtab)
+        sel, out = self._classify_classes(ji, jj, dgraphs, C, tab_bytes, gtab,
+                                          oc_only)
         return out if sel is None else tuple(a[sel] for a in out)
 
-    def _classify_classes(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False):
+    def _classify_classes(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
+                          oc_only=False):
         """(sel, per-class-pair results): job t has the results of class pair
         sel[t]; sel is None for short job lists (results are per job)."""
         ji, jj = np.asarray(ji, dtype=np.int64), np.asarray(jj, dtype=np.int64)
         if len(ji) < 4096:
             return None, self._classify_pairs(ji, jj, dgraphs, C, tab_bytes,
-                                              gtab)
+                                              gtab, oc_only)
         width = max(g.max_degree for g in dgraphs) + 1
         key = np.zeros((len(dgraphs), width + 1), dtype=np.int64)
         for k, g in enumerate(dgraphs):
@@ -823,12 +859,13 @@ void ${name}(params_t prm) {
         seen[pk] = True
         upk = np.flatnonzero(seen)
         out = self._classify_pairs(rep[upk // nc], rep[upk % nc], dgraphs, C,
-                                   tab_bytes, gtab)
+                                   tab_bytes, gtab, oc_only)
         pos = np.zeros(nc * nc, dtype=np.int32)
         pos[upk] = np.arange(len(upk), dtype=np.int32)
         return pos[pk], out
 
-    def _classify_pairs(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False):
+    def _classify_pairs(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
+                        oc_only=False):
         n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
         n_nz = np.array([g.n_nz for g in dgraphs], dtype=np.int64)
         width = int(n_node.max())
@@ -861,7 +898,7 @@ void ${name}(params_t prm) {
         for k, v in enumerate(self.variants):
             if not len(rem):
                 break
-            if v == GENERAL:
+            if v == GENERAL or (oc_only and not isinstance(v, OCVariant)):
                 continue
             if isinstance(v, OCVariant):
                 if tab_bytes:           # the table kernels are two-stage only
@@ -914,6 +951,8 @@ void ${name}(params_t prm) {
             fits &= slots[v.W][rem] <= v.S
             choice[rem[fits]] = k
             rem = rem[~fits]
+        if np.any(choice < 0) and oc_only:
+            raise NotOwnerComputes
         if np.any(choice < 0):
             if GENERAL not in self.variants:
                 bad = int(np.argmax(choice < 0))
@@ -928,7 +967,7 @@ void ${name}(params_t prm) {
 
     # -- the three phases -----------------------------------------------------------
     def _graphs_and_kernels(self, graphs, node_kernel, edge_kernel, traits,
-                            timer=None):
+                            timer=None, ngrad=False):
         """Pack (or fetch the cached packing of) every graph; wrap the edge
         kernel for weighted graphs; pick the solver flavour C."""
         tic = timer.tic if timer else (lambda *_: None)
@@ -947,12 +986,13 @@ void ${name}(params_t prm) {
             if dg.signature != sig0:
                 self._assert_homogeneous(dgraphs[0], dg)
         toc('transferring graphs to GPU')
-        if traits.eval_gradient is True and traits.nodal is not False:
+        if traits.eval_gradient is True and traits.nodal is not False \
+                and not ngrad:
             raise NotImplementedError(
                 'nodal gradients are evaluated by finite differences over '
                 'value launches (HIPBackend._nodal_gradient), not by a '
                 'gradient plan')
-        C = 2 if traits.eval_gradient is True else 1
+        C = 2 if traits.eval_gradient is True and not ngrad else 1
         # attributes the microkernels read: label classes are numbered over
         # these (before the weighted wrapper: the weight is not a label)
         fields = (self._used_fields(node_kernel),
@@ -961,14 +1001,16 @@ void ${name}(params_t prm) {
             edge_kernel = TensorProduct(weight=Product(), label=edge_kernel)
         return dgraphs, edge_kernel, C, fields
 
-    def _partition(self, dgraphs, jobs, C, tab_bytes=0, gtab=False):
+    def _partition(self, dgraphs, jobs, C, tab_bytes=0, gtab=False,
+                   oc_only=False):
         """Host half of a layout: solver variant per job, launch order (by
         variant, then descending cost) and launch geometry.  No device."""
         jobs = np.ascontiguousarray(jobs)
         ji = jobs['i'].astype(np.int64)
         jj = jobs['j'].astype(np.int64)
         sel, (choice, cost, ntask, gbytes, NP, gbytes_oc) = \
-            self._classify_classes(ji, jj, dgraphs, C, tab_bytes, gtab)
+            self._classify_classes(ji, jj, dgraphs, C, tab_bytes, gtab,
+                                   oc_only)
         # Launch order: by variant, then descending cost, then job index.
         # `choice` ... `gbytes_oc` are per class pair (or per job when sel is
         # None); the jobs are ordered by the rank of their class pair with one
@@ -1043,7 +1085,7 @@ void ${name}(params_t prm) {
         return jobs, used, order_all, launches
 
     def _sources(self, used, node_kernel, edge_kernel, p, dgraphs, C, nodal,
-                 tab=False, gtab=False):
+                 tab=False, gtab=False, ngrad=False):
         """One translation unit per solver variant in use (+ the one of the
         table kernel, key 'tables', when the owner-computes solvers read
         global tables).  The node / edge / start-probability code is shared
@@ -1053,7 +1095,7 @@ void ${name}(params_t prm) {
         sig = (node_kernel.gen_expr('x1', 'x2')[0], str(node_kernel.dtype),
                edge_kernel.gen_expr('x1', 'x2')[0], str(edge_kernel.dtype),
                p.gen_expr()[0], str(np.dtype(p.dtype)), dgraphs[0].signature,
-               C, nodal, tab, gtab)
+               C, nodal, tab, gtab, ngrad)
         out = {}
         todo = [(k, self.variants[k]) for k in used]
         if gtab and any(isinstance(v, OCVariant) for _, v in todo):
@@ -1066,7 +1108,7 @@ void ${name}(params_t prm) {
                     dgraphs[0].edge_t, [v], C, nodal,
                     tab=gtab if isinstance(v, OCVariant)
                     else (tab and v not in (GENERAL, TABLES)),
-                    weighted=dgraphs[0].weighted)
+                    weighted=dgraphs[0].weighted, ngrad=ngrad)
             out[k] = self._source_cache[key]
         return out
 
@@ -1096,7 +1138,7 @@ void ${name}(params_t prm) {
         return jit.compile_many(list(sources.values()), self.hipcc_extra)
 
     def _layout(self, dgraphs, jobs, starts, C, fields=(None, None),
-                timer=None):
+                timer=None, ngrad=False):
         """Everything of a plan that depends only on WHICH pairs of WHICH
         graphs are evaluated: variant per job, launch order and geometry, and
         the device copies of the job list, the order and `starts`.  Cached
@@ -1111,7 +1153,8 @@ void ${name}(params_t prm) {
         jobs_id = ('id', id(jobs)) if not jobs.flags.writeable else \
             ('crc', zlib.crc32(jobs.view(np.uint8)))
         key = (tuple(map(id, dgraphs)), len(jobs), jobs_id,
-               zlib.crc32(starts.view(np.uint8)), C, fields, self.tables)
+               zlib.crc32(starts.view(np.uint8)), C, fields, self.tables,
+               ngrad)
         hit = self._layouts.get(key)
         if hit is not None:
             self._layouts.move_to_end(key)
@@ -1124,9 +1167,12 @@ void ${name}(params_t prm) {
         lay.jobs_host = jobs
         lay.arena, lay.arena_buf, _ = self._arena(dgraphs, fields)
         lay.tab_bytes = self._table_bytes(lay.arena)
-        lay.gtab = self._global_tables(lay.arena)
+        # (the nodal-gradient solvers evaluate the microkernels directly)
+        lay.gtab = self._global_tables(lay.arena) and not ngrad
+        if ngrad:
+            lay.tab_bytes = 0
         jobs, lay.used, lay.order_host, lay.launches = self._partition(
-            dgraphs, jobs, C, lay.tab_bytes, lay.gtab)
+            dgraphs, jobs, C, lay.tab_bytes, lay.gtab, oc_only=ngrad)
         lay.n_jobs = len(jobs)
         lay.b_jobs = runtime.DeviceBuffer(max(jobs.nbytes, 8))
         lay.b_order = runtime.DeviceBuffer(max(lay.order_host.nbytes, 4))
@@ -1147,23 +1193,27 @@ void ${name}(params_t prm) {
 
     def prepare(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
                 jobs, starts, nX, nY, nJ, traits, timer=None, packed=False,
-                gramian_ptr=None, gradient_ptr=None):
+                gramian_ptr=None, gradient_ptr=None, ngrad=False):
         """Upload graphs / jobs, generate + compile code, partition the jobs.
         Returns a Plan whose launches can be replayed.  `gramian_ptr` /
         `gradient_ptr` (device addresses) make the kernels write into
-        caller-owned memory, e.g. the tensor handed to the all-gather."""
+        caller-owned memory, e.g. the tensor handed to the all-gather.
+        `ngrad`: nodal outputs with their finite-difference Jacobian in the
+        same launch (owner-computes solvers only: raises NotOwnerComputes if
+        some pair does not fit one)."""
         tic = timer.tic if timer else (lambda *_: None)
         toc = timer.toc if timer else (lambda *_: None)
         runtime.ensure_device(self.device)
+        node_kernel_in, edge_kernel_in = node_kernel, edge_kernel
         dgraphs, edge_kernel, C, fields = self._graphs_and_kernels(
-            graphs, node_kernel, edge_kernel, traits, timer)
-        lay = self._layout(dgraphs, jobs, starts, C, fields, timer)
+            graphs, node_kernel, edge_kernel, traits, timer, ngrad)
+        lay = self._layout(dgraphs, jobs, starts, C, fields, timer, ngrad)
         tab = lay.tab_bytes > 0
 
         tic('code generation')
         nodal = traits.nodal is not False
         sources = self._sources(lay.used, node_kernel, edge_kernel, p,
-                                dgraphs, C, nodal, tab, lay.gtab)
+                                dgraphs, C, nodal, tab, lay.gtab, ngrad)
         toc('code generation')
         tic('JIT')
         missing = [s for s in sources.values()
@@ -1196,7 +1246,8 @@ void ${name}(params_t prm) {
         rsize = np.dtype(self.real).itemsize
         n_out = lay.n_jobs if packed else plan.nX * plan.nY
         plan.n_out = n_out
-        plan.n_grad = n_out * plan.nJ if C == 2 else 0
+        plan.ngrad = ngrad
+        plan.n_grad = n_out * plan.nJ if (C == 2 or ngrad) else 0
 
         launches = []
         for G in lay.launches:
@@ -1206,7 +1257,7 @@ void ${name}(params_t prm) {
                 if isinstance(L['variant'], OCVariant) \
                 else tab and L['variant'] != GENERAL
             L['fn'] = fn = L['module'].function(
-                self.kernel_name(L['variant'], C, nodal, L['tab']))
+                self.kernel_name(L['variant'], C, nodal, L['tab'], ngrad))
             if L['variant'] == GENERAL:
                 L['grid'] = int(min(L['count'],
                                     2 * self.props.compute_units))
@@ -1219,7 +1270,7 @@ void ${name}(params_t prm) {
         # per-call device buffers (outputs, scratch) from the grow-only pool
         b_out = self._buffer('gramian', n_out * rsize)
         b_grad = self._buffer('gradient', plan.n_grad * rsize) \
-            if C == 2 else None
+            if plan.n_grad else None
         b_iters = self._buffer('iters', 4 * lay.n_jobs) \
             if self.record_iterations else None
         scratch_bytes = max([L.get('scratch_bytes', 0) for L in launches]
@@ -1266,6 +1317,27 @@ void ${name}(params_t prm) {
             dt, val = pack_theta(obj, self.real)
             if val is not None:
                 base[field] = val
+        fd = None
+        if ngrad:
+            # perturbed hyperparameter sets exp(log(theta) +- eps) of the
+            # central differences (reference: pack_state(diff_grid=True),
+            # _backend_cuda.py:230-245)
+            fd = np.zeros((), dtype=self._params_fd_dtype(
+                node_kernel, edge_kernel, p))
+            fd['q_plus'] = np.exp(np.log(q) + eps)
+            fd['q_minus'] = np.exp(np.log(q) - eps)
+            for which, kern in (('node', node_kernel), ('edge', edge_kernel)):
+                theta = np.array(list(flatten(kern.theta)), dtype=float)
+                for j_, t_ in enumerate(theta):
+                    fd[which + '_theta'][j_] = t_
+                    for s_, delta in enumerate((eps, -eps)):
+                        k2 = copy.deepcopy(kern)
+                        lt = np.log(theta)
+                        lt[j_] += delta
+                        k2.theta = fold_like(np.exp(lt), k2.theta)
+                        _, val = pack_theta(k2, self.real)
+                        if val is not None:
+                            fd[which + '_diff'][2 * j_ + s_] = val
         for L in launches:
             a = base.copy()
             a['order'] = lay.b_order.ptr + 4 * L['offset']
@@ -1274,7 +1346,12 @@ void ${name}(params_t prm) {
             a['n_launch_jobs'] = L['count']
             a['order_offset'] = L['offset']
             a['u_capacity'] = L['ucap']
-            L['args'] = a.tobytes()
+            if fd is not None:
+                f_ = fd.copy()
+                f_['base'] = a
+                L['args'] = f_.tobytes()
+            else:
+                L['args'] = a.tobytes()
         # launches that every solver launch depends on: the table kernel
         plan.pre_launches = []
         if b_tables is not None:
@@ -1328,7 +1405,7 @@ void ${name}(params_t prm) {
 
         out = fetch(plan.buffers['gramian'], plan.n_out, gramian)
         grad = None
-        if plan.C == 2:
+        if plan.C == 2 or getattr(plan, 'ngrad', False):
             grad = fetch(plan.buffers['gradient'], plan.n_grad, gradient)
         return out, grad
 
@@ -1427,7 +1504,23 @@ void ${name}(params_t prm) {
                  gtol, jobs, starts, gramian, gradient, nX, nY, nJ, traits,
                  timer):
         if traits.eval_gradient is True and traits.nodal is True:
+            # nodal Jacobian: in the same launch as the solve (owner-computes
+            # solvers, mgk_oc.h NGRAD); graphs they do not cover take the
+            # host-orchestrated re-launches
+            try:
+                plan = self.prepare(graphs, node_kernel, edge_kernel, p, q,
+                                    eps, ftol, gtol, jobs, starts, nX, nY,
+                                    nJ, traits, timer, ngrad=True) \
+                    if self.nodal_gradient_in_kernel else None
+            except NotOwnerComputes:
+                plan = None
             timer.tic('GPU kernel execution')
+            if plan is not None:
+                self.launch(plan)
+                runtime.synchronize()
+                timer.toc('GPU kernel execution')
+                self.collect(plan, gramian, gradient)
+                return
             self._nodal_gradient(graphs, node_kernel, edge_kernel, p, q, eps,
                                  ftol, gtol, jobs, starts, gramian, gradient,
                                  nX, nY, nJ, traits, timer)

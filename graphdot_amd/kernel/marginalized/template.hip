@@ -35,5 +35,8 @@ static_assert(sizeof(graphdot::graph_header_t) == 32, "graph header layout");
 static_assert(sizeof(node_t) == ${node_size}, "node_t layout differs from the host packer");
 static_assert(sizeof(edge_t) == ${edge_size}, "edge_t layout differs from the host packer");
 static_assert(sizeof(params_t) == ${params_size}, "params_t layout differs from the host packer");
+using params_fd_t = graphdot::mgk::params_fd_t<real_t, graph_t, node_kernel_t,
+                                               edge_kernel_t, p_start_t>;
+static_assert(sizeof(params_fd_t) == ${params_fd_size}, "params_fd_t layout differs from the host packer");
 
 ${entry_points}
