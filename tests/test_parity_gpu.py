@@ -408,24 +408,32 @@ def test_nodal_gradient_finite_differences(backend, name):
 @pytest.mark.parametrize('real', [np.float32, np.float64])
 def test_nodal_gradient_in_kernel_vs_relaunches(real):
     """The nodal Jacobian of the owner-computes solvers -- every +-eps system
-    re-solved warm-started inside the launch, stopped at gtol N like the
-    reference (template.cu:286-418) -- against the host-orchestrated form
-    (2 (n_theta + 1) fresh value launches converged to ftol N): same central
-    differences to 1e-3 of the column scale in float, 1e-4 in double, on the
-    molecular set, for the full nodal matrix, X x Y and `diag`."""
+    re-solved warm-started inside the launch, stopped at sqrt(rTr) < gtol N
+    like the reference (template.cu:286-418) -- against the host-orchestrated
+    form (2 (n_theta + 1) fresh value launches converged to ftol N).  With
+    the default gtol = 1e-6 the warm-started solves stop early by design and
+    the two agree to the reference's own bar (5 % of the column scale,
+    test_kernel.py:289); with gtol tightened they are the same central
+    differences (1e-3 of the column scale in float, 1e-5 in double) -- for
+    the full nodal matrix, X x Y, `diag`, and lmin = 1."""
     from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
     G = cases.config3_graphs(10, seed=17)
     knode, kedge, q = cases.config3_kernels()
     fused = HIPBackend(real=real)
     relaunch = HIPBackend(real=real, nodal_gradient_in_kernel=False)
-    a = MarginalizedGraphKernel(knode, kedge, q=q, backend=fused)
     b = MarginalizedGraphKernel(knode, kedge, q=q, backend=relaunch)
-    tol = 1e-3 if real is np.float32 else 1e-4
-    Ra, dRa = a(G, nodal=True, eval_gradient=True)
-    assert fused.last_plan.ngrad and len(fused.last_plan.launches) >= 1
     Rb, dRb = b(G, nodal=True, eval_gradient=True)
-    assert np.allclose(Ra, Rb, rtol=1e-6)
     scale = np.abs(dRb).max(axis=(0, 1), keepdims=True)
+    a0 = MarginalizedGraphKernel(knode, kedge, q=q, backend=fused)
+    Ra, dRa = a0(G, nodal=True, eval_gradient=True)
+    assert fused.last_plan.ngrad
+    assert np.allclose(Ra, Rb, rtol=1e-6)
+    assert np.all(np.abs(dRa - dRb) <= 0.05 * scale)
+    tight = 3e-8 if real is np.float32 else 1e-11
+    tol = 1e-3 if real is np.float32 else 1e-5
+    a = MarginalizedGraphKernel(knode, kedge, q=q, backend=fused, gtol=tight)
+    Ra, dRa = a(G, nodal=True, eval_gradient=True)
+    assert np.allclose(Ra, Rb, rtol=1e-6)
     assert np.all(np.abs(dRa - dRb) <= tol * scale)
     assert np.array_equal(dRa, dRa.transpose(1, 0, 2))
     Xa, dXa = a(G[:4], G[4:], nodal=True, eval_gradient=True)
