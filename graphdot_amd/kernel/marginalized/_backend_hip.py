@@ -619,9 +619,11 @@ struct ${name}_t : ${name}_theta_t {
     #: occupancy targets of the owner-computes variants, the fastest of a
     #: per-variant sweep on MI355X (scripts/oc_sweep.py: QM7-like set for
     #: D = 4, configuration 2 for D = 8): (double?, C) -> {(W, S, R, D): waves}
+    #: (float (28, 5) at 5 waves is 2 % faster than at 4 but writes 2 KB of
+    #: scratch per pair to HBM, profiles/r02_f32_pmc.csv: not taken)
     _OC_WAVES = {
         (False, 1): {(1, 12, 2, 4): 6, (1, 16, 3, 4): 6, (1, 20, 3, 4): 6,
-                     (1, 20, 4, 4): 4, (1, 24, 4, 4): 5, (1, 28, 5, 4): 5,
+                     (1, 20, 4, 4): 4, (1, 24, 4, 4): 5, (1, 28, 5, 4): 4,
                      (1, 28, 6, 4): 4, (1, 32, 7, 4): 4, (1, 36, 9, 4): 2,
                      (1, 32, 3, 8): 2, (1, 48, 5, 8): 2, (1, 64, 9, 8): 2,
                      (4, 32, 3, 8): 3, (4, 48, 4, 8): 2, (4, 64, 5, 8): 3,
