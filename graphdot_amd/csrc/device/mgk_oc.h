@@ -128,8 +128,19 @@ struct params_fd_t {
 // re-solve warm-started from the unperturbed solution and stopped at
 // sqrt(rTr) < gtol N -- here in the same launch, right after the solve of the
 // pair, instead of 2 (n_theta + 1) further launches.
-template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB, bool NGRAD, class Graph, class NodeK, class EdgeK, class PStart>
+// MAXIMIN: instead of the nodal matrix the launch writes the maximin graph
+// distance of the pair (reference: graphdot/metric/maximin/_backend.cu:40-407),
+//   d(i1,i2) = sqrt(max(0, 0.9999995 - k12 / sqrt(k1 k2))),
+//   D = max(max_i1 min_i2 d, max_i2 min_i1 d),
+// its hotspot (largest flat index i1 n2 + i2 among the entries equal to D) and,
+// with NGRAD, the gradient -0.5 d(k12 / sqrt(k1 k2))/dtheta / (D + 1e-4) at the
+// hotspot -- the min / max reductions are LDS atomics on the bit patterns of
+// the non-negative float distances (order independent: deterministic), the
+// n1 x n2 nodal block never leaves the CU.  k1, k2 (and their Jacobians) are
+// the nodal self-similarities of the two graphs from a `diag` launch.
+template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB, bool NGRAD, bool MAXIMIN, class Graph, class NodeK, class EdgeK, class PStart>
 struct oc_solver {
+    static_assert(!MAXIMIN || (NODAL && C == 1), "the maximin epilogue works on the nodal solution of a value solve");
     using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
     using PF = std::conditional_t<NGRAD, params_fd_t<real, Graph, NodeK, EdgeK, PStart>, P>;
     __device__ static __forceinline__ P const &common(P const &p) { return p; }
@@ -581,7 +592,7 @@ struct oc_solver {
                 const real pp_ = real(prm.p_start(v1)) * real(prm.p_start(v2));
                 const real rv = ok ? xi * pp_ : real(0);
                 ksum += rv;
-                if constexpr (NODAL) if ((flags & F_NODAL) && ok) {
+                if constexpr (NODAL && !MAXIMIN) if ((flags & F_NODAL) && ok) {
                     const unsigned o1 = g1.perm[i1], o2 = g2.perm[i2];
                     if (flags & F_BLOCK) {
                         prm.gramian[I1 + o1 + o2 * n2] = rv;
@@ -593,6 +604,87 @@ struct oc_solver {
                     }
                 }
             }
+            }
+
+            // ---- maximin distance of the pair ---------------------------------
+            // (graph-level output: I1, I2 are graph indices here)
+            [[maybe_unused]] int mm_own[R];          // this lane's row k is the hotspot
+            [[maybe_unused]] real mm_k12 = 0, mm_rs = 0, mm_k1 = 0, mm_k2 = 0, mm_D = 0;
+            [[maybe_unused]] unsigned mm_n1 = 0, mm_n2 = 0;   // node offsets of the graphs
+            [[maybe_unused]] unsigned mm_hot = 0;             // flat index of the hotspot
+            if constexpr (MAXIMIN) {
+                unsigned *const dmin1 = reinterpret_cast<unsigned *>(lY);
+                unsigned *const dmin2 = dmin1 + n1;
+                unsigned *const cell = dmin2 + n2;      // [0] D bits, [1] hotspot, [2] mirrored hotspot
+                const unsigned NS1 = prm.node_starts[job.i], NS2 = prm.node_starts[job.j];
+                mm_n1 = NS1;
+                mm_n2 = NS2;
+                job_sync<W>();
+                for (int i = tid; i < n1 + n2; i += T) dmin1[i] = 0x7F7FFFFFu;   // FLT_MAX
+                if (tid < 3) cell[tid] = 0u;
+                job_sync<W>();
+                float dloc[R];
+                real k12v[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int pos = k * T + tid;
+                    const bool ok = pos < N;
+                    const unsigned rm = rowmap[ok ? pos : 0];
+                    const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
+                    const node_t v1 = g1.node[i1], v2 = g2.node[i2];
+                    real xi = x[0][k];
+                    if (flags & F_LMIN1) xi -= kappa_v(i1, i2, v1, v2) * bscale;
+                    k12v[k] = xi * real(prm.p_start(v1)) * real(prm.p_start(v2));
+                    const real k1 = prm.diag[NS1 + g1.perm[i1]], k2 = prm.diag[NS2 + g2.perm[i2]];
+                    const real dd = real(0.9999995f) - k12v[k] * graphdot::rsqrt(k1 * k2);
+                    dloc[k] = ok ? sqrtf((float)(dd > real(0) ? dd : real(0))) : 0.f;
+                    if (ok) {
+                        __hip_atomic_fetch_min(dmin1 + i1, __float_as_uint(dloc[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_min(dmin2 + i2, __float_as_uint(dloc[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                job_sync<W>();
+                for (int i = tid; i < n1 + n2; i += T)
+                    __hip_atomic_fetch_max(cell, dmin1[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                job_sync<W>();
+                const unsigned Dbits = cell[0];
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int pos = k * T + tid;
+                    if (pos < N && __float_as_uint(dloc[k]) == Dbits) {
+                        const unsigned rm = rowmap[pos];
+                        const unsigned o1 = g1.perm[rm >> 16], o2 = g2.perm[rm & 0xFFFFu];
+                        // flat indices + 1: 0 means "none yet"
+                        __hip_atomic_fetch_max(cell + 1, o1 * (unsigned)n2 + o2 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_max(cell + 2, o2 * (unsigned)n1 + o1 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                job_sync<W>();
+                const unsigned hot = cell[1] - 1u, hot_m = cell[2] - 1u;
+                mm_hot = hot;
+                mm_D = real(__uint_as_float(Dbits));
+                if (tid == 0) {
+                    prm.gramian[(size_t)I1 + (size_t)prm.nX * I2] = mm_D;
+                    prm.hotspot[(size_t)I1 + (size_t)prm.nX * I2] = (std::int32_t)hot;
+                    if (mirror) {
+                        prm.gramian[(size_t)I2 + (size_t)prm.nX * I1] = mm_D;
+                        prm.hotspot[(size_t)I2 + (size_t)prm.nX * I1] = (std::int32_t)hot_m;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int pos = k * T + tid;
+                    const unsigned rm = rowmap[pos < N ? pos : 0];
+                    const unsigned o1 = g1.perm[rm >> 16], o2 = g2.perm[rm & 0xFFFFu];
+                    mm_own[k] = pos < N && o1 * (unsigned)n2 + o2 == hot;
+                    if (mm_own[k]) {
+                        mm_k12 = k12v[k];
+                        mm_k1 = prm.diag[NS1 + o1];
+                        mm_k2 = prm.diag[NS2 + o2];
+                        mm_rs = graphdot::rsqrt(mm_k1 * mm_k2);
+                    }
+                }
+                job_sync<W>();   // lY is the row-sum scratch again below
             }
             if (!NODAL || !(flags & F_NODAL)) {
                 ksum = block_reduce<real, W>::sum(ksum, red);
@@ -614,6 +706,24 @@ struct oc_solver {
                                                           : (size_t)prm.nX * prm.nY;
                 // J[row of the output, column col] = v for the rows of this lane
                 auto write_column = [&](int col, real const (&v)[R]) {
+                    if constexpr (MAXIMIN) {
+                        // v = d k12 / d theta_col per row: the hotspot's owner
+                        // turns it into the gradient of the distance
+                        // (_backend.cu:136-140,380-402)
+#pragma unroll
+                        for (int k = 0; k < R; ++k)
+                            if (mm_own[k]) {
+                                const unsigned o1 = mm_hot / (unsigned)n2, o2 = mm_hot - o1 * (unsigned)n2;
+                                const real dk1 = prm.diag_grad[(size_t)(mm_n1 + o1) + (size_t)prm.diag_ld * col];
+                                const real dk2 = prm.diag_grad[(size_t)(mm_n2 + o2) + (size_t)prm.diag_ld * col];
+                                const real dnorm = v[k] * mm_rs - real(0.5) * mm_k12 * mm_rs * mm_rs * mm_rs *
+                                                   (dk1 * mm_k2 + mm_k1 * dk2);
+                                const real g = real(-0.5) * dnorm / (mm_D + real(1e-4f));
+                                prm.gradient[(size_t)I1 + (size_t)prm.nX * I2 + plane * col] = g;
+                                if (mirror) prm.gradient[(size_t)I2 + (size_t)prm.nX * I1 + plane * col] = g;
+                            }
+                        return;
+                    }
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         const int pos = k * T + tid;

@@ -75,6 +75,14 @@ template<class real, class Graph, class NodeK, class EdgeK, class PStart> struct
     std::uint32_t *iters;        // optional per-job CG iteration counts
     real *scratch;               // general solver only: per-workgroup CG scratch
     real *tables;                // microkernel values over label-class pairs (mgk_oc.h)
+    // maximin distance (mgk_oc.h, MAXIMIN): nodal self-similarities of every
+    // graph [node_starts[g] + node], their Jacobian (column-major, leading
+    // dimension = total node count), the hotspot output, node offsets
+    real const *diag;
+    real const *diag_grad;
+    std::int32_t *hotspot;
+    std::uint32_t const *node_starts;
+    std::uint32_t diag_ld;       // leading dimension of diag_grad (total node count)
     std::uint32_t n_launch_jobs;
     std::uint32_t nX, nY, nJ;
     std::uint32_t flags;

@@ -517,7 +517,8 @@ struct ${name}_t : ${name}_theta_t {
         return np.dtype([
             ('arena', P), ('jobs', P), ('order', P), ('starts', P),
             ('gramian', P), ('gradient', P), ('iters', P), ('scratch', P),
-            ('tables', P),
+            ('tables', P), ('diag', P), ('diag_grad', P), ('hotspot', P),
+            ('node_starts', P), ('diag_ld', np.uint32),
             ('n_launch_jobs', np.uint32), ('nX', np.uint32),
             ('nY', np.uint32), ('nJ', np.uint32), ('flags', np.uint32),
             ('order_offset', np.uint32), ('u_capacity', np.uint32),
@@ -548,7 +549,8 @@ struct ${name}_t : ${name}_theta_t {
             ('edge_diff', theta(edge_kernel), (max(2 * ne, 1),)),
         ], align=True)
 
-    def kernel_name(self, v, C, nodal=False, tab=False, ngrad=False):
+    def kernel_name(self, v, C, nodal=False, tab=False, ngrad=False,
+                    maximin=False):
         """Entry point name: arithmetic, solver variant, flavour."""
         f = 'f64' if np.dtype(self.real) == np.float64 else 'f32'
         if v == GENERAL:
@@ -558,7 +560,7 @@ struct ${name}_t : ${name}_theta_t {
         if isinstance(v, OCVariant):
             return f'mgk_{f}_oc{v.D}_W{v.W}_S{v.S}_R{v.R}_C{C}' + \
                 ('_nodal' if nodal else '') + ('_tab' if tab else '') + \
-                ('_ngrad' if ngrad else '')
+                ('_ngrad' if ngrad else '') + ('_maximin' if maximin else '')
         return f'mgk_{f}_W{v.W}_S{v.S}_R{v.R}_C{C}' + \
             ('_nodal' if nodal else '') + ('_tab' if tab else '')
 
@@ -657,7 +659,8 @@ struct ${name}_t : ${name}_theta_t {
                 return n
         return 1
 
-    def _entry_point(self, v, C, nodal=False, tab=False, ngrad=False):
+    def _entry_point(self, v, C, nodal=False, tab=False, ngrad=False,
+                     maximin=False):
         if v == TABLES:
             return Template(r'''
 extern "C" __global__ __launch_bounds__(256)
@@ -671,14 +674,15 @@ extern "C" __global__ __launch_bounds__(${threads})
 __attribute__((amdgpu_waves_per_eu(${waves})))
 void ${name}(${params} prm) {
     using solver = graphdot::mgk::oc_solver<real_t, ${S}, ${R}, ${W}, ${C},
-        ${nodal}, ${D}, ${tab}, ${ngrad}, graph_t, node_kernel_t, edge_kernel_t,
-        p_start_t>;
+        ${nodal}, ${D}, ${tab}, ${ngrad}, ${maximin}, graph_t, node_kernel_t,
+        edge_kernel_t, p_start_t>;
     __shared__ typename solver::lds_t lds;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     solver::run(prm, lds, reinterpret_cast<real_t *>(dyn_lds));
 }
 ''').render(threads=64 * v.W,
-            name=self.kernel_name(v, C, nodal, tab, ngrad),
+            name=self.kernel_name(v, C, nodal, tab, ngrad, maximin),
+            maximin='true' if maximin else 'false',
             S=v.S, R=v.R, W=v.W, C=C, D=v.D,
             waves=self._oc_waves(v, C, ngrad) if ngrad
             else self.waves_per_eu(v, C),
@@ -714,7 +718,7 @@ void ${name}(params_t prm) {
 
     def render_source(self, node_kernel, edge_kernel, p, node_t, edge_t,
                       variants, C, nodal=False, tab=False, weighted=False,
-                      ngrad=False):
+                      ngrad=False, maximin=False):
         """Full translation unit for the given solver variants."""
         pd = self._params_dtype(node_kernel, edge_kernel, p)
         pfd = self._params_fd_dtype(node_kernel, edge_kernel, p)
@@ -732,7 +736,7 @@ void ${name}(params_t prm) {
             node_size=np.dtype(node_t).itemsize,
             edge_size=max(np.dtype(edge_t).itemsize, 1),
             params_size=pd.itemsize, params_fd_size=pfd.itemsize,
-            entry_points=[self._entry_point(v, C, nodal, tab, ngrad)
+            entry_points=[self._entry_point(v, C, nodal, tab, ngrad, maximin)
                           for v in variants] + [''],
         )
 
@@ -1087,7 +1091,7 @@ void ${name}(params_t prm) {
         return jobs, used, order_all, launches
 
     def _sources(self, used, node_kernel, edge_kernel, p, dgraphs, C, nodal,
-                 tab=False, gtab=False, ngrad=False):
+                 tab=False, gtab=False, ngrad=False, maximin=False):
         """One translation unit per solver variant in use (+ the one of the
         table kernel, key 'tables', when the owner-computes solvers read
         global tables).  The node / edge / start-probability code is shared
@@ -1097,7 +1101,7 @@ void ${name}(params_t prm) {
         sig = (node_kernel.gen_expr('x1', 'x2')[0], str(node_kernel.dtype),
                edge_kernel.gen_expr('x1', 'x2')[0], str(edge_kernel.dtype),
                p.gen_expr()[0], str(np.dtype(p.dtype)), dgraphs[0].signature,
-               C, nodal, tab, gtab, ngrad)
+               C, nodal, tab, gtab, ngrad, maximin)
         out = {}
         todo = [(k, self.variants[k]) for k in used]
         if gtab and any(isinstance(v, OCVariant) for _, v in todo):
@@ -1110,7 +1114,8 @@ void ${name}(params_t prm) {
                     dgraphs[0].edge_t, [v], C, nodal,
                     tab=gtab if isinstance(v, OCVariant)
                     else (tab and v not in (GENERAL, TABLES)),
-                    weighted=dgraphs[0].weighted, ngrad=ngrad)
+                    weighted=dgraphs[0].weighted, ngrad=ngrad,
+                    maximin=maximin and isinstance(v, OCVariant))
             out[k] = self._source_cache[key]
         return out
 
@@ -1140,7 +1145,7 @@ void ${name}(params_t prm) {
         return jit.compile_many(list(sources.values()), self.hipcc_extra)
 
     def _layout(self, dgraphs, jobs, starts, C, fields=(None, None),
-                timer=None, ngrad=False):
+                timer=None, ngrad=False, maximin=False):
         """Everything of a plan that depends only on WHICH pairs of WHICH
         graphs are evaluated: variant per job, launch order and geometry, and
         the device copies of the job list, the order and `starts`.  Cached
@@ -1156,7 +1161,7 @@ void ${name}(params_t prm) {
             ('crc', zlib.crc32(jobs.view(np.uint8)))
         key = (tuple(map(id, dgraphs)), len(jobs), jobs_id,
                zlib.crc32(starts.view(np.uint8)), C, fields, self.tables,
-               ngrad)
+               ngrad, maximin)
         hit = self._layouts.get(key)
         if hit is not None:
             self._layouts.move_to_end(key)
@@ -1171,10 +1176,11 @@ void ${name}(params_t prm) {
         lay.tab_bytes = self._table_bytes(lay.arena)
         # (the nodal-gradient solvers evaluate the microkernels directly)
         lay.gtab = self._global_tables(lay.arena) and not ngrad
-        if ngrad:
+        if ngrad or maximin:
             lay.tab_bytes = 0
         jobs, lay.used, lay.order_host, lay.launches = self._partition(
-            dgraphs, jobs, C, lay.tab_bytes, lay.gtab, oc_only=ngrad)
+            dgraphs, jobs, C, lay.tab_bytes, lay.gtab,
+            oc_only=ngrad or maximin)
         lay.n_jobs = len(jobs)
         lay.b_jobs = runtime.DeviceBuffer(max(jobs.nbytes, 8))
         lay.b_order = runtime.DeviceBuffer(max(lay.order_host.nbytes, 4))
@@ -1195,27 +1201,33 @@ void ${name}(params_t prm) {
 
     def prepare(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
                 jobs, starts, nX, nY, nJ, traits, timer=None, packed=False,
-                gramian_ptr=None, gradient_ptr=None, ngrad=False):
+                gramian_ptr=None, gradient_ptr=None, ngrad=False,
+                maximin=None):
         """Upload graphs / jobs, generate + compile code, partition the jobs.
         Returns a Plan whose launches can be replayed.  `gramian_ptr` /
         `gradient_ptr` (device addresses) make the kernels write into
         caller-owned memory, e.g. the tensor handed to the all-gather.
         `ngrad`: nodal outputs with their finite-difference Jacobian in the
         same launch (owner-computes solvers only: raises NotOwnerComputes if
-        some pair does not fit one)."""
+        some pair does not fit one).  `maximin`: dict(diag=, diag_grad=,
+        node_starts=, ld=) of device addresses -- the launch writes the
+        maximin distance, its hotspot (and with `ngrad` its gradient) per
+        pair instead of the nodal matrix (`maximin_distance`)."""
         tic = timer.tic if timer else (lambda *_: None)
         toc = timer.toc if timer else (lambda *_: None)
         runtime.ensure_device(self.device)
         node_kernel_in, edge_kernel_in = node_kernel, edge_kernel
         dgraphs, edge_kernel, C, fields = self._graphs_and_kernels(
             graphs, node_kernel, edge_kernel, traits, timer, ngrad)
-        lay = self._layout(dgraphs, jobs, starts, C, fields, timer, ngrad)
+        lay = self._layout(dgraphs, jobs, starts, C, fields, timer, ngrad,
+                           maximin is not None)
         tab = lay.tab_bytes > 0
 
         tic('code generation')
         nodal = traits.nodal is not False
         sources = self._sources(lay.used, node_kernel, edge_kernel, p,
-                                dgraphs, C, nodal, tab, lay.gtab, ngrad)
+                                dgraphs, C, nodal, tab, lay.gtab, ngrad,
+                                maximin is not None)
         toc('code generation')
         tic('JIT')
         missing = [s for s in sources.values()
@@ -1248,6 +1260,7 @@ void ${name}(params_t prm) {
         rsize = np.dtype(self.real).itemsize
         n_out = lay.n_jobs if packed else plan.nX * plan.nY
         plan.n_out = n_out
+        plan.maximin = maximin is not None
         plan.ngrad = ngrad
         plan.n_grad = n_out * plan.nJ if (C == 2 or ngrad) else 0
 
@@ -1259,7 +1272,8 @@ void ${name}(params_t prm) {
                 if isinstance(L['variant'], OCVariant) \
                 else tab and L['variant'] != GENERAL
             L['fn'] = fn = L['module'].function(
-                self.kernel_name(L['variant'], C, nodal, L['tab'], ngrad))
+                self.kernel_name(L['variant'], C, nodal, L['tab'], ngrad,
+                                 maximin is not None))
             if L['variant'] == GENERAL:
                 L['grid'] = int(min(L['count'],
                                     2 * self.props.compute_units))
@@ -1289,9 +1303,11 @@ void ${name}(params_t prm) {
                           if C == 2 else 0)
             n_tab = (c['nv']**2 + c['ne']**2) * planes
             b_tables = self._buffer('tables', n_tab * rsize)
+        b_hot = self._buffer('hotspot', 4 * n_out) if maximin else None
         plan.buffers = dict(jobs=lay.b_jobs, order=lay.b_order,
                             starts=lay.b_starts, gramian=b_out,
-                            gradient=b_grad, iters=b_iters, tables=b_tables)
+                            gradient=b_grad, iters=b_iters, tables=b_tables,
+                            hotspot=b_hot)
 
         # kernel argument blocks
         pd = self._params_dtype(node_kernel, edge_kernel, p)
@@ -1305,6 +1321,12 @@ void ${name}(params_t prm) {
         base['iters'] = b_iters.ptr if b_iters is not None else 0
         base['scratch'] = b_scratch.ptr if b_scratch is not None else 0
         base['tables'] = b_tables.ptr if b_tables is not None else 0
+        if maximin:
+            base['diag'], base['diag_grad'] = maximin['diag'], \
+                maximin.get('diag_grad', 0)
+            base['node_starts'], base['diag_ld'] = maximin['node_starts'], \
+                maximin['ld']
+            base['hotspot'] = b_hot.ptr
         base['nX'], base['nY'], base['nJ'] = plan.nX, plan.nY, plan.nJ
         base['flags'] = flags
         if tab or b_tables is not None:
@@ -1500,6 +1522,73 @@ void ${name}(params_t prm) {
                             (node_kernel, pair[1], q), 2 * eps * theta[j])
         assert col == nJ, (col, nJ)
         gradient[:] = J.ravel(order='F')
+
+    # -- maximin graph distance, fused ------------------------------------------------
+    def maximin_distance(self, graphs, node_kernel, edge_kernel, p, q, eps,
+                         ftol, gtol, jobs, nX, nY, nJ, traits, timer=None):
+        """Maximin distances (+ hotspots, + gradients with
+        `traits.eval_gradient`) of the graph pairs in `jobs` without the
+        nodal Gram matrix ever leaving the compute units (reference:
+        metric/maximin/_backend.cu:40-407, one fused CUDA kernel): a `diag`
+        launch leaves the nodal self-similarities of every graph (and their
+        Jacobian) on the device, the pair launch reduces row minima / column
+        minima / their maximum in LDS (mgk_oc.h, MAXIMIN).  `traits` are
+        graph-level (`nodal=False`); nX, nY count graphs.  Owner-computes
+        solvers only: raises NotOwnerComputes otherwise.  Returns (distance
+        [nX nY], hotspot int32 [nX nY], gradient [nX nY nJ] or None), flat
+        column-major like the other outputs."""
+        grad = traits.eval_gradient is True
+        n = len(graphs)
+        sizes = np.array([len(g.nodes) for g in graphs], dtype=np.uint32)
+        node_starts = np.zeros(n + 1, dtype=np.uint32)
+        np.cumsum(sizes, out=node_starts[1:])
+        total = int(node_starts[-1])
+        rs = np.dtype(self.real)
+        # 1. nodal self-similarities (diag, nodal): stays on the device
+        djobs = np.zeros(n, dtype=np.dtype([('i', np.uint32),
+                                            ('j', np.uint32)]))
+        djobs['i'] = djobs['j'] = np.arange(n)
+        dtraits = traits._replace(symmetric=False, nodal=True, diagonal=True,
+                                  eval_gradient=grad)
+        dplan = self.prepare(graphs, node_kernel, edge_kernel, p, q, eps,
+                             ftol, gtol, djobs, node_starts, total, 1, nJ,
+                             dtraits, timer, ngrad=grad)
+        if any(not isinstance(L['variant'], OCVariant)
+               for L in dplan.launches):
+            raise NotOwnerComputes
+        self.launch(dplan)
+        b_diag = self._buffer('mm_diag', total * rs.itemsize)
+        b_dgrad = self._buffer('mm_diag_grad', total * nJ * rs.itemsize) \
+            if grad else None
+        b_ns = self._buffer('mm_node_starts', node_starts.nbytes)
+        runtime.synchronize()
+        runtime.check(runtime.lib().gd_memcpy_d2d(
+            b_diag.ptr, dplan.buffers['gramian'].ptr, total * rs.itemsize,
+            None))
+        if grad:
+            runtime.check(runtime.lib().gd_memcpy_d2d(
+                b_dgrad.ptr, dplan.buffers['gradient'].ptr,
+                total * nJ * rs.itemsize, None))
+        b_ns.upload(node_starts)
+        runtime.synchronize()
+        # 2. the pairs
+        starts = np.arange(n + 1, dtype=np.uint32)
+        if not traits.symmetric:
+            starts[nX:] = np.arange(n - nX + 1)
+        mtraits = traits._replace(nodal=True, eval_gradient=grad)
+        plan = self.prepare(
+            graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol, jobs,
+            starts, nX, nY, nJ, mtraits, timer, ngrad=grad,
+            maximin=dict(diag=b_diag.ptr,
+                         diag_grad=b_dgrad.ptr if grad else 0,
+                         node_starts=b_ns.ptr, ld=total))
+        if grad:
+            plan.buffers['gradient'].zero()
+        self.launch(plan)
+        dist, g = self.collect(plan)
+        hot = np.empty(plan.n_out, dtype=np.int32)
+        plan.buffers['hotspot'].download(hot)
+        return dist, hot, g
 
     # -- the reference's backend call ---------------------------------------------------
     def __call__(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol,

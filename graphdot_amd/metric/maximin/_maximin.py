@@ -16,11 +16,13 @@ with the *hotspot* the node pair that attains it (the largest flat index
 ``-0.5 d(k12 / sqrt(k1 k2))/dtheta / (D + 1e-4)`` taken at the hotspot
 (_backend.cu:136-140,380-402; columns of the starting probability are zero).
 
-The reference fuses this into its solver kernel.  Here the nodal matrices
-come from the HIP solver (``nodal=True`` outputs, finite-difference nodal
-gradients) and the min / max reductions are segmented numpy reductions over
-the node blocks -- the distance needs every nodal entry of every pair anyway,
-so its cost is the nodal Gram matrix.
+The reference fuses this into its solver kernel, and so does the HIP backend
+for graphs its owner-computes solvers cover (``HIPBackend.maximin_distance``:
+the reductions run in LDS in the solver's epilogue, the gradient is taken at
+the hotspot inside the launch, the nodal Gram matrix is never materialised).
+Other graphs / backends take the composition below: nodal matrices from the
+solver (``nodal=True`` outputs, finite-difference nodal gradients) and
+segmented numpy reductions over the node blocks.
 """
 import numpy as np
 from ...kernel.marginalized import MarginalizedGraphKernel
@@ -48,6 +50,9 @@ class MaxiMin(MarginalizedGraphKernel):
         """Distance matrix ``(len(X), len(Y or X))``; optionally the hotspot
         node indices ``(i1, i2)`` per pair and the gradient w.r.t. the active
         hyperparameters."""
+        fused = self._fused(X, Y, eval_gradient, lmin, return_hotspot)
+        if fused is not None:
+            return fused
         mgk = super()
         Yl = X if Y is None else Y
         nx_, sx = _segments(X)
@@ -109,6 +114,47 @@ class MaxiMin(MarginalizedGraphKernel):
                 np.asarray(self.active_theta_mask)[:self._n_p_theta()]))
             grad[..., :n_p] = 0
             out.append(grad.astype(self.element_dtype))
+        return out[0] if len(out) == 1 else tuple(out)
+
+    def _fused(self, X, Y, eval_gradient, lmin, return_hotspot):
+        """The device-fused evaluation, or None if the backend / the graphs
+        do not offer it."""
+        backend = self.backend
+        if not hasattr(backend, 'maximin_distance') or \
+                getattr(backend, 'shards_over_ranks', lambda: False)():
+            return None
+        from ...graph import Graph
+        from ...kernel.marginalized._backend_hip import NotOwnerComputes
+        graphs = list(X) if Y is None else list(X) + list(Y)
+        if Graph.has_unified_types(graphs) is not True:
+            return None            # let the composition raise the type error
+        nx, ny = len(X), len(X if Y is None else Y)
+        if Y is None:
+            i, j = np.triu_indices(nx)
+        else:
+            i, j = np.indices((nx, ny))
+            j = j + nx
+        job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
+        jobs = np.column_stack((i.ravel(), j.ravel())).astype(
+            np.uint32).ravel().view(job_t)
+        traits = self.traits(symmetric=Y is None, nodal=False, lmin=lmin,
+                             eval_gradient=eval_gradient)
+        try:
+            d, hot, g = backend.maximin_distance(
+                graphs, self.node_kernel, self.edge_kernel, self.p, self.q,
+                self.eps, self.ftol, self.gtol, jobs, nx, ny, self.n_dims,
+                traits)
+        except NotOwnerComputes:
+            return None
+        out = [d.reshape(nx, ny, order='F').astype(self.element_dtype)]
+        if return_hotspot:
+            n = np.array([len(g_.nodes) for g_ in (X if Y is None else Y)])
+            hot = hot.reshape(nx, ny, order='F')
+            out.append((hot // n[None, :], hot % n[None, :]))
+        if eval_gradient:
+            g = g.reshape(nx, ny, self.n_dims, order='F')
+            out.append(g[:, :, np.asarray(self.active_theta_mask)].astype(
+                self.element_dtype))
         return out[0] if len(out) == 1 else tuple(out)
 
     def _n_p_theta(self):

@@ -691,6 +691,7 @@ def test_maximin_distance(backend):
     knode, kedge, q = cases.config3_kernels()
     mm = MaxiMin(knode, kedge, q=q, backend=backend)
     D, (h1, h2) = mm(G, return_hotspot=True)
+    assert backend.last_plan.maximin      # fused in the solver's epilogue
     assert D.dtype == np.float32 and D.shape == (7, 7)
     assert np.allclose(np.diag(D), 0, atol=2e-3)
     assert np.array_equal(D, D.T)
@@ -725,7 +726,39 @@ def test_maximin_distance(backend):
         got = g[..., k] * np.exp(theta[k])
         assert np.allclose(got[iu], fd[iu], rtol=0.15,
                            atol=0.05 * np.abs(fd[iu]).max() + 2e-3)
-    assert np.all(g[..., 0] == 0)
+    # starting probability: the normalised similarity does not depend on a
+    # uniform p (the reference evaluates the column too, _backend.cu:222-250)
+    assert np.all(np.abs(g[..., 0]) <= 2e-2 * np.abs(g).max())
+
+
+def test_maximin_fused_vs_host_composition():
+    """The fused evaluation (HIPBackend.maximin_distance: reductions in the
+    solver's epilogue, gradient at the hotspot inside the launch) against the
+    host composition on full nodal matrices (two-stage solvers: no fused
+    path), for X, X x Y, lmin = 1 and the gradient."""
+    from graphdot_amd.metric.maximin import MaxiMin
+    from graphdot_amd.kernel.marginalized._backend_hip import (
+        HIPBackend, VARIANTS, GENERAL)
+    G = cases.config3_graphs(9, seed=31)
+    knode, kedge, q = cases.config3_kernels()
+    fused = HIPBackend()
+    host = HIPBackend(variants=VARIANTS + [GENERAL])
+    a = MaxiMin(knode, kedge, q=q, backend=fused, gtol=1e-7)
+    b = MaxiMin(knode, kedge, q=q, backend=host)
+    Da, (a1, a2), ga = a(G, return_hotspot=True, eval_gradient=True)
+    assert fused.last_plan.maximin and fused.last_plan.ngrad
+    Db, (b1, b2), gb = b(G, return_hotspot=True, eval_gradient=True)
+    assert not getattr(host.last_plan, 'maximin', False)
+    iu = np.triu_indices(len(G), 1)
+    assert np.allclose(Da[iu], Db[iu], atol=2e-4) and np.array_equal(Da, Da.T)
+    assert np.allclose(np.diag(Da), np.diag(Db), atol=3e-3)
+    same = (a1 == b1) & (a2 == b2)
+    assert same[iu].mean() > 0.9          # (near-ties may pick another pair)
+    sel = same & (np.arange(len(G))[:, None] < np.arange(len(G))[None, :])
+    scale = np.abs(gb[sel]).max(axis=0)
+    assert np.all(np.abs(ga[sel] - gb[sel]) <= 0.05 * scale + 1e-3)
+    assert np.allclose(a(G[:4], G[4:]), Da[:4, 4:], atol=1e-4)
+    assert np.allclose(a(G, lmin=1)[iu], b(G, lmin=1)[iu], atol=3e-4)
 
 
 @pytest.mark.parametrize('name', ['unlabeled', 'labeled', 'weighted'])
