@@ -731,6 +731,37 @@ def test_maximin_distance(backend):
     assert np.all(np.abs(g[..., 0]) <= 2e-2 * np.abs(g).max())
 
 
+def test_maximin_at_full_size(backend):
+    """Maximin distances of all 500 500 pairs of the 1000 QM7-like graphs in
+    one fused evaluation (the host composition would need the 15 500 x 15 500
+    nodal Gram matrix): symmetric, zero on the diagonal to the clamp's
+    resolution, and 40 sampled pairs against the definition evaluated on the
+    dense oracle's nodal solutions."""
+    from graphdot_amd.metric.maximin import MaxiMin
+    G = cases.config3_graphs(1000)
+    knode, kedge, q = cases.config3_kernels()
+    mm = MaxiMin(knode, kedge, q=q, backend=backend)
+    D, (h1, h2) = mm(G, return_hotspot=True)
+    assert backend.last_plan.maximin and D.shape == (1000, 1000)
+    assert np.array_equal(D, D.T) and np.all(np.isfinite(D))
+    assert np.abs(np.diag(D)).max() <= 3e-3
+    rng = np.random.default_rng(3)
+    self_sim = {}
+
+    def nodal_diag(g):
+        if id(g) not in self_sim:
+            R, _ = oracle.pair_value(g, g, knode, kedge, q=q, nodal=True)
+            self_sim[id(g)] = np.diag(R)
+        return self_sim[id(g)]
+    for a, b in rng.integers(0, 1000, size=(40, 2)):
+        R, _ = oracle.pair_value(G[a], G[b], knode, kedge, q=q, nodal=True)
+        d = np.sqrt(np.maximum(0, 0.9999995 - R / np.sqrt(
+            nodal_diag(G[a])[:, None] * nodal_diag(G[b])[None, :])))
+        ref = max(d.min(axis=1).max(), d.min(axis=0).max())
+        assert D[a, b] == pytest.approx(ref, abs=3e-3)
+        assert d[h1[a, b], h2[a, b]] == pytest.approx(D[a, b], abs=3e-3)
+
+
 def test_maximin_fused_vs_host_composition():
     """The fused evaluation (HIPBackend.maximin_distance: reductions in the
     solver's epilogue, gradient at the hotspot inside the launch) against the
