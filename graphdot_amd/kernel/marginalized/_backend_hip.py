@@ -260,9 +260,14 @@ class HIPBackend(Backend):
         Overrides the measured occupancy targets (also ``$GD_OCCUPANCY``).
     concurrent: bool
         One HIP stream per solver variant (default) or all on one stream.
-    tables: bool
-        Evaluate the microkernels once per pair of label classes into LDS
-        tables instead of per nonzero pair (off by default; see __init__).
+    tables: 'global' (default), 'lds' or False
+        Microkernel values per pair of label classes from tables instead of
+        per nonzero pair (see __init__).
+    min_launch: int
+        Owner-computes launches of fewer pairs are merged into the next larger
+        compatible variant in use (default 2048; 0: never).
+    nodal_gradient_in_kernel: bool
+        Nodal Jacobians inside the launch (default) or by re-launches.
     """
 
     @staticmethod
@@ -318,6 +323,8 @@ class HIPBackend(Backend):
             raise ValueError(f'tables={tables!r}: False, "lds" or "global"')
         self.tables = tables
         self._launch_set = None
+        self.min_launch = int(kwargs.pop(
+            'min_launch', os.environ.get('GD_MIN_LAUNCH', 2048)))
         self.nodal_gradient_in_kernel = bool(kwargs.pop(
             'nodal_gradient_in_kernel', True))
         if self.occupancy is None and os.environ.get('GD_OCCUPANCY'):
@@ -1022,6 +1029,27 @@ void ${name}(params_t prm) {
         # None); the jobs are ordered by the rank of their class pair with one
         # stable sort of small integers, and every per-launch maximum is taken
         # over class pairs.
+        # Launches of a few hundred pairs cannot fill 256 CUs: their jobs ride
+        # in the next larger owner-computes variant in use (same waves per
+        # pair and degree bound, S and R at least as large) -- fewer, fuller
+        # launches, which matters most for the shards of a multi-GPU run.
+        if self.min_launch > 0:
+            members_ = np.ones(len(choice), dtype=np.int64) if sel is None \
+                else np.bincount(sel, minlength=len(choice))
+            used_ = sorted(set(choice.tolist()))
+            for a_, k in enumerate(used_):
+                v = self.variants[k]
+                if not isinstance(v, OCVariant):
+                    continue
+                here = choice == k
+                if int(members_[here].sum()) >= self.min_launch:
+                    continue
+                for k2 in used_[a_ + 1:]:
+                    v2 = self.variants[k2]
+                    if (isinstance(v2, OCVariant) and v2.W == v.W
+                            and v2.D == v.D and v2.S >= v.S and v2.R >= v.R):
+                        choice = np.where(here, k2, choice)
+                        break
         rank_of = np.empty(len(choice), dtype=np.int64)
         by_rank = np.lexsort((-cost, choice))
         # class pairs of equal (variant, cost) share a rank: their jobs stay
