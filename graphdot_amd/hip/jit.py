@@ -31,14 +31,23 @@ class CompileError(RuntimeError):
 
 
 def hipcc_version():
+    """Identity of the compiler for the cache key.  Read from the ROCm
+    installation's version file when there is one -- running
+    ``hipcc --version`` pages the whole compiler in, tens of seconds on a
+    fresh machine, which a run served entirely from the cache never needs."""
     global _version
     if _version is None:
+        root = os.path.dirname(os.path.dirname(os.path.realpath(HIPCC)))
         try:
-            out = subprocess.run([HIPCC, '--version'], capture_output=True,
-                                 text=True).stdout
-            _version = out.splitlines()[0] if out else 'unknown'
-        except OSError as e:
-            raise CompileError(f'hipcc not found at {HIPCC}: {e}')
+            with open(os.path.join(root, '.info', 'version')) as f:
+                _version = 'rocm ' + f.read().strip()
+        except OSError:
+            try:
+                out = subprocess.run([HIPCC, '--version'],
+                                     capture_output=True, text=True).stdout
+                _version = out.splitlines()[0] if out else 'unknown'
+            except OSError as e:
+                raise CompileError(f'hipcc not found at {HIPCC}: {e}')
     return _version
 
 

@@ -322,6 +322,12 @@ def distributed_backend(**kwargs):
     class DistributedHIPBackend(HIPBackend):
 
         def __init__(self, shard_single_rank=False, collective='torch', **kw):
+            # Which solver variant a pair runs on must not depend on the
+            # shard it falls into: the variants are different instantiations
+            # (compiled with fast-math) and agree to round-off only.  Without
+            # launch merging the results are bit-identical for any number of
+            # ranks (and to HIPBackend(min_launch=0) on one GPU).
+            kw.setdefault('min_launch', 0)
             super().__init__(**kw)
             self.shard_single_rank = shard_single_rank
             self.collective = collective
