@@ -328,6 +328,57 @@ def test_random_graphs_all_variants(backend, variant):
     assert it.min() >= 1 and it.max() < 200
 
 
+@pytest.mark.parametrize('real', [np.float32, np.float64])
+def test_multi_wave_owner_computes_all_outputs(real):
+    """Weighted random graphs of 20..48 nodes with degrees 4..7 run on the
+    D = 8 owner-computes solvers with 4, 8 and 16 waves per pair: analytic
+    gradient (element-wise bound against the C restatement of compute_duo +
+    derivative), nodal outputs, lmin = 1, `diag`, and the in-launch nodal
+    Jacobian against the host-orchestrated re-launches."""
+    from graphdot_amd.kernel.marginalized._backend_hip import (
+        HIPBackend, OCVariant)
+    G = cases.config2_graphs(8, nmin=20, nmax=48, seed=11)
+    knode, kedge, q = cases.config2b_kernels()
+    backend = HIPBackend(real=real)
+    k = MarginalizedGraphKernel(
+        knode, kedge, q=q, backend=backend,
+        ftol=1e-8 if real is np.float32 else 1e-13)
+    K, dK = k(G, eval_gradient=True)
+    used = {(type(L['variant']), L['variant'].W)
+            for L in backend.last_plan.launches}
+    assert {(OCVariant, 4), (OCVariant, 8)} <= used, used
+    i, j = np.triu_indices(len(G))
+    batch = oracle.TensorProductBatch(G, knode, kedge)
+    ref_v, ref_g, _ = batch.run_gradient(i, j, q=q, real='f64')
+    mask = k.active_theta_mask
+    assert np.allclose(K[i, j], ref_v, rtol=1e-5 if real is np.float32 else 1e-8)
+    assert elementwise_gradient_error(
+        dK[i, j, :], ref_g[:, mask],
+        *((2e-3, 2e-5) if real is np.float32 else (1e-6, 1e-9))) <= 1
+    ref, _ = batch.run(i, j, q=q, real='f64', tol=1e-14, lmin=1)
+    assert np.allclose(k(G, lmin=1)[i, j], ref,
+                       rtol=2e-5 if real is np.float32 else 1e-8)
+    Kn = k(G[:3], nodal=True)
+    assert np.allclose(Kn, oracle.gram(G[:3], knode, kedge, q=q, nodal=True),
+                       rtol=2e-5 if real is np.float32 else 1e-8)
+    assert np.allclose(k.diag(G), np.diag(K),
+                       rtol=1e-6 if real is np.float32 else 1e-9)
+    # nodal Jacobian: in the launch (tight gtol) against re-launches
+    tight = 3e-8 if real is np.float32 else 1e-12
+    a = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend,
+                                gtol=tight, ftol=k.ftol)
+    b = MarginalizedGraphKernel(
+        knode, kedge, q=q, ftol=k.ftol,
+        backend=HIPBackend(real=real, nodal_gradient_in_kernel=False))
+    Ra, dRa = a(G[:3], nodal=True, eval_gradient=True)
+    assert backend.last_plan.ngrad
+    Rb, dRb = b(G[:3], nodal=True, eval_gradient=True)
+    scale = np.abs(dRb).max(axis=(0, 1), keepdims=True)
+    assert np.allclose(Ra, Rb, rtol=2e-6)
+    assert np.all(np.abs(dRa - dRb) <=
+                  (3e-3 if real is np.float32 else 1e-5) * scale)
+
+
 def test_qm7_like_sample(backend):
     """config 3 family at a size the oracle finishes in seconds."""
     G = cases.config3_graphs(40, seed=99)
