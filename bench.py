@@ -19,6 +19,8 @@ job list and hyperparameters into the device-resident result.
                         time_kernel.py:14-29), fp32 by default (the reference
                         solver's arithmetic)
   --gradient            value + dK/dtheta (the kernel part of config 5)
+  --gpr                 config 5 end to end on one GPU: GPR log marginal
+                        likelihood + gradient step (kernel + dense algebra)
 
 With N > 1 (launched by torch.distributed.run, one rank per GPU) the pairs are
 sharded over the ranks and one RCCL all-gather per step reassembles the packed
@@ -68,6 +70,13 @@ def parse():
                     help='skip the short measurement in the other arithmetic')
     ap.add_argument('--gradient', action='store_true',
                     help='also evaluate dK/dtheta (config 5 kernel part)')
+    ap.add_argument('--gpr', action='store_true',
+                    help='configuration 5 end to end on one GPU: a step is one '
+                         'log-marginal-likelihood + gradient evaluation of a '
+                         'Gaussian process on the set (kernel + dK/dtheta on '
+                         'the solver, dense algebra through torch on the same '
+                         'GPU); value = pairs of the Gram matrix per second of '
+                         'that step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api', action='store_true',
                     help='skip the numpy-in / numpy-out measurement')
@@ -203,8 +212,60 @@ def measure_api(graphs, knode, kedge, q, real, device, gradient, n_pairs):
             'note': 'host-, PCIe- and conversion-inclusive; never `value`'}
 
 
+def gpr_step_line(args):
+    """`--gpr`: the caller of configuration 5 (SURVEY 8f rank 3,
+    graphdot/model/gaussian_process/gpr.py:222-268) on one GPU."""
+    import torch                                    # noqa: F401  (first)
+    import cases
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    from graphdot_amd.model.gaussian_process import GaussianProcessRegressor
+    real = np.float32 if args.dtype == 'f32' else np.float64
+    n = args.graphs or 1000
+    graphs = cases.config3_graphs(n)
+    knode, kedge, q = cases.config3_kernels()
+    kernel = MarginalizedGraphKernel(knode, kedge, q=q,
+                                     backend=HIPBackend(real=real))
+    y = np.random.default_rng(0).normal(size=n)
+    d = kernel.diag(graphs)
+    gpr = GaussianProcessRegressor(kernel, alpha=float(1e-2 * d.mean()),
+                                   normalize_y=True)
+    gpr.X, gpr.y = graphs, y
+    theta = np.array(kernel.theta)
+    parts = {'kernel': 0.0, 'linalg': 0.0}
+    for w in range(max(args.warmup, 1)):
+        gpr.log_marginal_likelihood(theta + 1e-3 * w, eval_gradient=True)
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        gpr.log_marginal_likelihood(theta + 1e-3 * it, eval_gradient=True)
+        for k in parts:
+            parts[k] += gpr.last_timing[k]
+    dt = (time.perf_counter() - t0) / args.steps
+    n_pairs = n * (n + 1) // 2
+    return {
+        'metric': 'graph-pairs/sec (GPR likelihood + gradient step)',
+        'value': n_pairs / dt, 'unit': 'graph-pairs/s', 'n_gpus': 1,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': f'GPR log marginal likelihood + gradient on '
+                               f'the QM7-like set ({n} molecules, {n_pairs} '
+                               'pairs, 7 hyperparameters): value + dK/dtheta '
+                               'on the solver, Cholesky and the gradient '
+                               'contractions in float64 torch on the same GPU',
+                   'graphs': n, 'pairs': n_pairs, 'parallelism': 'single'},
+        'kernel_ms': 1e3 * parts['kernel'] / args.steps,
+        'dense_algebra_ms': 1e3 * parts['linalg'] / args.steps,
+        'roofline': None, 'cpu_baseline': None}
+
+
 def main():
     args = parse()
+    if args.gpr:
+        if args.dtype is None:
+            args.dtype = 'f32'
+        print(json.dumps(gpr_step_line(args)), flush=True)
+        return
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))

@@ -11,7 +11,7 @@ if [ "$what" = tests ] || [ "$what" = all ]; then
   tail -30 gpurun_out/pytest_gpu.log
 fi
 if [ "$what" = bench ] || [ "$what" = all ]; then
-  for tag in "f64:" "f32:--dtype f32" "grad64:--gradient" "grad32:--gradient --dtype f32" "c2:--config 2" "c2f64:--config 2 --dtype f64"; do
+  for tag in "f64:" "f32:--dtype f32" "grad64:--gradient" "grad32:--gradient --dtype f32" "c2:--config 2" "c2f64:--config 2 --dtype f64" "gpr:--gpr" "gpr64:--gpr --dtype f64"; do
     name=${tag%%:*}; args=${tag#*:}
     timeout 900 python bench.py $args > gpurun_out/bench_$name.json 2> gpurun_out/bench_$name.err
     echo "bench $name rc=$?"; head -c 300 gpurun_out/bench_$name.json; echo
