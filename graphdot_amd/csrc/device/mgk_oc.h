@@ -189,17 +189,11 @@ struct oc_solver {
         const int lane = wave::laneid();
         const int tid = (W == 1) ? lane : (int)threadIdx.x;
         const int wv = (W == 1) ? 0 : uni((int)(threadIdx.x / 64));
-        // dynamic LDS: [p: u_capacity * C reals][Y: NR * C reals]
-        //              [rowmap | rowcsr | rowdeg: NR u32 each][G1][G2]
+        // dynamic LDS: [p: u_capacity * C reals][Y: NR * C reals][rowmap: NR u32][G1][G2]
         real *const lp = dyn;
         real *const lY = lp + (size_t)prm.u_capacity * C;
-        // per sorted row: (i1 << 16) | i2, (row start 1 << 16) | row start 2,
-        // (deg1 << 16) | deg2 -- everything the slot walks need, written
-        // once, read lane-contiguously (no dependent row-pointer reads)
         unsigned *const rowmap = reinterpret_cast<unsigned *>(lY + (size_t)NR * C);
-        unsigned *const rowcsr = rowmap + NR;
-        unsigned *const rowdeg = rowcsr + NR;
-        char *const lG1 = reinterpret_cast<char *>(rowdeg + NR);
+        char *const lG1 = reinterpret_cast<char *>(rowmap + NR);
         char *const lG2 = lG1 + prm.g_capacity;
         real *const red = lds.red;
         const unsigned lY_off = uni((int)lds_offset(lY));
@@ -320,17 +314,12 @@ struct oc_solver {
                     const bool ok = k * T + tid < N;
                     const int i1 = ok ? row.hi : 0, i2 = ok ? row.lo : 0;
                     row.next();
-                    const int rs1 = lrp1[i1], rs2 = lrp2[i2];
-                    const int d1 = (int)lrp1[i1 + 1] - rs1;
-                    const int d2 = (int)lrp2[i2 + 1] - rs2;
+                    const int d1 = (int)lrp1[i1 + 1] - (int)lrp1[i1];
+                    const int d2 = (int)lrp2[i2 + 1] - (int)lrp2[i2];
                     const int pos = lds.tab_off[d1 * NC + d2] +
                                     (i1 - lds.tab_cls[d1]) * lds.tab_cls[16 + d2] +
                                     (i2 - lds.tab_cls[32 + d2]);
-                    if (ok) {
-                        rowmap[pos] = ((unsigned)i1 << 16) | (unsigned)i2;
-                        rowcsr[pos] = ((unsigned)rs1 << 16) | (unsigned)rs2;
-                        rowdeg[pos] = ((unsigned)d1 << 16) | (unsigned)d2;
-                    }
+                    if (ok) rowmap[pos] = ((unsigned)i1 << 16) | (unsigned)i2;
                 }
             }
             job_sync<W>();
@@ -339,15 +328,14 @@ struct oc_solver {
                 row_t r;
                 const int pos = kb * T + tid;
                 const bool ok = pos < N;
-                const int at = ok ? pos : 0;
-                const unsigned rm = rowmap[at], cs = rowcsr[at], dd = rowdeg[at];
+                const unsigned rm = rowmap[ok ? pos : 0];
                 r.i1 = (int)(rm >> 16);
                 r.i2 = (int)(rm & 0xFFFFu);
-                r.rs1 = (int)(cs >> 16);
-                r.rs2 = (int)(cs & 0xFFFFu);
-                r.d1 = (int)(dd >> 16);
-                r.d2 = (int)(dd & 0xFFFFu);
-                r.prod = ok ? r.d1 * r.d2 : 0;
+                r.rs1 = lrp1[r.i1];
+                r.rs2 = lrp2[r.i2];
+                r.d1 = ok ? (int)lrp1[r.i1 + 1] - r.rs1 : 0;
+                r.d2 = ok ? (int)lrp2[r.i2 + 1] - r.rs2 : 0;
+                r.prod = r.d1 * r.d2;
                 return r;
             };
 
@@ -366,8 +354,9 @@ struct oc_solver {
                     const int pos = k * T + 64 * wv;
                     int trip = 0;
                     if (pos < N) {
-                        const unsigned dd = (unsigned)uni((int)rowdeg[pos]);
-                        trip = (int)(dd >> 16) * (int)(dd & 0xFFFFu);
+                        const unsigned rm = (unsigned)uni((int)rowmap[pos]);
+                        const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
+                        trip = uni(((int)lrp1[i1 + 1] - (int)lrp1[i1]) * ((int)lrp2[i2 + 1] - (int)lrp2[i2]));
                     }
                     if (trip > 0) {
                         n_slots += trip;
@@ -387,10 +376,10 @@ struct oc_solver {
                         ? ((unsigned)(cur.rs1 + ja) << 16) | (unsigned)(cur.rs2 + jb) : ~0u;
                     asm volatile("" : "+v"(adr[s]));
                     ++j;
-                    {   // (jb, ja) = next nonzero pair of the row, as selects
-                        const bool wrap = jb + 1 >= cur.d2;
-                        jb = wrap ? 0 : jb + 1;
-                        ja += wrap ? 1 : 0;
+                    ++jb;
+                    if (jb >= cur.d2) {
+                        jb = 0;
+                        ++ja;
                     }
                     if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
                         ++kb;
@@ -842,10 +831,10 @@ struct oc_solver {
                             const real e = ek(g1.edge[a], g2.edge[b]);
                             val[s] = ok ? e : real(0);
                             ++j;
-                            {
-                                const bool wrap = jb + 1 >= cur.d2;
-                                jb = wrap ? 0 : jb + 1;
-                                ja += wrap ? 1 : 0;
+                            ++jb;
+                            if (jb >= cur.d2) {
+                                jb = 0;
+                                ++ja;
                             }
                             if ((fm[s / 32] >> (s % 32)) & 1u) {
                                 ++kb;
@@ -999,10 +988,10 @@ struct oc_solver {
                                 for (int jj = 0; jj < EdgeK::jac_dims; ++jj) jac[off_e + jj] += w * real(de[jj]);
                             }
                             ++j;
-                            {
-                                const bool wrap = jb + 1 >= cur.d2;
-                                jb = wrap ? 0 : jb + 1;
-                                ja += wrap ? 1 : 0;
+                            ++jb;
+                            if (jb >= cur.d2) {
+                                jb = 0;
+                                ++ja;
                             }
                             if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
                                 ++kb;

@@ -633,7 +633,7 @@ struct ${name}_t : ${name}_theta_t {
     _OC_WAVES = {
         (False, 1): {(1, 12, 2, 4): 6, (1, 16, 3, 4): 6, (1, 20, 3, 4): 6,
                      (1, 20, 4, 4): 4, (1, 24, 4, 4): 5, (1, 28, 5, 4): 4,
-                     (1, 28, 6, 4): 4, (1, 32, 7, 4): 3, (1, 36, 9, 4): 2,
+                     (1, 28, 6, 4): 4, (1, 32, 7, 4): 4, (1, 36, 9, 4): 2,
                      (1, 32, 3, 8): 2, (1, 48, 5, 8): 2, (1, 64, 9, 8): 2,
                      (4, 32, 3, 8): 3, (4, 48, 4, 8): 2, (4, 64, 5, 8): 3,
                      (8, 48, 3, 8): 4, (8, 64, 4, 8): 2, (16, 48, 3, 8): 4,
@@ -766,7 +766,7 @@ void ${name}(params_t prm) {
             rs = np.dtype(self.real).itemsize
             NR = 64 * v.W * v.R
             pcap = -(-(np.asarray(ntask) + 1) // 4) * 4
-            return (pcap + NR) * C * rs + 12 * NR + 2 * np.asarray(gbytes) \
+            return (pcap + NR) * C * rs + 4 * NR + 2 * np.asarray(gbytes) \
                 + 2 * v.W * rs + 4 * (128 if v.D > 6 else 64) + 256
         wpb = WPB1 if v.W == 1 else 1
         T = 64 * v.W
@@ -1087,11 +1087,11 @@ void ${name}(params_t prm) {
                 continue
             if isinstance(v, OCVariant):
                 # one pair per workgroup; dynamic LDS: p | row sums | row map
-                # (three words per row) | two images (mgk_oc.h)
+                # | two images (mgk_oc.h)
                 pcap = int(-(-(NP[idx].max() + 1) // 4) * 4)
                 gcap = int(-(-gbytes_oc[idx].max() // 16) * 16)
                 NR = 64 * v.W * v.R
-                dyn = (pcap + NR) * C * rsize + 12 * NR + 2 * gcap
+                dyn = (pcap + NR) * C * rsize + 4 * NR + 2 * gcap
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=pcap, gcap=gcap,
                     dynamic_lds=dyn, count=count,

@@ -29,8 +29,7 @@ node_t, edge_t = dgs[0].node_t, dgs[0].edge_t
 ke2 = ke
 oc = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--oc=')]
 variant = OCVariant(W, S, R, oc[0]) if oc else Variant(W, S, R)
-src = backend.render_source(kn, ke2, k.p, node_t, edge_t, [variant], C,
-                            tab='--tab' in sys.argv)
+src = backend.render_source(kn, ke2, k.p, node_t, edge_t, [variant], C)
 path = f'/tmp/_dump_isa_{W}_{S}_{R}_{C}_{int(real is np.float64)}.hip'
 open(path, 'w').write(src)
 flags = [f for f in jit.BASE_FLAGS if f != '--genco'] + \
