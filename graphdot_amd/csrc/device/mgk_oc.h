@@ -138,6 +138,47 @@ struct params_fd_t {
 // the non-negative float distances (order independent: deterministic), the
 // n1 x n2 nodal block never leaves the CU.  k1, k2 (and their Jacobians) are
 // the nodal self-similarities of the two graphs from a `diag` launch.
+// Workgroup sums with ONE barrier each: the per-wave partials go to one of two
+// scratch halves, and consecutive reductions alternate between them -- the
+// barrier of reduction k + 1 (other half) is behind every wave's reads of
+// reduction k, so half k % 2 can be rewritten at reduction k + 2 without the
+// "previous readers are done" barrier block_reduce needs (5 -> 3 barriers per
+// CG iteration for the multi-wave pairs).
+template<class real, int W> struct alternating_reduce {
+    __device__ static __forceinline__ void sum2(real &a, real &b, real *half) {
+        wave::sum2(a, b);
+        if constexpr (W > 1) {
+            const int w = threadIdx.x / 64;
+            if (wave::laneid() == 0) {
+                half[2 * w] = a;
+                half[2 * w + 1] = b;
+            }
+            __syncthreads();
+            real sa = 0, sb = 0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                sa += half[2 * k];
+                sb += half[2 * k + 1];
+            }
+            a = sa;
+            b = sb;
+        }
+    }
+    __device__ static __forceinline__ real sum(real a, real *half) {
+        a = wave::sum(a);
+        if constexpr (W > 1) {
+            const int w = threadIdx.x / 64;
+            if (wave::laneid() == 0) half[2 * w] = a;
+            __syncthreads();
+            real sa = 0;
+#pragma unroll
+            for (int k = 0; k < W; ++k) sa += half[2 * k];
+            a = sa;
+        }
+        return a;
+    }
+};
+
 template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB, bool NGRAD, bool MAXIMIN, class Graph, class NodeK, class EdgeK, class PStart>
 struct oc_solver {
     static_assert(!MAXIMIN || (NODAL && C == 1), "the maximin epilogue works on the nodal solution of a value solve");
@@ -173,7 +214,7 @@ struct oc_solver {
     constexpr static class_order<DMAX> ORD{};
 
     struct lds_t {
-        real red[2 * W];
+        real red[2][2 * W];     // two halves: see alternating_reduce
         int tab_off[NTAB];      // sorted-row offset of rectangle d1 * NC + d2
         int tab_cls[64];        // [0..NC) start1, [16..) cnt2, [32..) start2
     };
@@ -195,7 +236,8 @@ struct oc_solver {
         unsigned *const rowmap = reinterpret_cast<unsigned *>(lY + (size_t)NR * C);
         char *const lG1 = reinterpret_cast<char *>(rowmap + NR);
         char *const lG2 = lG1 + prm.g_capacity;
-        real *const red = lds.red;
+        real *const red0 = lds.red[0], *const red1 = lds.red[1];
+        using reduce = alternating_reduce<real, W>;
         const unsigned lY_off = uni((int)lds_offset(lY));
         graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
         const int dump = (int)prm.u_capacity - 1;   // cell that dead rows publish to
@@ -455,7 +497,8 @@ struct oc_solver {
                 }
             };
             publish(p);
-            rTz = block_reduce<real, W>::sum(rTz, red);
+            job_sync<W>();   // the previous pair's last reduction is read
+            rTz = reduce::sum(rTz, red1);
 
             const real tol = (C == 2) ? real(1e-10) * real(2 * N) : prm.ftol * real(N);
             const real tol2 = tol * tol;
@@ -523,7 +566,7 @@ struct oc_solver {
                         pAp += p[c][k] * Ap[c][k];
                     }
                 }
-                pAp = block_reduce<real, W>::sum(pAp, red);
+                pAp = reduce::sum(pAp, red0);
                 if (pAp == real(0)) break;
                 const real alpha = rTz / pAp;
                 real rTr = 0, rTz_next = 0;
@@ -544,7 +587,7 @@ struct oc_solver {
                         rTr += r[c][k] * r[c][k];
                         rTz_next += r[c][k] * z[c][k];
                     }
-                block_reduce<real, W>::sum2(rTr, rTz_next, red);
+                reduce::sum2(rTr, rTz_next, red1);
                 if (rTr < tol2) {   // sqrt(rTr) < tol
                     ++it;
                     break;
@@ -687,7 +730,8 @@ struct oc_solver {
                 job_sync<W>();   // lY is the row-sum scratch again below
             }
             if (!NODAL || !(flags & F_NODAL)) {
-                ksum = block_reduce<real, W>::sum(ksum, red);
+                job_sync<W>();   // (the loop may have left through either half)
+                ksum = reduce::sum(ksum, red0);
                 if (tid == 0) {
                     if (flags & F_PACKED) {
                         prm.gramian[prm.order[t]] = ksum;
@@ -859,7 +903,7 @@ struct oc_solver {
                         pv[k] = mi[k] * rr[k];
                         rz += rr[k] * pv[k];
                     }
-                    rz = block_reduce<real, W>::sum(rz, red);
+                    rz = reduce::sum(rz, red1);
                     for (unsigned itw = 0; itw < (unsigned)N && rz != real(0); ++itw) {
                         job_sync<W>();
                         publish1(pv);
@@ -871,7 +915,7 @@ struct oc_solver {
                             y[k] = dg[k] * pv[k] - y[k];
                             pAp += pv[k] * y[k];
                         }
-                        pAp = block_reduce<real, W>::sum(pAp, red);
+                        pAp = reduce::sum(pAp, red0);
                         if (pAp == real(0)) break;
                         const real alpha = rz / pAp;
                         real rTr = 0, rz_next = 0;
@@ -882,7 +926,7 @@ struct oc_solver {
                             rTr += rr[k] * rr[k];
                             rz_next += rr[k] * rr[k] * mi[k];
                         }
-                        block_reduce<real, W>::sum2(rTr, rz_next, red);
+                        reduce::sum2(rTr, rz_next, red1);
                         if (rTr < gt2) break;
                         const real beta = rz_next / rz;
 #pragma unroll
@@ -1003,7 +1047,7 @@ struct oc_solver {
                 }
 #pragma unroll
                 for (int j = 0; j < n_jac; ++j) {
-                    const real g = block_reduce<real, W>::sum(jac[j], red);
+                    const real g = reduce::sum(jac[j], (j & 1) ? red1 : red0);
                     if (tid == 0) {
                         if (flags & F_PACKED) {
                             prm.gradient[(size_t)prm.order[t] * n_jac + j] = g;
