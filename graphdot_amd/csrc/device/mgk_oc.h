@@ -221,6 +221,17 @@ struct oc_solver {
 
     __device__ static __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+    // Sorted position of the row that thread `tid` (lane `lane` of wave `wv`)
+    // owns in batch k.  The 64-row chunks of a batch go to the waves in snake
+    // order (wave w takes chunk w in even batches, chunk W - 1 - w in odd
+    // ones): the rows are sorted by cost, and dealt plainly wave 0 would hold
+    // the heaviest chunk of every batch -- its slot count, which every other
+    // wave waits for at the barriers, is 36 % (8 waves) / 49 % (16 waves)
+    // above the mean on configuration 2, 25 % / 23 % in snake order.
+    __device__ static __forceinline__ int row_pos(int k, int wv, int lane) {
+        return k * T + 64 * ((k & 1) ? W - 1 - wv : wv) + lane;
+    }
+
     struct row_t {        // the row a lane is filling slots for
         int i1, i2, rs1, rs2, d1, d2, prod;
     };
@@ -368,7 +379,7 @@ struct oc_solver {
 
             auto open_row = [&](int kb) -> row_t {
                 row_t r;
-                const int pos = kb * T + tid;
+                const int pos = row_pos(kb, wv, lane);
                 const bool ok = pos < N;
                 const unsigned rm = rowmap[ok ? pos : 0];
                 r.i1 = (int)(rm >> 16);
@@ -393,7 +404,7 @@ struct oc_solver {
                 // wave = degree product of its first row -> flush mask
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const int pos = k * T + 64 * wv;
+                    const int pos = row_pos(k, wv, 0);
                     int trip = 0;
                     if (pos < N) {
                         const unsigned rm = (unsigned)uni((int)rowmap[pos]);
@@ -461,7 +472,7 @@ struct oc_solver {
             real rTz = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const int pos = k * T + tid;
+                const int pos = row_pos(k, wv, lane);
                 const bool ok = pos < N;
                 const unsigned rm = rowmap[ok ? pos : 0];
                 const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
@@ -614,7 +625,7 @@ struct oc_solver {
                 if (flags & F_LMIN1) {   // minus sum_i pp_i kappa_v(i) q^2/q0^2
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        const int pos = k * T + tid;
+                        const int pos = row_pos(k, wv, lane);
                         const bool ok = pos < N;
                         const unsigned rm = rowmap[ok ? pos : 0];
                         const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
@@ -625,7 +636,7 @@ struct oc_solver {
             } else {
 #pragma unroll
             for (int k = 0; k < R; ++k) {
-                const int pos = k * T + tid;
+                const int pos = row_pos(k, wv, lane);
                 const bool ok = pos < N;
                 const unsigned rm = rowmap[ok ? pos : 0];
                 const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
@@ -670,7 +681,7 @@ struct oc_solver {
                 real k12v[R];
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const int pos = k * T + tid;
+                    const int pos = row_pos(k, wv, lane);
                     const bool ok = pos < N;
                     const unsigned rm = rowmap[ok ? pos : 0];
                     const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
@@ -693,7 +704,7 @@ struct oc_solver {
                 const unsigned Dbits = cell[0];
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const int pos = k * T + tid;
+                    const int pos = row_pos(k, wv, lane);
                     if (pos < N && __float_as_uint(dloc[k]) == Dbits) {
                         const unsigned rm = rowmap[pos];
                         const unsigned o1 = g1.perm[rm >> 16], o2 = g2.perm[rm & 0xFFFFu];
@@ -716,7 +727,7 @@ struct oc_solver {
                 }
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const int pos = k * T + tid;
+                    const int pos = row_pos(k, wv, lane);
                     const unsigned rm = rowmap[pos < N ? pos : 0];
                     const unsigned o1 = g1.perm[rm >> 16], o2 = g2.perm[rm & 0xFFFFu];
                     mm_own[k] = pos < N && o1 * (unsigned)n2 + o2 == hot;
@@ -770,7 +781,7 @@ struct oc_solver {
                     }
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        const int pos = k * T + tid;
+                        const int pos = row_pos(k, wv, lane);
                         if (pos < N) {
                             const unsigned rm = rowmap[pos];
                             const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
@@ -792,7 +803,7 @@ struct oc_solver {
                     real col[PStart::jac_dims > 0 ? PStart::jac_dims : 1][R];
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        const int pos = k * T + tid;
+                        const int pos = row_pos(k, wv, lane);
                         const bool ok = pos < N;
                         const unsigned rm = rowmap[ok ? pos : 0];
                         const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
@@ -852,7 +863,7 @@ struct oc_solver {
                     const real s = real(1) / ((real(1) - qv) * (real(1) - qv));
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        const int pos = k * T + tid;
+                        const int pos = row_pos(k, wv, lane);
                         const bool ok = pos < N;
                         const unsigned rm = rowmap[ok ? pos : 0];
                         const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
@@ -977,7 +988,7 @@ struct oc_solver {
                 const real Q = real(1) / (real(1) - q), Q3 = Q * Q * Q;
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    const int pos = k * T + tid;
+                    const int pos = row_pos(k, wv, lane);
                     const bool ok = pos < N;
                     const unsigned rm = rowmap[ok ? pos : 0];
                     const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);

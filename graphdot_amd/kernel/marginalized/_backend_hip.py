@@ -803,8 +803,9 @@ void ${name}(params_t prm) {
     def oc_slots_needed(hist1, hist2, W, D):
         """Slots per lane of the owner-computes walk (mgk_oc.h): rows are
         sorted by descending degree product -- rectangle (d1, d2) holds
-        hist1[d1] * hist2[d2] rows -- and dealt in batches of T = 64 W; wave w
-        of batch k walks the product of its first row.  `hist*`: (n_jobs,
+        hist1[d1] * hist2[d2] rows -- and dealt in batches of T = 64 W, the
+        64-row chunks of a batch to the waves in snake order; a wave walks, per
+        batch, the product of the first row of its chunk.  `hist*`: (n_jobs,
         D + 1) degree histograms of the two graphs.  Returns the maximum over
         the waves."""
         order = sorted(((a, b) for a in range(D + 1) for b in range(D + 1)),
@@ -825,8 +826,10 @@ void ${name}(params_t prm) {
         shift = np.arange(n, dtype=np.int64) * stride
         flat = (cum + shift[:, None]).ravel()
         worst = np.zeros(n, dtype=np.int64)
+        kk = np.arange(nb, dtype=np.int64)
         for w in range(W):
-            first = np.arange(nb, dtype=np.int64) * T + 64 * w
+            # (snake order of the chunks over the waves: mgk_oc.h, row_pos)
+            first = kk * T + 64 * np.where(kk % 2 == 1, W - 1 - w, w)
             c = np.searchsorted(flat, (first[None, :] + shift[:, None]).ravel(),
                                 side='right').reshape(n, nb) \
                 - (np.arange(n, dtype=np.int64) * ncp)[:, None]

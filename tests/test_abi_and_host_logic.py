@@ -157,7 +157,7 @@ def test_owner_computes_classification():
         # ties in the rectangle order (d1, d2) ascending, then row-major
         rows = sorted(((-int(x) * int(y), int(x), int(y))
                        for x in d1 for y in d2))
-        need = sum(-rows[t][0] for t in range(0, len(rows), 64))
+        need = sum(-rows[t][0] for t in range(0, len(rows), 64))   # (W = 1)
         assert need <= v.S and len(rows) <= 64 * v.R
         assert backend.lds_bytes(v, 1, NP[k], gb_oc[k]) <= 160 * 1024
     # graphs with nodes of degree 5..8 take the D = 8 kernels, and the
@@ -171,6 +171,33 @@ def test_owner_computes_classification():
         v = backend.variants[c]
         assert isinstance(v, OCVariant)
         assert v.D == (8 if max(md[a], md[b]) > 4 else 4)
+    # multi-wave pairs: the 64-row chunks of a batch go to the waves in snake
+    # order; a wave walks, per batch, the product of its chunk's first row
+    G3 = cases.config2_graphs(10, nmin=24, nmax=48, seed=2)
+    dg3 = [backend._register_graph(g) for g in G3]
+    i3, j3 = np.triu_indices(len(G3))
+    c3, *_ = backend.classify(i3, j3, dg3, 1)
+    seen_w = set()
+    for c, a, b in zip(c3, i3, j3):
+        v = backend.variants[c]
+        if not isinstance(v, OCVariant):
+            continue
+        seen_w.add(v.W)
+        prod = np.sort(np.outer(dg3[a].adjacency_count,
+                                dg3[b].adjacency_count).ravel())[::-1]
+        T, worst = 64 * v.W, 0
+        for w in range(v.W):
+            total, k = 0, 0
+            while True:
+                first = k * T + 64 * ((v.W - 1 - w) if k % 2 else w)
+                if k * T >= len(prod):
+                    break
+                if first < len(prod):
+                    total += int(prod[first])
+                k += 1
+            worst = max(worst, total)
+        assert worst <= v.S and len(prod) <= T * v.R
+    assert seen_w & {4, 8, 16}
     two_stage = HIPBackend(variants=VARIANTS)
     c3, *_ = two_stage.classify(np.array([0, 1]), np.array([2, 3]), dg2, 1)
     assert all(not isinstance(two_stage.variants[c], OCVariant) for c in c3)
