@@ -56,9 +56,11 @@ OC_VARIANTS = [
     OCVariant(1, 20, 4, 4), OCVariant(1, 24, 4, 4), OCVariant(1, 28, 5, 4),
     OCVariant(1, 28, 6, 4), OCVariant(1, 32, 7, 4), OCVariant(1, 36, 9, 4),
     OCVariant(1, 32, 3, 8), OCVariant(1, 48, 5, 8), OCVariant(1, 64, 9, 8),
-    OCVariant(4, 32, 3, 8), OCVariant(4, 48, 4, 8), OCVariant(4, 64, 5, 8),
-    OCVariant(8, 48, 3, 8), OCVariant(8, 64, 4, 8),
-    OCVariant(16, 32, 2, 8), OCVariant(16, 48, 3, 8), OCVariant(16, 64, 3, 8),
+    OCVariant(4, 32, 3, 8), OCVariant(4, 40, 2, 8), OCVariant(4, 48, 4, 8),
+    OCVariant(4, 64, 5, 8),
+    OCVariant(8, 40, 2, 8), OCVariant(8, 48, 3, 8), OCVariant(8, 64, 4, 8),
+    OCVariant(16, 32, 2, 8), OCVariant(16, 40, 2, 8), OCVariant(16, 48, 3, 8),
+    OCVariant(16, 64, 3, 8),
 ]
 #: sentinel: the global-memory general solver (any pair size)
 GENERAL = Variant(0, 0, 0)
