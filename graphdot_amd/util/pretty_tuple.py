@@ -2,10 +2,17 @@
 indented -- the shape ``MarginalizedGraphKernel.hyperparameters`` returns
 (reference: ``graphdot/util/pretty_tuple.py:7-30``)."""
 from collections import namedtuple
+from functools import lru_cache
 
 
 def pretty_tuple(typename, fields):
-    fields = list(fields)
+    # (building a namedtuple class costs ~70 us; `theta` properties ask for
+    # the same few classes dozens of times per kernel evaluation)
+    return _pretty_tuple(typename, tuple(fields))
+
+
+@lru_cache(maxsize=None)
+def _pretty_tuple(typename, fields):
     base = namedtuple(typename, fields)
 
     def _repr(self):
