@@ -46,7 +46,9 @@ try:
         everything = {'f32': everything}
 except (OSError, ValueError):
     everything = {}
-everything[bench['dtype']] = {'source': f'profiles/{tag}_pmc.csv',
-                              'kernels': traffic}
+# key of this profile in traffic.json: the arithmetic, or argv[2] for the
+# profiles of other workloads (gradient, configuration 2)
+key = sys.argv[2] if len(sys.argv) > 2 else bench['dtype']
+everything[key] = {'source': f'profiles/{tag}_pmc.csv', 'kernels': traffic}
 json.dump(everything, open('profiles/traffic.json', 'w'), indent=1)
 print(json.dumps(traffic, indent=1))
