@@ -83,6 +83,12 @@ def parse():
     ap.add_argument('--sharded', action='store_true',
                     help='one rank through the multi-GPU code path (process '
                          'group of size 1, RCCL all-gather, device reassembly)')
+    ap.add_argument('--pipeline', action='store_true',
+                    help='sharded steps overlap: the solvers of a step run '
+                         'during the all-gather and the reassembly of the '
+                         'previous one (default: one after the other -- on '
+                         'one GPU the extra cross-stream dependencies cost '
+                         'more than the overlap hides, DESIGN.md section 8)')
     ap.add_argument('--serial', action='store_true',
                     help='all solver variants on one stream (default: one '
                          'HIP stream per variant so short launches fill the '
@@ -323,7 +329,8 @@ def main():
     if sharded:
         step = ShardedStep(backend, graphs, knode, kedge, kernel.p, kernel.q,
                            kernel.eps, kernel.ftol, kernel.gtol, all_jobs,
-                           starts, n, n, nJ, traits)
+                           starts, n, n, nJ, traits,
+                           pipeline=args.pipeline)
         plan, local_jobs, shard = step.plan, step.local_jobs, step.shard
     else:
         plan = backend.prepare(graphs, knode, kedge, kernel.p, kernel.q,
@@ -352,6 +359,7 @@ def main():
     t0 = time.perf_counter()
     for it in range(args.steps):
         step.enqueue(ev_sets[it], serial=args.serial)
+    host_enqueue_ms = 1e3 * (time.perf_counter() - t0) / max(args.steps, 1)
     sync()
     barrier()
     sync()
@@ -614,6 +622,8 @@ def main():
         'step_aggregate': step_aggregate, 'kernels': per_kernel,
         'cpu_baseline': cpu, 'api_inclusive': api,
         'sharded_check': sharded_check, 'other_arithmetic': other,
+        # host time to issue one step (launches, events, collective)
+        'host_enqueue_ms': host_enqueue_ms,
     }
     # RCCL announces itself on C stdio ("Librccl path : ..."), which a pipe
     # would deliver after Python's buffer: flush it so that the JSON line is

@@ -201,11 +201,25 @@ class LaunchSet:
     def __init__(self):
         self.streams, self.done = [], []
         self.start = runtime.Event()
+        self._n_last = 0
+        self.max_streams = int(os.environ.get('GD_MAX_STREAMS', '3'))
 
-    def enqueue(self, plan, events=None, serial=False):
+    def enqueue(self, plan, events=None, serial=False, front=None, after=()):
+        """`front`: a stream that takes the place of the null stream for the
+        table kernel and the start event (pipelined steps: the null stream
+        may still be busy with the previous step's collective).  It first
+        waits for the events in `after` and for the solver launches of the
+        previous `enqueue` (they read the table buffer this step rewrites)."""
+        fh = None
+        if front is not None and not serial:
+            fh = front.h
+            for e in after:
+                front.wait_event(e)
+            for slot in range(self._n_last):
+                front.wait_event(self.done[slot])
         for L in plan.pre_launches:
             runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                           dynamic_lds=L['dynamic_lds'])
+                           stream=fh, dynamic_lds=L['dynamic_lds'])
         n = len(plan.launches)
         if serial:
             for k, L in enumerate(plan.launches):
@@ -215,29 +229,41 @@ class LaunchSet:
                                dynamic_lds=L['dynamic_lds'])
                 if events is not None:
                     events[k][1].record()
+            self._n_last = 0
             return
-        while len(self.streams) < n:
+        # longest launch first, each to the stream with the least work so far
+        # (at most `max_streams` streams: the runtime multiplexes them onto a
+        # few hardware queues, and every stream costs two cross-queue
+        # dependencies per step)
+        cost = [plan.launches[k]['count'] * (plan.launches[k]['variant'].S + 8)
+                for k in range(n)]
+        order = sorted(range(n), key=lambda k: -cost[k])
+        ns = max(1, min(n, self.max_streams or n))
+        while len(self.streams) < ns:
             k = len(self.streams)
             if len(_STREAM_POOL) <= k:
                 _STREAM_POOL.append(runtime.Stream())
                 _EVENT_POOL.append(runtime.Event())
             self.streams.append(_STREAM_POOL[k])
             self.done.append(_EVENT_POOL[k])
-        self.start.record()
-        order = sorted(range(n), key=lambda k: -plan.launches[k]['count']
-                       * (plan.launches[k]['variant'].S + 8))
-        for slot, k in enumerate(order):
+        self.start.record(fh)
+        load = [0] * ns
+        for slot in range(ns):
+            self.streams[slot].wait_event(self.start)
+        for k in order:
+            slot = load.index(min(load))
+            load[slot] += cost[k]
             L, s = plan.launches[k], self.streams[slot]
-            s.wait_event(self.start)
             if events is not None:
                 events[k][0].record(s.h)
             runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
                            stream=s.h, dynamic_lds=L['dynamic_lds'])
             if events is not None:
                 events[k][1].record(s.h)
-            self.done[slot].record(s.h)
-        for slot in range(n):
+        for slot in range(ns):
+            self.done[slot].record(self.streams[slot].h)
             runtime.null_stream_wait_event(self.done[slot])
+        self._n_last = ns
 
 
 class HIPBackend(Backend):

@@ -168,7 +168,8 @@ class ShardedStep:
 
     def __init__(self, backend, graphs, node_kernel, edge_kernel, p, q, eps,
                  ftol, gtol, jobs, starts, nX, nY, nJ, traits, group=None,
-                 timer=None, shard_plan=None, collective='torch'):
+                 timer=None, shard_plan=None, collective='torch',
+                 pipeline=False):
         import torch
         import torch.distributed as dist
         from ...hip import runtime
@@ -205,16 +206,37 @@ class ShardedStep:
         cap = self.capacity = sp.capacity
         rs = np.dtype(backend.real)
         self.tdtype = torch.float32 if rs == np.float32 else torch.float64
+        # pipeline: two slab / gather buffers and a front stream, so that the
+        # solvers of step i + 1 run while the collective and the reassembly of
+        # step i are still on the null stream (they only wait for the buffer
+        # pair they write, i.e. for the reassembly of step i - 1)
+        self.depth = 2 if pipeline else 1
+        self.front = runtime.Stream() if pipeline else None
+        self.buffer_free = [runtime.Event() for _ in range(self.depth)]
+        self._count = 0
         with torch.cuda.device(self.device):
-            self.local_out = torch.zeros(max(cap * n_cols, 1),
-                                         dtype=self.tdtype, device=self.device)
-            self.gathered = torch.empty(self.world * max(cap * n_cols, 1),
-                                        dtype=self.tdtype, device=self.device)
+            self.local_outs = [torch.zeros(max(cap * n_cols, 1),
+                                           dtype=self.tdtype,
+                                           device=self.device)
+                               for _ in range(self.depth)]
+            self.gathereds = [torch.empty(self.world * max(cap * n_cols, 1),
+                                          dtype=self.tdtype,
+                                          device=self.device)
+                              for _ in range(self.depth)]
+            self.local_out, self.gathered = self.local_outs[0], \
+                self.gathereds[0]
             self.result = torch.zeros(n_cols * self.nX * self.nY,
                                       dtype=self.tdtype, device=self.device)
             src, dst = sp.reassembly_index(self.n_grad)
             self.t_src = torch.from_numpy(src).to(self.device)
             self.t_dst = torch.from_numpy(dst).to(self.device)
+            # every element of the result has a source (the usual case: the
+            # jobs cover the matrix): the reassembly is one gather kernel
+            self.t_perm = None
+            perm = np.full(self.result.numel(), -1, dtype=np.int64)
+            perm[dst] = src
+            if len(perm) and perm.min() >= 0:
+                self.t_perm = torch.from_numpy(perm).to(self.device)
             torch.cuda.synchronize(self.device)
         local_jobs = jobs[sp.local]
         local_jobs.flags.writeable = False         # recognised by identity
@@ -232,12 +254,13 @@ class ShardedStep:
         from ...hip import runtime
         graphs, _, starts, nX, nY, nJ, traits = self._args
         rs = np.dtype(self.backend.real)
-        self.plan = self.backend.prepare(
+        self.plans = [self.backend.prepare(
             graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
             self.local_jobs, starts, nX, nY, nJ, traits, timer, packed=True,
-            gramian_ptr=self.local_out.data_ptr(),
-            gradient_ptr=self.local_out.data_ptr()
-            + self.capacity * rs.itemsize)
+            gramian_ptr=out.data_ptr(),
+            gradient_ptr=out.data_ptr() + self.capacity * rs.itemsize)
+            for out in self.local_outs]
+        self.plan = self.plans[0]
 
     def enqueue(self, events=None, serial=False):
         """One step: solver launches, all-gather, reassembly -- all
@@ -247,24 +270,34 @@ class ShardedStep:
         stream it runs on (bench.py's per-kernel timing)."""
         import torch
         import torch.distributed as dist
-        self.launch_set.enqueue(self.plan, events, serial)
+        b = self._count % self.depth
+        self._count += 1
+        local_out, gathered = self.local_outs[b], self.gathereds[b]
+        self.local_out, self.gathered = local_out, gathered   # (the latest)
+        self.launch_set.enqueue(self.plans[b], events, serial,
+                                front=self.front,
+                                after=(self.buffer_free[b],))
         with torch.cuda.device(self.device):
             if self.comm is not None:
                 # null stream: behind the solvers (LaunchSet) and in front of
                 # the reassembly torch enqueues there
                 self.comm.all_gather(
-                    self.local_out.data_ptr(), self.gathered.data_ptr(),
-                    self.local_out.numel(), self.backend.real)
+                    local_out.data_ptr(), gathered.data_ptr(),
+                    local_out.numel(), self.backend.real)
             elif self.on_device:
-                dist.all_gather_into_tensor(self.gathered, self.local_out,
+                dist.all_gather_into_tensor(gathered, local_out,
                                             group=self.group)
             else:
-                h = self.local_out.cpu()           # waits for the solvers
+                h = local_out.cpu()                # waits for the solvers
                 g = torch.empty(self.world * h.numel(), dtype=h.dtype)
                 dist.all_gather_into_tensor(g, h, group=self.group)
-                self.gathered.copy_(g)
-            self.result.index_copy_(
-                0, self.t_dst, self.gathered.index_select(0, self.t_src))
+                gathered.copy_(g)
+            if self.t_perm is not None:
+                torch.index_select(gathered, 0, self.t_perm, out=self.result)
+            else:
+                self.result.index_copy_(
+                    0, self.t_dst, gathered.index_select(0, self.t_src))
+        self.buffer_free[b].record()       # (null stream: slabs are consumed)
 
     def synchronize(self):
         import torch
@@ -321,7 +354,8 @@ def distributed_backend(**kwargs):
 
     class DistributedHIPBackend(HIPBackend):
 
-        def __init__(self, shard_single_rank=False, collective='torch', **kw):
+        def __init__(self, shard_single_rank=False, collective='torch',
+                     pipeline=False, **kw):
             # Which solver variant a pair runs on must not depend on the
             # shard it falls into: the variants are different instantiations
             # (compiled with fast-math) and agree to round-off only.  Without
@@ -331,6 +365,7 @@ def distributed_backend(**kwargs):
             super().__init__(**kw)
             self.shard_single_rank = shard_single_rank
             self.collective = collective
+            self.pipeline = pipeline
             self._shard_plans = {}
             self._steps = {}      # (shard plan, nJ, traits) -> ShardedStep
 
@@ -380,7 +415,8 @@ def distributed_backend(**kwargs):
                 step = self._steps[key] = ShardedStep(
                     self, graphs, node_kernel, edge_kernel, p, q, eps, ftol,
                     gtol, jobs, starts, nX, nY, nJ, traits, timer=timer,
-                    shard_plan=sp, collective=self.collective)
+                    shard_plan=sp, collective=self.collective,
+                    pipeline=self.pipeline)
             else:
                 step.bind(node_kernel, edge_kernel, p, q, eps, ftol, gtol,
                           timer)

@@ -105,8 +105,26 @@ def _rccl_worker(rank, world, port, tmp):
     k4 = MarginalizedGraphKernel(knode, kedge, q=q, backend=abi)
     K4, dK4 = k4(G, eval_gradient=True)
     assert abi.last_step.comm is not None
+    # pipelined steps (two slab / gather buffers, solvers of step i + 1
+    # overlapping the collective of step i): five back-to-back steps, one
+    # download
+    pipe = distributed_backend(device=0, shard_single_rank=True,
+                               pipeline=True)
+    k5 = MarginalizedGraphKernel(knode, kedge, q=q, backend=pipe)
+    K5, dK5 = k5(G, eval_gradient=True)
+    step = pipe.last_step
+    assert step.depth == 2 and step.front is not None
+    step.result.zero_()
+    for _ in range(5):
+        step.enqueue()
+    K6 = np.empty(K5.size)
+    dK6 = np.empty(dK5.size)
+    step.download(K6, dK6)
+    n = len(G)
+    K6 = K6.reshape(n, n, order='F')
+    dK6 = dK6.reshape(n, n, -1, order='F')
     np.savez(os.path.join(tmp, 'rccl.npz'), K=K, K2=K2, dK=dK, Kxy=Kxy, K3=K3,
-             theta=k2.theta, K4=K4, dK4=dK4)
+             theta=k2.theta, K4=K4, dK4=dK4, K5=K5, dK5=dK5, K6=K6, dK6=dK6)
     dist.destroy_process_group()
 
 
@@ -132,6 +150,8 @@ def test_rccl_process_group_of_one_rank(tmp_path):
     assert np.array_equal(r['K2'], K2) and np.array_equal(r['dK'], dK)
     assert np.array_equal(r['Kxy'], k(G[:12], G[12:]))
     assert np.array_equal(r['K4'], K2) and np.array_equal(r['dK4'], dK)
+    assert np.array_equal(r['K5'], K2) and np.array_equal(r['dK5'], dK)
+    assert np.array_equal(r['K6'], K2) and np.array_equal(r['dK6'], dK)
     k.theta = r['theta']
     assert np.array_equal(r['K3'], k(G))
 
