@@ -209,11 +209,15 @@ def measure_api(graphs, knode, kedge, q, real, device, gradient, n_pairs):
     # (the code objects of this workload are already loaded in this process:
     # `first` is graph packing + job layout + uploads + solve + download)
     reps = 5
-    t0 = time.perf_counter()
+    each = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         kernel(graphs, eval_gradient=gradient)
-    rep = (time.perf_counter() - t0) / reps
+        each.append(time.perf_counter() - t0)
+    rep = float(np.median(each))     # (an occasional collector pause in one
+    #                                    of the calls is not the call's cost)
     return {'first_call_ms': 1e3 * first, 'repeat_call_ms': 1e3 * rep,
+            'repeat_calls_ms': [round(1e3 * t, 3) for t in each],
             'value': n_pairs / rep, 'unit': 'graph-pairs/s',
             'note': 'host-, PCIe- and conversion-inclusive; never `value`'}
 

@@ -195,7 +195,17 @@ struct oc_solver {
     constexpr static int NCP = NC * NC;         // degree-pair rectangles
     constexpr static int NTAB = ((NCP + 63) / 64) * 64;
     constexpr static int NM = (S + 31) / 32;    // 32-bit flush-mask words
-    constexpr static int SETUP_CHUNK = 4;
+#ifndef GD_OC_CHUNK
+#define GD_OC_CHUNK 4
+#endif
+#ifndef GD_OC_PIN
+#define GD_OC_PIN 0   // 1: pin every slot's registers (serialises the slots' loads)
+#endif
+    constexpr static int SETUP_CHUNK = GD_OC_CHUNK;
+    // slot setup in one pass over running element indices (15 VALU per slot
+    // instead of 29 in two passes); the two-pass form keeps fewer registers
+    // live and stays where the register file is the limit
+    constexpr static bool ONE_PASS = sizeof(real) == 4 || W == 1;
 #ifndef GD_OC_GCH
 #define GD_OC_GCH 8
 #endif
@@ -394,7 +404,7 @@ struct oc_solver {
 
             // ---- nonzero slots owned by this thread ---------------------------
             real val[S];
-            unsigned adr[S];   // pass 1: (a << 16) | b, or ~0u; pass 2: index into p
+            unsigned adr[S];   // gather index into p (two-pass setup: first (a << 16) | b, or ~0u)
             unsigned fm[NM];
 #pragma unroll
             for (int w = 0; w < NM; ++w) fm[w] = 0;
@@ -420,47 +430,113 @@ struct oc_solver {
                     }
                 }
                 n_slots = n_slots > S ? S : n_slots;
-                // pass 1 (unrolled): the nonzero pair (a, b) of every slot
-                int kb = 0, j = 0, ja = 0, jb = 0;
-                row_t cur = open_row(0);
+                if constexpr (ONE_PASS) {
+                    // one unrolled pass over the slots.  A lane walks the nonzero
+                    // pairs (e1, e2) of its row, e2 fastest, as two running element
+                    // indices; the row is over when e1 reaches its end.  Dead rows
+                    // (no terms, or beyond N) walk element 0 and are never valid.
+                    struct walk_t {
+                        unsigned e1, end1, last1, e2, rs2, end2;
+                    };
+                    auto open_walk = [&](int kb) -> walk_t {
+                        const row_t r = open_row(kb);
+                        const bool live = r.prod > 0;
+                        walk_t w;
+                        w.e1 = live ? (unsigned)r.rs1 : 0u;
+                        w.end1 = live ? (unsigned)(r.rs1 + r.d1) : 0u;
+                        w.last1 = live ? (unsigned)(r.rs1 + r.d1 - 1) : 0u;
+                        w.rs2 = live ? (unsigned)r.rs2 : 0u;
+                        w.end2 = live ? (unsigned)(r.rs2 + r.d2) : 1u;
+                        w.e2 = w.rs2;
+                        return w;
+                    };
+                    int kb = 0;
+                    walk_t cur = open_walk(0);
+    #pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        // (limits the scheduler's hoisting of loads -- and with it the
+                        // live registers -- to SETUP_CHUNK slots)
+                        if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
+                        const bool ok = cur.e1 < cur.end1;
+                        const unsigned a = cur.e1 < cur.last1 ? cur.e1 : cur.last1, b = cur.e2;
+                        const nz_t z1 = at32(g1.nz, a), z2 = at32(g2.nz, b);
+                        real e;
+                        if constexpr (TAB) {
+                            e = at32(ketab, __umul24((unsigned)ecls1[a], nec) + ecls2[b]);
+                            if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                                e *= real(edge_weight<edge_t>::get(at32(g1.edge, a))) *
+                                     real(edge_weight<edge_t>::get(at32(g2.edge, b)));
+                        } else {
+                            const edge_t e1 = at32(g1.edge, a), e2 = at32(g2.edge, b);
+                            e = prm.edge_kernel(e1, e2);
+                        }
+                        val[s] = ok ? e : real(0);
+                        unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
+#if GD_OC_PIN
+                        asm volatile("" : "+v"(val[s]), "+v"(col));
+#endif
+                        adr[s] = col;
+#if !GD_OC_PIN
+                        if (s % SETUP_CHUNK == SETUP_CHUNK - 1 || s == S - 1) {
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    adr[s] = (s < n_slots && j < cur.prod)
-                        ? ((unsigned)(cur.rs1 + ja) << 16) | (unsigned)(cur.rs2 + jb) : ~0u;
-                    asm volatile("" : "+v"(adr[s]));
-                    ++j;
-                    ++jb;
-                    if (jb >= cur.d2) {
-                        jb = 0;
-                        ++ja;
+                            for (int u = s - s % SETUP_CHUNK; u <= s; ++u) asm volatile("" : "+v"(val[u]), "+v"(adr[u]));
+                        }
+#endif
+                        // next nonzero pair of the row
+                        ++cur.e2;
+                        const bool wrap = cur.e2 == cur.end2;
+                        cur.e2 = wrap ? cur.rs2 : cur.e2;
+                        cur.e1 += wrap ? 1u : 0u;
+                        if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform: next row batch
+                            ++kb;
+                            cur = open_walk(kb);
+                        }
                     }
-                    if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
-                        ++kb;
-                        j = ja = jb = 0;
-                        cur = open_row(kb);
+                } else {
+                    // two passes (double precision with several waves per pair:
+                    // fewer registers live across the microkernel evaluation)
+                    // pass 1 (unrolled): the nonzero pair (a, b) of every slot
+                    int kb = 0, j = 0, ja = 0, jb = 0;
+                    row_t cur = open_row(0);
+    #pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        adr[s] = (s < n_slots && j < cur.prod)
+                            ? ((unsigned)(cur.rs1 + ja) << 16) | (unsigned)(cur.rs2 + jb) : ~0u;
+                        asm volatile("" : "+v"(adr[s]));
+                        ++j;
+                        ++jb;
+                        if (jb >= cur.d2) {
+                            jb = 0;
+                            ++ja;
+                        }
+                        if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
+                            ++kb;
+                            j = ja = jb = 0;
+                            cur = open_row(kb);
+                        }
                     }
-                }
-                // pass 2: labels -> edge-kernel value and gather index
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
-                    const bool ok = adr[s] != ~0u;
-                    const unsigned a = ok ? (adr[s] >> 16) : 0u, b = ok ? (adr[s] & 0xFFFFu) : 0u;
-                    const nz_t z1 = at32(g1.nz, a), z2 = at32(g2.nz, b);
-                    real e;
-                    if constexpr (TAB) {
-                        e = at32(ketab, __umul24((unsigned)ecls1[a], nec) + ecls2[b]);
-                        if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
-                            e *= real(edge_weight<edge_t>::get(at32(g1.edge, a))) *
-                                 real(edge_weight<edge_t>::get(at32(g2.edge, b)));
-                    } else {
-                        const edge_t e1 = at32(g1.edge, a), e2 = at32(g2.edge, b);
-                        e = prm.edge_kernel(e1, e2);
+                    // pass 2: labels -> edge-kernel value and gather index
+    #pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
+                        const bool ok = adr[s] != ~0u;
+                        const unsigned a = ok ? (adr[s] >> 16) : 0u, b = ok ? (adr[s] & 0xFFFFu) : 0u;
+                        const nz_t z1 = at32(g1.nz, a), z2 = at32(g2.nz, b);
+                        real e;
+                        if constexpr (TAB) {
+                            e = at32(ketab, __umul24((unsigned)ecls1[a], nec) + ecls2[b]);
+                            if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                                e *= real(edge_weight<edge_t>::get(at32(g1.edge, a))) *
+                                     real(edge_weight<edge_t>::get(at32(g2.edge, b)));
+                        } else {
+                            const edge_t e1 = at32(g1.edge, a), e2 = at32(g2.edge, b);
+                            e = prm.edge_kernel(e1, e2);
+                        }
+                        val[s] = ok ? e : real(0);
+                        unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
+                        asm volatile("" : "+v"(val[s]), "+v"(col));
+                        adr[s] = col;
                     }
-                    val[s] = ok ? e : real(0);
-                    unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
-                    asm volatile("" : "+v"(val[s]), "+v"(col));
-                    adr[s] = col;
                 }
             }
 

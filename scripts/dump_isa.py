@@ -2,7 +2,7 @@
 """Dump the gfx950 ISA of one solver variant built for the bench workload
 (QM7-like TensorProduct kernels) -- for instruction-count work on the CG loop.
 
-    python scripts/dump_isa.py W S R [C] [--f64] [--oc=D] > out.s
+    python scripts/dump_isa.py W S R [C] [--f64] [--oc=D] [--tab|--tab=2] > out.s
 """
 import os
 import subprocess
@@ -29,7 +29,8 @@ node_t, edge_t = dgs[0].node_t, dgs[0].edge_t
 ke2 = ke
 oc = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--oc=')]
 variant = OCVariant(W, S, R, oc[0]) if oc else Variant(W, S, R)
-src = backend.render_source(kn, ke2, k.p, node_t, edge_t, [variant], C)
+src = backend.render_source(kn, ke2, k.p, node_t, edge_t, [variant], C,
+                            tab=2 if '--tab=2' in sys.argv else '--tab' in sys.argv)
 path = f'/tmp/_dump_isa_{W}_{S}_{R}_{C}_{int(real is np.float64)}.hip'
 open(path, 'w').write(src)
 flags = [f for f in jit.BASE_FLAGS if f != '--genco'] + \
