@@ -402,6 +402,35 @@ struct oc_solver {
                 return r;
             };
 
+            // A lane walks the nonzero pairs (e1, e2) of a row, e2 fastest, as two
+            // running element indices; the row is over when e1 reaches its end.
+            // Dead rows (no terms, or beyond N) walk element 0 and are never valid.
+            struct walk_t {
+                unsigned e1, end1, last1, e2, rs2, end2;
+                int row;    // i1 * ldp + i2
+                __device__ __forceinline__ bool valid() const { return e1 < end1; }
+                __device__ __forceinline__ unsigned a() const { return e1 < last1 ? e1 : last1; }
+                __device__ __forceinline__ void next() {
+                    ++e2;
+                    const bool wrap = e2 == end2;
+                    e2 = wrap ? rs2 : e2;
+                    e1 += wrap ? 1u : 0u;
+                }
+            };
+            auto open_walk = [&](int kb) -> walk_t {
+                const row_t r = open_row(kb);
+                const bool live = r.prod > 0;
+                walk_t w;
+                w.e1 = live ? (unsigned)r.rs1 : 0u;
+                w.end1 = live ? (unsigned)(r.rs1 + r.d1) : 0u;
+                w.last1 = live ? (unsigned)(r.rs1 + r.d1 - 1) : 0u;
+                w.rs2 = live ? (unsigned)r.rs2 : 0u;
+                w.end2 = live ? (unsigned)(r.rs2 + r.d2) : 1u;
+                w.e2 = w.rs2;
+                w.row = r.i1 * ldp + r.i2;
+                return w;
+            };
+
             // ---- nonzero slots owned by this thread ---------------------------
             real val[S];
             unsigned adr[S];   // gather index into p (two-pass setup: first (a << 16) | b, or ~0u)
@@ -431,25 +460,7 @@ struct oc_solver {
                 }
                 n_slots = n_slots > S ? S : n_slots;
                 if constexpr (ONE_PASS) {
-                    // one unrolled pass over the slots.  A lane walks the nonzero
-                    // pairs (e1, e2) of its row, e2 fastest, as two running element
-                    // indices; the row is over when e1 reaches its end.  Dead rows
-                    // (no terms, or beyond N) walk element 0 and are never valid.
-                    struct walk_t {
-                        unsigned e1, end1, last1, e2, rs2, end2;
-                    };
-                    auto open_walk = [&](int kb) -> walk_t {
-                        const row_t r = open_row(kb);
-                        const bool live = r.prod > 0;
-                        walk_t w;
-                        w.e1 = live ? (unsigned)r.rs1 : 0u;
-                        w.end1 = live ? (unsigned)(r.rs1 + r.d1) : 0u;
-                        w.last1 = live ? (unsigned)(r.rs1 + r.d1 - 1) : 0u;
-                        w.rs2 = live ? (unsigned)r.rs2 : 0u;
-                        w.end2 = live ? (unsigned)(r.rs2 + r.d2) : 1u;
-                        w.e2 = w.rs2;
-                        return w;
-                    };
+                    // one unrolled pass over the slots (walk_t above)
                     int kb = 0;
                     walk_t cur = open_walk(0);
     #pragma unroll
@@ -457,8 +468,8 @@ struct oc_solver {
                         // (limits the scheduler's hoisting of loads -- and with it the
                         // live registers -- to SETUP_CHUNK slots)
                         if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
-                        const bool ok = cur.e1 < cur.end1;
-                        const unsigned a = cur.e1 < cur.last1 ? cur.e1 : cur.last1, b = cur.e2;
+                        const bool ok = cur.valid();
+                        const unsigned a = cur.a(), b = cur.e2;
                         const nz_t z1 = at32(g1.nz, a), z2 = at32(g2.nz, b);
                         real e;
                         if constexpr (TAB) {
@@ -482,11 +493,7 @@ struct oc_solver {
                             for (int u = s - s % SETUP_CHUNK; u <= s; ++u) asm volatile("" : "+v"(val[u]), "+v"(adr[u]));
                         }
 #endif
-                        // next nonzero pair of the row
-                        ++cur.e2;
-                        const bool wrap = cur.e2 == cur.end2;
-                        cur.e2 = wrap ? cur.rs2 : cur.e2;
-                        cur.e1 += wrap ? 1u : 0u;
+                        cur.next();
                         if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform: next row batch
                             ++kb;
                             cur = open_walk(kb);
@@ -1095,15 +1102,15 @@ struct oc_solver {
                 job_sync<W>();
                 if constexpr (EdgeK::jac_dims > 0) {
                     // walk the slots again: row = the batch's row, col = adr
-                    int kb = 0, j = 0, ja = 0, jb = 0;
-                    row_t cur = open_row(0);
+                    int kb = 0;
+                    walk_t cur = open_walk(0);
+                    real yrow = lp[cur.row * 2 + 1];
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         if (s < n_slots) {   // wave-uniform
-                            const bool ok = j < cur.prod;
-                            const int a = ok ? cur.rs1 + ja : 0, b = ok ? cur.rs2 + jb : 0;
-                            const int row = cur.i1 * ldp + cur.i2;
-                            real w = ok ? lp[row * 2 + 1] * lp[adr[s] * 2 + 0] : real(0);
+                            const bool ok = cur.valid();
+                            const unsigned a = cur.a(), b = cur.e2;
+                            real w = ok ? yrow * lp[adr[s] * 2 + 0] : real(0);
                             if constexpr (TAB) {
                                 const unsigned cidx = __umul24((unsigned)ecls1[a], nec) + ecls2[b];
                                 if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
@@ -1118,16 +1125,11 @@ struct oc_solver {
 #pragma unroll
                                 for (int jj = 0; jj < EdgeK::jac_dims; ++jj) jac[off_e + jj] += w * real(de[jj]);
                             }
-                            ++j;
-                            ++jb;
-                            if (jb >= cur.d2) {
-                                jb = 0;
-                                ++ja;
-                            }
+                            cur.next();
                             if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
                                 ++kb;
-                                j = ja = jb = 0;
-                                cur = open_row(kb);
+                                cur = open_walk(kb);
+                                yrow = lp[cur.row * 2 + 1];
                             }
                         }
                     }
