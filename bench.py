@@ -488,8 +488,13 @@ def main():
     # has been committed (scripts/profile.sh + scripts/summarize_profile.py)
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-            tr = json.load(f)[args.dtype]['kernels'].get(roofline['kernel'])
-        if tr and not args.gradient and world == 1 and args.config == 3:
+            # profiled commands: config 3 in both arithmetics, its fp64
+            # gradient step, configuration 2 in fp32 (scripts/profile_all.sh)
+            key = {(3, False): args.dtype, (3, True): 'grad' + args.dtype[1:],
+                   (2, False): 'c2' if args.dtype == 'f32' else 'c2f64'}[
+                       (args.config, bool(args.gradient))]
+            tr = json.load(f)[key]['kernels'].get(roofline['kernel'])
+        if tr and world == 1:
             # the image staging is a 16-byte-per-lane coalesced read, which
             # FETCH_SIZE counts at half its bytes on gfx950
             # (MI355X_MICROARCH.md, HBM): 2 x FETCH_SIZE + WRITE_SIZE
