@@ -12,7 +12,9 @@ import itertools as it
 import numpy as np
 from ..codegen.typetool import common_min_type, is_scalar_type
 from ..minipandas import DataFrame
-from ..util.cookie import VolatileCookie
+from ..util.cookie import VolatileCookie, IdentityCache
+
+_UNIFIED = IdentityCache()
 from ._from_networkx import _from_networkx, _to_networkx
 
 __all__ = ['Graph']
@@ -109,6 +111,12 @@ class Graph:
                                             g.edges.rowtype())
                 return t
 
+        # (the same list as last time, no graph touched since: still unified)
+        if not isinstance(graphs, (list, tuple)):
+            graphs = list(graphs)
+        key, hit = _UNIFIED.get(graphs)
+        if hit:
+            return True
         first = next(iter(graphs))
         node_t, edge_t = rowtypes(first)
         for other in graphs:
@@ -117,6 +125,7 @@ class Graph:
                 return ('nodes', first, other)
             if et is not edge_t and et != edge_t:
                 return ('edges', first, other)
+        _UNIFIED.put(key, graphs, True)
         return True
 
     @classmethod

@@ -17,6 +17,7 @@ import zlib
 from collections import OrderedDict, namedtuple
 import numpy as np
 from ...codegen import Template
+from ...util.cookie import IdentityCache
 from ...codegen.sympy_printer import to_real_expr
 from ...codegen.typetool import _dtype_util
 from ...hip import jit, runtime
@@ -185,6 +186,16 @@ _MODULES = {}
 #: HIP streams / events are expensive to create (milliseconds each): every
 #: LaunchSet draws from this process-wide pool, in order
 _STREAM_POOL, _EVENT_POOL = [], []
+
+
+class _DeviceGraphList(list):
+    """The packed graphs of one call, with the tuple of their identities
+    (the key of the arena and layout caches) computed once."""
+    ids = None
+
+
+def _ids(dgraphs):
+    return getattr(dgraphs, 'ids', None) or tuple(map(id, dgraphs))
 
 
 class LaunchSet:
@@ -367,6 +378,7 @@ class HIPBackend(Backend):
         self._modules = _MODULES           # (tu key) -> runtime.Module
         self._arenas = OrderedDict()       # tuple(id(DeviceGraph)) -> (arena, buf)
         self._pool = {}                    # name -> DeviceBuffer (grow-only)
+        self._dgraph_lists = IdentityCache()
         self._layouts = OrderedDict()      # job-list key -> Layout (LRU)
         self._source_cache = {}            # (code signature, variant) -> text
         self.layout_cache_size = 8
@@ -451,7 +463,7 @@ class HIPBackend(Backend):
         return GraphArena(dgraphs, *fields, classes=bool(self.tables))
 
     def _arena(self, dgraphs, fields=(None, None)):
-        key = (tuple(id(g) for g in dgraphs), fields if self.tables else None)
+        key = (_ids(dgraphs), fields if self.tables else None)
         hit = self._arenas.get(key)
         if hit is not None:
             self._arenas.move_to_end(key)
@@ -1022,16 +1034,24 @@ void ${name}(params_t prm) {
         tic('transferring graphs to GPU')
         # graphs seen for the first time are packed together in one
         # vectorised pass (_devicegraph.pack_many)
-        key = (self.uuid, np.dtype(self.real).str)
-        new = [g for g in graphs if key not in g.cookie]
-        if new:
-            for g, dg in zip(new, pack_many(new, real=self.real)):
-                g.cookie[key] = dg
-        dgraphs = [g.cookie[key] for g in graphs]
-        sig0 = dgraphs[0].signature
-        for dg in dgraphs:
-            if dg.signature != sig0:
-                self._assert_homogeneous(dgraphs[0], dg)
+        # (the same list of graphs as in a recent call, none touched since:
+        # the same packings -- util.cookie.IdentityCache)
+        if not isinstance(graphs, (list, tuple)):
+            graphs = list(graphs)
+        ckey, dgraphs = self._dgraph_lists.get(graphs)
+        if dgraphs is None:
+            key = (self.uuid, np.dtype(self.real).str)
+            new = [g for g in graphs if key not in g.cookie]
+            if new:
+                for g, dg in zip(new, pack_many(new, real=self.real)):
+                    g.cookie[key] = dg
+            dgraphs = _DeviceGraphList(g.cookie[key] for g in graphs)
+            sig0 = dgraphs[0].signature
+            for dg in dgraphs:
+                if dg.signature != sig0:
+                    self._assert_homogeneous(dgraphs[0], dg)
+            dgraphs.ids = tuple(map(id, dgraphs))
+            self._dgraph_lists.put(ckey, graphs, dgraphs)
         toc('transferring graphs to GPU')
         if traits.eval_gradient is True and traits.nodal is not False \
                 and not ngrad:
@@ -1221,7 +1241,7 @@ void ${name}(params_t prm) {
         # keeps its lists that way), anything else by checksum
         jobs_id = ('id', id(jobs)) if not jobs.flags.writeable else \
             ('crc', zlib.crc32(jobs.view(np.uint8)))
-        key = (tuple(map(id, dgraphs)), len(jobs), jobs_id,
+        key = (_ids(dgraphs), len(jobs), jobs_id,
                zlib.crc32(starts.view(np.uint8)), C, fields, self.tables,
                ngrad, maximin)
         hit = self._layouts.get(key)

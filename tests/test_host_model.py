@@ -289,6 +289,34 @@ def test_row_type_cache_follows_graph_mutation():
     assert Graph.has_unified_types([ga, gb]) is True
 
 
+def test_graph_list_identity_cache_dies_with_the_cookie_epoch():
+    """`has_unified_types` and the backend remember what they derived from a
+    list of graphs by the identities of its members
+    (util.cookie.IdentityCache); any graph dropping cached state (permute,
+    re-typing, a deleted packing) invalidates every entry."""
+    from graphdot_amd.util.cookie import IdentityCache, VolatileCookie
+    import graphdot_amd.graph as graph_module
+    G = graphs_from(load('mlgk_cases.json')['labeled']['graphs'])
+    cache = IdentityCache(maxsize=2)
+    key, hit = cache.get(G)
+    assert hit is None
+    cache.put(key, G, 'derived')
+    assert cache.get(G)[1] == 'derived'
+    assert cache.get(list(G))[1] == 'derived'         # same members
+    assert cache.get(G[::-1])[1] is None              # other order
+    G[0].cookie['x'] = 1                              # adding keeps entries
+    assert cache.get(G)[1] == 'derived'
+    before = VolatileCookie.epoch
+    del G[0].cookie['x']
+    assert VolatileCookie.epoch == before + 1 and cache.get(G)[1] is None
+    # the type check: cached positive, re-run after a mutation
+    assert Graph.has_unified_types(G) is True
+    assert graph_module._UNIFIED.get(G)[1] is True
+    G[1].permute(np.arange(len(G[1].nodes))[::-1], inplace=True)
+    assert graph_module._UNIFIED.get(G)[1] is None
+    assert Graph.has_unified_types(G) is True
+
+
 def test_batch_packer_is_byte_identical_to_the_per_graph_packer():
     """`pack_many` (one vectorised pass over all graphs of a call, SURVEY 8f
     rank 1; reference: _octilegraph.py:37-177 once per graph) produces the
