@@ -13,6 +13,7 @@ the shard (the HIP plan on a GPU, the oracle in the CPU tests) and
 ``all_gather(local)`` is ``torch.distributed.all_gather_into_tensor`` over RCCL
 (backend "nccl") on GPUs or gloo on CPU.
 """
+import os
 import numpy as np
 
 
@@ -21,10 +22,23 @@ def predict_cost(n_node, n_nz, ji, jj):
     return n_nz[ji] * n_nz[jj] + 4 * n_node[ji] * n_node[jj]
 
 
-def partition(cost, world_size):
-    """Deal jobs to ranks in descending-cost snake order (LPT-like).  Returns
-    a list of job-id arrays, one per rank, each sorted by descending cost."""
+def partition(cost, world_size, mode=None):
+    """Deal jobs to ranks.  Returns a list of job-id arrays, one per rank,
+    each sorted by descending cost.
+
+    'snake' (default): descending-cost snake order (LPT-like) -- every rank
+    gets the same mix of pairs, balanced whatever the cost model is worth.
+    'blocks': contiguous runs of the cost-sorted list with equal total cost --
+    a rank gets pairs of similar size, i.e. of one or two solver variants
+    (fewer, larger launches per rank), and is as well balanced as the cost
+    model is accurate."""
+    mode = mode or os.environ.get('GD_SHARD_MODE', 'snake')
     order = np.argsort(-cost, kind='stable')
+    if mode == 'blocks':
+        c = np.cumsum(cost[order], dtype=np.float64)
+        total = c[-1] if len(c) else 0.0
+        cuts = np.searchsorted(c, total * np.arange(1, world_size) / world_size)
+        return np.split(order, cuts)
     k = np.arange(len(order))
     rnd, pos = k // world_size, k % world_size
     rank = np.where(rnd % 2 == 0, pos, world_size - 1 - pos)

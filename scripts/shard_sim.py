@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""What one rank of an N-GPU run computes, timed on one GPU: for every rank of
+a world of 2 / 4 / 8 the local shard of the 1000-graph matrix is prepared and
+its step timed; max over ranks against (full step) / N is the compute part of
+the strong-scaling efficiency (the all-gather is not in it).
+    python scripts/shard_sim.py [--f32] [--mode=snake|blocks] [--gradient]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tests'))
+import numpy as np
+import cases
+from graphdot_amd.hip import runtime
+from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend, LaunchSet
+from graphdot_amd.kernel.marginalized._sharded import ShardPlan, partition, predict_cost
+
+real = np.float32 if '--f32' in sys.argv else np.float64
+grad = '--gradient' in sys.argv
+modes = [a.split('=')[1] for a in sys.argv if a.startswith('--mode=')] or ['snake', 'blocks']
+n = 1000
+G = cases.config3_graphs(n)
+kn, ke, q = cases.config3_kernels()
+b = HIPBackend(real=real)
+k = MarginalizedGraphKernel(kn, ke, q=q, backend=b)
+job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
+i, j = np.triu_indices(n)
+jobs = np.column_stack((i, j)).astype(np.uint32).ravel().view(job_t)
+starts = np.arange(n + 1, dtype=np.uint32)
+traits = k.traits(symmetric=True, eval_gradient=grad)
+dgs = [b._register_graph(g) for g in G]
+n_node = np.array([g.n_node for g in dgs], np.int64)
+n_nz = np.array([g.n_nz for g in dgs], np.int64)
+cost = predict_cost(n_node, n_nz, i.astype(np.int64), j.astype(np.int64))
+ls = LaunchSet()
+
+
+def step_ms(local_jobs, steps=30):
+    plan = b.prepare(G, kn, ke, k.p, k.q, k.eps, k.ftol, k.gtol, local_jobs,
+                     starts, n, n, k.n_dims, traits, packed=True)
+    for _ in range(3):
+        ls.enqueue(plan)
+    runtime.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ls.enqueue(plan)
+    runtime.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps, len(plan.launches)
+
+
+full, nl = step_ms(jobs)
+print(f'full step {full:.3f} ms, {nl} launches')
+for world in (2, 4, 8):
+    for mode in modes:
+        shards = partition(cost, world, mode)
+        t = [step_ms(np.ascontiguousarray(jobs[s])) for s in shards]
+        ms = np.array([x[0] for x in t])
+        print(f'world {world} {mode:6s}: max {ms.max():.3f} mean {ms.mean():.3f} '
+              f'ideal {full / world:.3f}  efficiency {full / world / ms.max():.2f}  '
+              f'launches {[x[1] for x in t]}  pairs {[len(s) for s in shards]}')
+        print('      per rank ms', np.round(ms, 3))
