@@ -1161,3 +1161,69 @@ def test_config2_full_size_properties(backend):
     batch = oracle.TensorProductBatch(G, knode, kedge)
     ref, _ = batch.run(ii, jj, q=q, real='f64', tol=1e-13)
     assert np.allclose(K[ii, jj], ref, rtol=2e-5)
+
+
+@pytest.mark.parametrize('real', [np.float32, np.float64])
+def test_mixed_degree_structures_all_pairs(real):
+    """Stars, paths, cycles, cliques, regular and random graphs of 2..30 nodes
+    with up to 8 neighbours per node, all pairs (value, gradient, iteration
+    counts) against the C restatement: rows of one wave instruction range from
+    one term (leaf x leaf) to 64 (hub x hub), with single-term rows wrapping
+    at every slot and dead rows in every batch -- what the slot walk of the
+    owner-computes solvers (mgk_oc.h, walk_t) has to get right."""
+    import networkx as nx
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    rng = np.random.default_rng(5)
+    nets = [nx.star_graph(k) for k in (1, 2, 4, 7, 8)]
+    nets += [nx.path_graph(k) for k in (2, 3, 9, 30)]
+    nets += [nx.cycle_graph(k) for k in (3, 8, 17)]
+    nets += [nx.complete_graph(k) for k in (3, 5, 8, 9)]
+    nets += [nx.random_regular_graph(d, k, seed=int(rng.integers(1 << 30)))
+             for d, k in ((3, 10), (4, 15), (6, 12), (8, 20))]
+    nets += [nx.barbell_graph(4, 3), nx.wheel_graph(9),
+             nx.balanced_tree(3, 2), nx.grid_2d_graph(4, 5)]
+    for _ in range(12):
+        k = int(rng.integers(4, 30))
+        g = nx.gnp_random_graph(k, float(rng.uniform(0.1, 0.5)),
+                                seed=int(rng.integers(1 << 30)))
+        g.remove_nodes_from([v for v in list(g.nodes) if g.degree(v) > 8])
+        g = nx.convert_node_labels_to_integers(g)
+        if g.number_of_edges():
+            nets.append(g)
+    graphs = []
+    for g in nets:
+        g = nx.convert_node_labels_to_integers(g)
+        for v in g.nodes:
+            g.nodes[v]['category'] = int(rng.integers(1, 4))
+        for e in g.edges:
+            g.edges[e]['order'] = float(rng.integers(1, 4))
+        graphs.append(Graph.from_networkx(g))
+    graphs = Graph.unify_datatype(graphs)
+    knode = TensorProduct(category=KroneckerDelta(0.5))
+    kedge = TensorProduct(order=SquareExponential(1.0))
+    q = 0.05
+    backend = HIPBackend(real=real, record_iterations=True)
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    K, dK = k(graphs, eval_gradient=True)
+    assert np.array_equal(K, K.T)
+    i, j = np.triu_indices(len(graphs))
+    batch = oracle.TensorProductBatch(graphs, knode, kedge)
+    ref_v, ref_g, _ = batch.run_gradient(i, j, q=q, real='f64')
+    assert np.allclose(K[i, j], ref_v, rtol=2e-5 if real is np.float32 else 1e-8)
+    mask = np.asarray(k.active_theta_mask)
+    got = dK[i, j]
+    want = ref_g[:, mask] if ref_g.shape[1] == len(mask) else ref_g
+    assert got.shape == want.shape
+    scale = np.abs(want).max(axis=0)
+    rtol, atol = (2e-3, 2e-5) if real is np.float32 else (1e-6, 1e-9)
+    assert np.all(np.abs(got - want) <= rtol * np.abs(want) + atol * scale)
+    # value solve: the reference's iteration counts (stopping rule included)
+    Kv = k(graphs)
+    it = backend.iterations(backend.last_plan)
+    val, it_ref = batch.run(i, j, q=q, tol=k.ftol,
+                            real='f32' if real is np.float32 else 'f64')
+    assert np.allclose(Kv[i, j], val, rtol=2e-5 if real is np.float32 else 1e-9)
+    if real is np.float64:
+        # same arithmetic, same rule: counts agree up to the last-bit cases
+        assert len(it) == len(it_ref)
+        assert abs(int(it.sum()) - int(it_ref.sum())) <= 0.02 * it_ref.sum()
