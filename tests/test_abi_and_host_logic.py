@@ -212,6 +212,14 @@ def test_partition_is_balanced_and_complete():
     loads = np.array([cost[s].sum() for s in shards])
     assert loads.max() / loads.mean() < 1.02
     assert max(map(len, shards)) - min(map(len, shards)) <= 1
+    # 'blocks': contiguous runs of the cost-sorted list with equal total cost
+    blocks = partition(cost, 8, mode='blocks')
+    assert np.sort(np.concatenate(blocks)).tolist() == list(range(1001))
+    loads = np.array([cost[s].sum() for s in blocks])
+    assert loads.max() / loads.mean() < 1.05
+    for a, b in zip(blocks, blocks[1:]):     # rank r: costlier pairs than r + 1
+        assert cost[a].min() >= cost[b].max()
+    assert len(blocks[0]) < len(blocks[-1])
 
 
 def _shard_worker(rank, world, port, tmp):
