@@ -303,8 +303,9 @@ class HIPBackend(Backend):
         Microkernel values per pair of label classes from tables instead of
         per nonzero pair (see __init__).
     min_launch: int
-        Owner-computes launches of fewer pairs are merged into the next larger
-        compatible variant in use (default 2048; 0: never).
+        Owner-computes launches of fewer waves (pairs x waves per pair) are
+        merged into the next larger compatible variant in use (default 8192;
+        0: never).
     nodal_gradient_in_kernel: bool
         Nodal Jacobians inside the launch (default) or by re-launches.
     """
@@ -363,7 +364,7 @@ class HIPBackend(Backend):
         self.tables = tables
         self._launch_set = None
         self.min_launch = int(kwargs.pop(
-            'min_launch', os.environ.get('GD_MIN_LAUNCH', 2048)))
+            'min_launch', os.environ.get('GD_MIN_LAUNCH', 8192)))
         self.nodal_gradient_in_kernel = bool(kwargs.pop(
             'nodal_gradient_in_kernel', True))
         if self.occupancy is None and os.environ.get('GD_OCCUPANCY'):
@@ -1083,10 +1084,13 @@ void ${name}(params_t prm) {
         # None); the jobs are ordered by the rank of their class pair with one
         # stable sort of small integers, and every per-launch maximum is taken
         # over class pairs.
-        # Launches of a few hundred pairs cannot fill 256 CUs: their jobs ride
-        # in the next larger owner-computes variant in use (same waves per
-        # pair and degree bound, S and R at least as large) -- fewer, fuller
-        # launches, which matters most for the shards of a multi-GPU run.
+        # Launches of a few thousand waves cannot fill 256 CUs for long (a pair
+        # takes ~20 us from staging to result: every launch has a tail of that
+        # length): their jobs ride in the next larger owner-computes variant in
+        # use (same waves per pair and degree bound, S and R at least as large)
+        # -- fewer, fuller launches, which matters most for the shards of a
+        # multi-GPU run (scripts/minlaunch_experiment.sh: 8192 against 2048
+        # waves: -1 % on the full matrix, -2...8 % on 1/2...1/8 of it).
         if self.min_launch > 0:
             members_ = np.ones(len(choice), dtype=np.int64) if sel is None \
                 else np.bincount(sel, minlength=len(choice))
@@ -1096,7 +1100,7 @@ void ${name}(params_t prm) {
                 if not isinstance(v, OCVariant):
                     continue
                 here = choice == k
-                if int(members_[here].sum()) >= self.min_launch:
+                if int(members_[here].sum()) * v.W >= self.min_launch:
                     continue
                 for k2 in used_[a_ + 1:]:
                     v2 = self.variants[k2]
