@@ -50,6 +50,9 @@ class _Dense:
                     'the first kernel evaluation); dense algebra runs on '
                     'the CPU')
         self.device = torch.device(device)
+        #: Cholesky factorisations on the GPU by the kernels of potrf.hip
+        #: (GD_NATIVE_CHOLESKY=0: torch.linalg.cholesky_ex)
+        self.native_cholesky = os.environ.get('GD_NATIVE_CHOLESKY', '1') != '0'
 
     def tensor(self, a):
         """float64 device tensor of `a`.  A column-major array (the kernel
@@ -69,11 +72,25 @@ class _Dense:
         definite (the reference clamps small eigenvalues to the cutoff:
         base.py:126-127, linalg/spectral.py)."""
         torch = _torch()
-        L, info = torch.linalg.cholesky_ex(K)
-        if int(info) == 0:
-            Kinv = torch.cholesky_inverse(L)
-            logdet = 2.0 * torch.log(torch.diagonal(L)).sum()
-            return Kinv, float(logdet)
+        if K.is_cuda and K.dtype == torch.float64 and self.native_cholesky:
+            # blocked factorisation of potrf.hip (0.9 ms against the 2.7 ms
+            # of the library's column-by-column one at n = 1000), then
+            # K^-1 = X^T X with X = L^-1 from one triangular solve
+            from ._potrf import cholesky_
+            L = torch.tril(cholesky_(K.clone()))
+            d = torch.diagonal(L)
+            ok = bool((torch.isfinite(d) & (d > 0)).all())
+            if ok:
+                X = torch.linalg.solve_triangular(
+                    L, torch.eye(len(L), dtype=L.dtype, device=L.device),
+                    upper=False)
+                return X.T @ X, float(2.0 * torch.log(d).sum())
+        else:
+            L, info = torch.linalg.cholesky_ex(K)
+            if int(info) == 0:
+                Kinv = torch.cholesky_inverse(L)
+                logdet = 2.0 * torch.log(torch.diagonal(L)).sum()
+                return Kinv, float(logdet)
         warnings.warn('Kernel matrix singular, falling back to pseudoinverse')
         w, V = torch.linalg.eigh(0.5 * (K + K.T))
         if not bool(torch.isfinite(w).all()):

@@ -1,0 +1,225 @@
+// Blocked Cholesky factorisation of a dense symmetric positive definite
+// matrix in double precision on gfx950, for the Gaussian process caller of the
+// marginalized graph kernel (reference: scipy on the host,
+// graphdot/model/gaussian_process/base.py:108-127).
+//
+// A 1000 x 1000 kernel matrix is 0.33 GFLOP: the library factorisation
+// (rocSOLVER through torch.linalg.cholesky) is bound by its column-by-column
+// dependency chain, 2.7 ms on MI355X, a fifth of a GPR likelihood step.  Here:
+// right-looking, 64-column panels, two launches per panel --
+//
+//   potrf_panel:  every workgroup factors the (already updated) diagonal
+//                 block by itself, in registers (redundant, but no grid-wide
+//                 dependency inside a launch), with the inverse of the factor
+//                 as a by-product, and turns its own 64-row block of the
+//                 panel into L_ik = A_ik L_kk^-T with one 64 x 64 x 64 product;
+//   syrk_update:  one workgroup per tile of the trailing matrix,
+//                 A_ij -= L_ik L_jk^T.
+//
+// Row-major, lower triangle, in place; the strict upper triangle of the
+// diagonal blocks is zeroed, tiles above the diagonal are left untouched (the
+// caller takes tril).  A matrix that is not positive definite ends with NaN on
+// the diagonal of L.  Compiled without fast-math: the square roots and
+// divisions are the IEEE ones.
+#include <hip/hip_runtime.h>
+
+namespace {
+
+constexpr int B = 64;        // panel width = tile edge
+constexpr int LD = B + 1;    // LDS row stride of a tile (odd: no bank conflicts
+                             // for column walks)
+
+// load a B x B tile (rows r0.., columns c0..) of the n x n row-major matrix;
+// out-of-range entries read 0, or 1 on the diagonal when `identity` is set
+__device__ __forceinline__ void load_tile(double (*T)[LD], const double *A, int ld, int n,
+                                          int r0, int c0, bool identity) {
+    for (int e = threadIdx.x; e < B * B; e += blockDim.x) {
+        const int r = e / B, c = e % B;
+        const int gr = r0 + r, gc = c0 + c;
+        double v = 0;
+        if (gr < n && gc < n) v = A[(size_t)gr * ld + gc];
+        else if (identity && r == c) v = 1;
+        T[r][c] = v;
+    }
+}
+
+// 1 / sqrt(x) to the last bit or two: hardware estimate + two Newton steps
+// (the IEEE sqrt and division it replaces are ~80 dependent instructions on
+// the critical path of every column)
+__device__ __forceinline__ double rsqrt_f64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return x > 0.0 ? y : __builtin_nan("");
+}
+
+}  // namespace
+
+// Panel k0 / 64.  grid.x = number of 64-row blocks from the diagonal block
+// down; 256 threads.  The diagonal block and the inverse of its factor live in
+// registers: thread (ti, tj) of a 16 x 16 grid owns the elements
+// (ti + 16 u, tj + 16 v), u, v = 0..3, of both.  Column j of the factorisation
+// is one barrier: the owners publish column j of D and row j of W = L^-1 (and
+// the owner of the pivot its square root) to one of two LDS buffers, everyone
+// scales what it needs and applies the rank-1 updates
+//     D[r][c] -= l_r l_c   (r, c > j),      W[r][:] -= l_r W[j][:]   (r > j),
+// i.e. the eliminations that turn D into L also turn the identity into L^-1.
+extern "C" __global__ __launch_bounds__(256)
+void potrf_panel_f64(double *A, int ld, int n, int k0) {
+    __shared__ double Li[B][LD];         // L_kk^-1 for the product below
+    __shared__ double C[B][LD];          // this workgroup's block of the panel
+    __shared__ double colD[2][B];        // column j of D (unscaled), two buffers
+    __shared__ double rowW[2][B];        // row j of W (unscaled)
+    __shared__ double pivot[2];          // 1 / sqrt(D[j][j])
+    const int tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
+    const int r0 = k0 + B * (int)blockIdx.x;     // first row of this block
+    double d[4][4], w[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = ti + 16 * u, c = tj + 16 * v;
+            const int gr = k0 + r, gc = k0 + c;
+            // (beyond the matrix: identity, so that the factor stays defined)
+            d[u][v] = (gr < n && gc < n) ? A[(size_t)gr * ld + gc] : (r == c ? 1.0 : 0.0);
+            w[u][v] = (r == c) ? 1.0 : 0.0;
+        }
+    if (blockIdx.x > 0) load_tile(C, A, ld, n, r0, k0, false);
+
+    // (the quarter jq = j / 16 of the column is a compile-time index of the
+    // register tiles: the loop over it is unrolled, the loop over jr is not)
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+#pragma nounroll
+        for (int jr = 0; jr < 16; ++jr) {
+            const int j = 16 * jq + jr, buf = jr & 1;
+            // owners publish column j of D, row j of W and the pivot
+            if (tj == jr) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) colD[buf][ti + 16 * u] = d[u][jq];
+            }
+            if (ti == jr) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) rowW[buf][tj + 16 * v] = w[jq][v];
+                if (tj == jr) pivot[buf] = rsqrt_f64(d[jq][jq]);   // (NaN if not positive)
+            }
+            __syncthreads();
+            const double inv = pivot[buf];
+            double lr[4], lc[4], wj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = ti + 16 * u, c = tj + 16 * u;
+                const double a = colD[buf][r] * inv, b = colD[buf][c] * inv;
+                // column j itself keeps the scaled entries; rows / columns up to
+                // j take no update
+                if (tj == jr && r >= j) d[u][jq] = a;
+                lr[u] = r > j ? a : 0.0;
+                lc[u] = c > j ? b : 0.0;
+                wj[u] = rowW[buf][c] * inv;
+            }
+            if (ti == jr) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) w[jq][v] = wj[v];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    d[u][v] -= lr[u] * lc[v];
+                    w[u][v] -= lr[u] * wj[v];
+                }
+            // (no second barrier: column j + 1 goes to the other buffer, and a
+            // thread is at most one barrier ahead of the slowest)
+        }
+    }
+
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = ti + 16 * u, c = tj + 16 * v;
+                if (k0 + r < n && k0 + c < n)
+                    A[(size_t)(k0 + r) * ld + k0 + c] = c <= r ? d[u][v] : 0.0;
+            }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = ti + 16 * u, c = tj + 16 * v;
+            Li[r][c] = c <= r ? w[u][v] : 0.0;
+        }
+    __syncthreads();
+
+    // ---- L_ik = C L_kk^-T:  X[r][c] = sum_{p <= c} C[r][p] Linv[c][p] --------
+    // (thread (ti, tj) computes the outputs (ti + 16 u, tj + 16 v): the 16
+    // threads of a row read 16 rows of Linv at the odd stride LD -- distinct
+    // banks -- and write 16 consecutive columns)
+    {
+        double x[4][4] = {};
+        for (int p = 0; p < B; ++p) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = C[ti + 16 * u][p];
+                b[u] = Li[tj + 16 * u][p];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) x[u][v] += a[u] * b[v];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int gr = r0 + ti + 16 * u, gc = k0 + tj + 16 * v;
+                if (gr < n && gc < n) A[(size_t)gr * ld + gc] = x[u][v];
+            }
+    }
+}
+
+// Trailing update after panel k0 / 64: tile t of the lower triangle of the
+// remaining blocks, A_ij -= L_ik L_jk^T.  grid.x = m (m + 1) / 2 with m the
+// number of row blocks below the panel's diagonal block.
+extern "C" __global__ __launch_bounds__(256)
+void syrk_update_f64(double *A, int ld, int n, int k0) {
+    __shared__ double Ti[B][LD];
+    __shared__ double Tj[B][LD];
+    // linear tile index -> (bi, bj), bj <= bi
+    int t = blockIdx.x, bi = 0;
+    while (t > bi) {
+        t -= bi + 1;
+        ++bi;
+    }
+    const int bj = t;
+    const int r0 = k0 + B * (bi + 1), c0 = k0 + B * (bj + 1);
+    load_tile(Ti, A, ld, n, r0, k0, false);
+    load_tile(Tj, A, ld, n, c0, k0, false);
+    __syncthreads();
+    const int tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
+    double x[4][4] = {};
+    for (int p = 0; p < B; ++p) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = Ti[ti + 16 * u][p];
+            b[u] = Tj[tj + 16 * u][p];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) x[u][v] += a[u] * b[v];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int gr = r0 + ti + 16 * u, gc = c0 + tj + 16 * v;
+            if (gr < n && gc < n) A[(size_t)gr * ld + gc] -= x[u][v];
+        }
+}

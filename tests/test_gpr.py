@@ -341,3 +341,91 @@ def test_against_the_reference_regressor():
         lmean, lstd = g3.predict_loocv(Z, z, return_std=True)
         assert np.allclose(lmean, c['loocv_mean'], rtol=1e-8, atol=1e-10)
         assert np.allclose(lstd, c['loocv_std'], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_native_blocked_cholesky():
+    """potrf.hip (64-column panels, two launches per panel) against
+    torch.linalg.cholesky in float64: sizes around the panel width, the
+    benchmark size, a non-contiguous row stride; a matrix that is not
+    positive definite ends with NaN on the diagonal; the GPR uses it
+    (likelihood and gradient equal to the library path's)."""
+    import torch
+    from graphdot_amd.model.gaussian_process._potrf import cholesky_
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for n in (1, 2, 5, 63, 64, 65, 128, 130, 500, 1000, 1037):
+        A = torch.randn(n, n, dtype=torch.float64, device='cuda', generator=g)
+        K = A @ A.T / n + 0.1 * torch.eye(n, dtype=torch.float64,
+                                          device='cuda')
+        ref = torch.linalg.cholesky(K)
+        L = torch.tril(cholesky_(K.clone()))
+        err = float((L - ref).abs().max() / ref.abs().max())
+        assert err < 1e-12, (n, err)
+        assert float((L @ L.T - K).abs().max() / K.abs().max()) < 1e-13
+    # row stride larger than n
+    big = torch.zeros(200, 256, dtype=torch.float64, device='cuda')
+    A = torch.randn(200, 200, dtype=torch.float64, device='cuda', generator=g)
+    K = A @ A.T / 200 + 0.1 * torch.eye(200, dtype=torch.float64,
+                                        device='cuda')
+    view = big[:, :200]
+    view.copy_(K)
+    L = torch.tril(cholesky_(view))
+    assert float((L - torch.linalg.cholesky(K)).abs().max()) < 1e-12
+    assert float(big[:, 200:].abs().max()) == 0.0
+    # column-major (what the kernel's device_gram hands to the regressor)
+    Kc = K.T.contiguous().T
+    assert Kc.stride(0) == 1
+    L = torch.tril(cholesky_(Kc.clone()))
+    assert float((L - torch.linalg.cholesky(K)).abs().max()) < 1e-12
+    # not positive definite
+    K = torch.eye(100, dtype=torch.float64, device='cuda')
+    K[70, 70] = -1.0
+    d = torch.diagonal(torch.tril(cholesky_(K.clone())))
+    assert not bool(torch.isfinite(d).all())
+    # through the regressor
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(300, 2))
+    y = np.sin(X[:, 0]) + 0.1 * rng.normal(size=300)
+
+    class RBF:
+        def __init__(self, ls=1.0):
+            self.ls = ls
+
+        @property
+        def theta(self):
+            return np.log([self.ls])
+
+        @theta.setter
+        def theta(self, t):
+            self.ls = float(np.exp(t[0]))
+
+        @property
+        def bounds(self):
+            return np.log([[1e-2, 1e2]])
+
+        def clone_with_theta(self, t):
+            k = RBF()
+            k.theta = t
+            return k
+
+        def __call__(self, X, Y=None, eval_gradient=False):
+            Y = X if Y is None else Y
+            d2 = ((X[:, None, :] - Y[None, :, :])**2).sum(-1)
+            K = np.exp(-0.5 * d2 / self.ls**2)
+            if eval_gradient:
+                return K, (K * d2 / self.ls**3)[:, :, None]
+            return K
+
+        def diag(self, X):
+            return np.ones(len(X))
+
+    results = []
+    for native in (True, False):
+        gpr = GaussianProcessRegressor(RBF(0.7), alpha=1e-3, device='cuda')
+        gpr._dense().native_cholesky = native
+        gpr.X, gpr.y = X, y
+        results.append(gpr.log_marginal_likelihood(np.log([0.7]),
+                                                   eval_gradient=True))
+    (v1, g1), (v0, g0) = results
+    assert v1 == pytest.approx(v0, rel=1e-10)
+    assert np.allclose(g1, g0, rtol=1e-8)
