@@ -2,7 +2,7 @@
 """How well does a cost model linear in (product-graph nonzeros, product-graph
 rows, 1) -- the shape of `_sharded.predict_cost` -- explain the measured
 per-variant launch times of profiles/r02_bench_{f64,f32}.json?  (Host only.)
-Answer on MI355X: not well -- residuals of -45 ... +9 %: the time per pair
+Answer on MI355X: not well -- residuals of -57 ... +9 %: the time per pair
 steps with the solver variant (registers -> waves per SIMD), not with the
 arithmetic.  Hence the snake dealing of `_sharded.partition`, which is balanced
 whatever the weights are."""
