@@ -90,8 +90,8 @@ def parse():
                          'one GPU the extra cross-stream dependencies cost '
                          'more than the overlap hides, DESIGN.md section 8)')
     ap.add_argument('--serial', action='store_true',
-                    help='all solver variants on one stream (default: one '
-                         'HIP stream per variant so short launches fill the '
+                    help='all solver variants on one stream (default: dealt '
+                         'onto three HIP streams so short launches fill the '
                          'tails of long ones)')
     ap.add_argument('--isolated-steps', type=int, default=3,
                     help='serial steps after the timed region that give the '
@@ -125,7 +125,7 @@ def algorithmic_lds_reals(n_node, n_nz, ji, jj, iters):
 
 class LocalStep:
     """One rank, no collective: the plan's launches through a `LaunchSet`
-    (table kernel on the null stream, one stream per solver variant, ordered
+    (table kernel on the null stream, solver launches on three streams, ordered
     against the previous step by device-side events)."""
 
     def __init__(self, backend, plan):
