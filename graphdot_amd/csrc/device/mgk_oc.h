@@ -198,6 +198,9 @@ struct oc_solver {
 #ifndef GD_OC_CHUNK
 #define GD_OC_CHUNK 4
 #endif
+#ifndef GD_OC_RCP
+#define GD_OC_RCP 1
+#endif
 #ifndef GD_OC_PIN
 #define GD_OC_PIN 0   // 1: pin every slot's registers (serialises the slots' loads)
 #endif
@@ -230,6 +233,23 @@ struct oc_solver {
     };
 
     __device__ static __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+    // alpha and beta of the CG recurrence, a / b of two wave-uniform numbers.
+    // Double: v_rcp_f64 and two Newton steps, then one product -- 6
+    // instructions for a result within 1.5 ulp, against the 9 to 11 of the
+    // division the compiler expands (a third refinement and a final
+    // correction that the 1e-8 N stopping rule cannot see).
+    __device__ static __forceinline__ float cg_ratio(float a, float b) { return a / b; }
+    __device__ static __forceinline__ double cg_ratio(double a, double b) {
+#if GD_OC_RCP
+        double y = __builtin_amdgcn_rcp(b);
+        y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+        y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
+        return a * y;
+#else
+        return a / b;
+#endif
+    }
 
     // Sorted position of the row that thread `tid` (lane `lane` of wave `wv`)
     // owns in batch k.  The 64-row chunks of a batch go to the waves in snake
@@ -662,7 +682,7 @@ struct oc_solver {
                 }
                 pAp = reduce::sum(pAp, red0);
                 if (pAp == real(0)) break;
-                const real alpha = rTz / pAp;
+                const real alpha = cg_ratio(rTz, pAp);
                 real rTr = 0, rTz_next = 0;
                 real z[C][R];
                 if constexpr (!KEEP_X) {
@@ -670,6 +690,9 @@ struct oc_solver {
 #pragma unroll
                     for (int k = 0; k < R; ++k) pdot += pp[k] * p[0][k];
                     xs += alpha * pdot;
+                    // (here, not after the update of p: the old p can then be
+                    // overwritten in place instead of being copied)
+                    asm volatile("" : "+v"(xs));
                 }
 #pragma unroll
                 for (int k = 0; k < R; ++k)
@@ -686,7 +709,10 @@ struct oc_solver {
                     ++it;
                     break;
                 }
-                const real beta = rTz_next / rTz;
+                real beta = cg_ratio(rTz_next, rTz);
+                // (one scalar: without the pin fast-math turns z + beta p into
+                // (p rTz') (1 / rTz) + z, a multiplication more per element)
+                asm volatile("" : "+v"(beta));
 #pragma unroll
                 for (int k = 0; k < R; ++k)
 #pragma unroll
