@@ -1,7 +1,9 @@
 """Host side of the blocked Cholesky factorisation of potrf.hip: compiles the
-two kernels once (JIT cache of graphdot_amd.hip.jit, IEEE arithmetic: no
+three kernels once (JIT cache of graphdot_amd.hip.jit, IEEE arithmetic: no
 fast-math) and runs them on a float64 torch tensor in place.  The launches go
-to the null stream, where torch's own work of this process is ordered too."""
+to torch's *current* stream of the tensor's device, so that they are ordered
+against the torch operations around them (the clone before, tril / the
+triangular solve after) whatever stream the caller works on."""
 import os
 import struct
 import threading
@@ -31,7 +33,8 @@ def _load():
         if _kernels is None:
             from ...hip import jit, runtime
             mod = runtime.Module(jit.load_image(precompile()))
-            _kernels = (mod, mod.function('potrf_panel_f64'),
+            _kernels = (mod, mod.function('potrf_diag_f64'),
+                        mod.function('potrf_panel_f64'),
                         mod.function('syrk_update_f64'))
     return _kernels
 
@@ -53,16 +56,24 @@ def cholesky_(A):
         assert A.stride(0) == 1, 'rows or columns must be contiguous'
         A = A.T
     ld = A.stride(0) if n > 1 else 1
-    _, panel, syrk = _load()
+    _, diag, panel, syrk = _load()
     ptr = A.data_ptr()
-    # (torch's current stream of a default-configured process is the null
-    # stream; a caller on another stream orders against it with events)
+    with torch.cuda.device(A.device):
+        stream = torch.cuda.current_stream().cuda_stream or None
+        # L_kk^-1 of the panel in flight (64 x 64): written by the one
+        # workgroup that factors the diagonal block, read by the panel launch
+        # behind it (the caching allocator keeps the block tied to this stream)
+        work = torch.empty(_B * _B, dtype=torch.float64, device=A.device)
     nb = -(-n // _B)
-    for kb in range(nb):
-        k0 = kb * _B
-        args = struct.pack('<Qiii', ptr, ld, n, k0)
-        runtime.launch(panel, nb - kb, 256, args)
-        m = nb - kb - 1
-        if m > 0:
-            runtime.launch(syrk, m * (m + 1) // 2, 256, args)
+
+    def args(k0):
+        return struct.pack('<QiiiiQ', ptr, ld, n, k0, 0, work.data_ptr())  # (pad: Linv is 8-aligned)
+    runtime.launch(diag, 1, 256, args(0), stream=stream)
+    for kb in range(nb - 1):
+        a = args(kb * _B)
+        m = nb - kb - 1              # row blocks below the diagonal block
+        runtime.launch(panel, m, 256, a, stream=stream)
+        # (tile 0 of the trailing update is the next diagonal block: its
+        # workgroup factors it and refills `work`)
+        runtime.launch(syrk, m * (m + 1) // 2, 256, a, stream=stream)
     return A

@@ -8,13 +8,22 @@
 // dependency chain, 2.7 ms on MI355X, a fifth of a GPR likelihood step.  Here:
 // right-looking, 64-column panels, two launches per panel --
 //
-//   potrf_panel:  every workgroup factors the (already updated) diagonal
-//                 block by itself, in registers (redundant, but no grid-wide
-//                 dependency inside a launch), with the inverse of the factor
-//                 as a by-product, and turns its own 64-row block of the
-//                 panel into L_ik = A_ik L_kk^-T with one 64 x 64 x 64 product;
+//   potrf_panel:  one workgroup per 64-row block below the diagonal block,
+//                 L_ik = A_ik L_kk^-T, one 64 x 64 x 64 product with the
+//                 inverse of the diagonal factor read from a 64 x 64 workspace;
 //   syrk_update:  one workgroup per tile of the trailing matrix,
-//                 A_ij -= L_ik L_jk^T.
+//                 A_ij -= L_ik L_jk^T; the workgroup of the first tile -- the
+//                 next panel's diagonal block -- goes on to factor it (in
+//                 registers, with the inverse of the factor as a by-product)
+//                 and leaves L in place and L^-1 in the workspace;
+//
+// and one potrf_diag launch (a single workgroup) for the first diagonal block.
+// Exactly ONE workgroup ever reads and writes a diagonal block, and the
+// launches that consume its factor come behind it in stream order: nothing
+// inside a launch depends on another workgroup.  (Round 2 had every workgroup
+// of the panel launch factor the diagonal block redundantly from global memory
+// while workgroup 0 wrote the factor back in place: a workgroup dispatched
+// late could read L_kk for A_kk.)
 //
 // Row-major, lower triangle, in place; the strict upper triangle of the
 // diagonal blocks is zeroed, tiles above the diagonal are left untouched (the
@@ -53,40 +62,23 @@ __device__ __forceinline__ double rsqrt_f64(double x) {
     return x > 0.0 ? y : __builtin_nan("");
 }
 
-}  // namespace
-
-// Panel k0 / 64.  grid.x = number of 64-row blocks from the diagonal block
-// down; 256 threads.  The diagonal block and the inverse of its factor live in
-// registers: thread (ti, tj) of a 16 x 16 grid owns the elements
-// (ti + 16 u, tj + 16 v), u, v = 0..3, of both.  Column j of the factorisation
-// is one barrier: the owners publish column j of D and row j of W = L^-1 (and
-// the owner of the pivot its square root) to one of two LDS buffers, everyone
-// scales what it needs and applies the rank-1 updates
+// Factorisation of one 64 x 64 diagonal block held in registers by 256
+// threads: thread (ti, tj) of a 16 x 16 grid owns the elements
+// (ti + 16 u, tj + 16 v), u, v = 0..3, of the block D and of W, which starts as
+// the identity.  Column j is one barrier: the owners publish column j of D and
+// row j of W (and the owner of the pivot its inverse square root) to one of
+// two LDS buffers, everyone scales what it needs and applies the rank-1 updates
 //     D[r][c] -= l_r l_c   (r, c > j),      W[r][:] -= l_r W[j][:]   (r > j),
 // i.e. the eliminations that turn D into L also turn the identity into L^-1.
-extern "C" __global__ __launch_bounds__(256)
-void potrf_panel_f64(double *A, int ld, int n, int k0) {
-    __shared__ double Li[B][LD];         // L_kk^-1 for the product below
-    __shared__ double C[B][LD];          // this workgroup's block of the panel
-    __shared__ double colD[2][B];        // column j of D (unscaled), two buffers
-    __shared__ double rowW[2][B];        // row j of W (unscaled)
-    __shared__ double pivot[2];          // 1 / sqrt(D[j][j])
+struct factor_lds_t {
+    double colD[2][B];        // column j of D (unscaled), two buffers
+    double rowW[2][B];        // row j of W (unscaled)
+    double pivot[2];          // 1 / sqrt(D[j][j])
+};
+
+__device__ __forceinline__ void factor_block(double (&d)[4][4], double (&w)[4][4], factor_lds_t &s) {
     const int tid = threadIdx.x;
     const int ti = tid >> 4, tj = tid & 15;
-    const int r0 = k0 + B * (int)blockIdx.x;     // first row of this block
-    double d[4][4], w[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int r = ti + 16 * u, c = tj + 16 * v;
-            const int gr = k0 + r, gc = k0 + c;
-            // (beyond the matrix: identity, so that the factor stays defined)
-            d[u][v] = (gr < n && gc < n) ? A[(size_t)gr * ld + gc] : (r == c ? 1.0 : 0.0);
-            w[u][v] = (r == c) ? 1.0 : 0.0;
-        }
-    if (blockIdx.x > 0) load_tile(C, A, ld, n, r0, k0, false);
-
     // (the quarter jq = j / 16 of the column is a compile-time index of the
     // register tiles: the loop over it is unrolled, the loop over jr is not)
 #pragma unroll
@@ -97,26 +89,26 @@ void potrf_panel_f64(double *A, int ld, int n, int k0) {
             // owners publish column j of D, row j of W and the pivot
             if (tj == jr) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) colD[buf][ti + 16 * u] = d[u][jq];
+                for (int u = 0; u < 4; ++u) s.colD[buf][ti + 16 * u] = d[u][jq];
             }
             if (ti == jr) {
 #pragma unroll
-                for (int v = 0; v < 4; ++v) rowW[buf][tj + 16 * v] = w[jq][v];
-                if (tj == jr) pivot[buf] = rsqrt_f64(d[jq][jq]);   // (NaN if not positive)
+                for (int v = 0; v < 4; ++v) s.rowW[buf][tj + 16 * v] = w[jq][v];
+                if (tj == jr) s.pivot[buf] = rsqrt_f64(d[jq][jq]);   // (NaN if not positive)
             }
             __syncthreads();
-            const double inv = pivot[buf];
+            const double inv = s.pivot[buf];
             double lr[4], lc[4], wj[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int r = ti + 16 * u, c = tj + 16 * u;
-                const double a = colD[buf][r] * inv, b = colD[buf][c] * inv;
+                const double a = s.colD[buf][r] * inv, b = s.colD[buf][c] * inv;
                 // column j itself keeps the scaled entries; rows / columns up to
                 // j take no update
                 if (tj == jr && r >= j) d[u][jq] = a;
                 lr[u] = r > j ? a : 0.0;
                 lc[u] = c > j ? b : 0.0;
-                wj[u] = rowW[buf][c] * inv;
+                wj[u] = s.rowW[buf][c] * inv;
             }
             if (ti == jr) {
 #pragma unroll
@@ -133,62 +125,99 @@ void potrf_panel_f64(double *A, int ld, int n, int k0) {
             // thread is at most one barrier ahead of the slowest)
         }
     }
+}
 
-    if (blockIdx.x == 0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int r = ti + 16 * u, c = tj + 16 * v;
-                if (k0 + r < n && k0 + c < n)
-                    A[(size_t)(k0 + r) * ld + k0 + c] = c <= r ? d[u][v] : 0.0;
-            }
-        return;
-    }
+// L (lower triangle, zeros above) of the diagonal block at k0 into A, its
+// inverse into the dense 64 x 64 row-major workspace
+__device__ __forceinline__ void store_factor(double *A, int ld, int n, int k0, double *Linv,
+                                             const double (&d)[4][4], const double (&w)[4][4]) {
+    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int r = ti + 16 * u, c = tj + 16 * v;
-            Li[r][c] = c <= r ? w[u][v] : 0.0;
+            if (k0 + r < n && k0 + c < n)
+                A[(size_t)(k0 + r) * ld + k0 + c] = c <= r ? d[u][v] : 0.0;
+            Linv[r * B + c] = c <= r ? w[u][v] : 0.0;
         }
-    __syncthreads();
+}
 
-    // ---- L_ik = C L_kk^-T:  X[r][c] = sum_{p <= c} C[r][p] Linv[c][p] --------
+}  // namespace
+
+// The first diagonal block (k0 = 0 in a full factorisation): ONE workgroup of
+// 256 threads factors it and leaves L in place and L^-1 in `Linv`.
+extern "C" __global__ __launch_bounds__(256)
+void potrf_diag_f64(double *A, int ld, int n, int k0, double *Linv) {
+    __shared__ factor_lds_t s;
+    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+    double d[4][4], w[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = ti + 16 * u, c = tj + 16 * v;
+            const int gr = k0 + r, gc = k0 + c;
+            // (beyond the matrix: identity, so that the factor stays defined)
+            d[u][v] = (gr < n && gc < n) ? A[(size_t)gr * ld + gc] : (r == c ? 1.0 : 0.0);
+            w[u][v] = (r == c) ? 1.0 : 0.0;
+        }
+    factor_block(d, w, s);
+    store_factor(A, ld, n, k0, Linv, d, w);
+}
+
+// Panel k0 / 64 below its (already factored) diagonal block: workgroup b takes
+// the 64-row block b + 1, L_ik = A_ik L_kk^-T.  grid.x = number of 64-row
+// blocks below the diagonal block; 256 threads.  Reads `Linv`, never the
+// diagonal block.
+extern "C" __global__ __launch_bounds__(256)
+void potrf_panel_f64(double *A, int ld, int n, int k0, const double *Linv) {
+    __shared__ double Li[B][LD];         // L_kk^-1
+    __shared__ double C[B][LD];          // this workgroup's block of the panel
+    const int tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
+    const int r0 = k0 + B * ((int)blockIdx.x + 1);     // first row of this block
+    load_tile(C, A, ld, n, r0, k0, false);
+    for (int e = tid; e < B * B; e += 256) Li[e / B][e % B] = Linv[e];
+    __syncthreads();
+    // X[r][c] = sum_{p <= c} C[r][p] Linv[c][p]
     // (thread (ti, tj) computes the outputs (ti + 16 u, tj + 16 v): the 16
     // threads of a row read 16 rows of Linv at the odd stride LD -- distinct
     // banks -- and write 16 consecutive columns)
-    {
-        double x[4][4] = {};
-        for (int p = 0; p < B; ++p) {
-            double a[4], b[4];
+    double x[4][4] = {};
+    for (int p = 0; p < B; ++p) {
+        double a[4], b[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = C[ti + 16 * u][p];
-                b[u] = Li[tj + 16 * u][p];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) x[u][v] += a[u] * b[v];
+        for (int u = 0; u < 4; ++u) {
+            a[u] = C[ti + 16 * u][p];
+            b[u] = Li[tj + 16 * u][p];
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int gr = r0 + ti + 16 * u, gc = k0 + tj + 16 * v;
-                if (gr < n && gc < n) A[(size_t)gr * ld + gc] = x[u][v];
-            }
+            for (int v = 0; v < 4; ++v) x[u][v] += a[u] * b[v];
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int gr = r0 + ti + 16 * u, gc = k0 + tj + 16 * v;
+            if (gr < n && gc < n) A[(size_t)gr * ld + gc] = x[u][v];
+        }
 }
 
 // Trailing update after panel k0 / 64: tile t of the lower triangle of the
 // remaining blocks, A_ij -= L_ik L_jk^T.  grid.x = m (m + 1) / 2 with m the
-// number of row blocks below the panel's diagonal block.
+// number of row blocks below the panel's diagonal block.  Tile 0 is the next
+// panel's diagonal block: its workgroup -- the only one that touches it --
+// factors the updated block from its registers and writes L in place and
+// L^-1 to `Linv` (which the panel launch of k0 has finished reading: stream
+// order).
 extern "C" __global__ __launch_bounds__(256)
-void syrk_update_f64(double *A, int ld, int n, int k0) {
+void syrk_update_f64(double *A, int ld, int n, int k0, double *Linv) {
     __shared__ double Ti[B][LD];
     __shared__ double Tj[B][LD];
+    __shared__ factor_lds_t s;
     // linear tile index -> (bi, bj), bj <= bi
     int t = blockIdx.x, bi = 0;
     while (t > bi) {
@@ -214,6 +243,21 @@ void syrk_update_f64(double *A, int ld, int n, int k0) {
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int v = 0; v < 4; ++v) x[u][v] += a[u] * b[v];
+    }
+    if (blockIdx.x == 0) {      // (workgroup-uniform)
+        double w[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = ti + 16 * u, c = tj + 16 * v;
+                const int gr = r0 + r, gc = c0 + c;
+                x[u][v] = (gr < n && gc < n) ? A[(size_t)gr * ld + gc] - x[u][v] : (r == c ? 1.0 : 0.0);
+                w[u][v] = (r == c) ? 1.0 : 0.0;
+            }
+        factor_block(x, w, s);
+        store_factor(A, ld, n, r0, Linv, x, w);
+        return;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)

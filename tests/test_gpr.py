@@ -345,7 +345,8 @@ def test_against_the_reference_regressor():
 
 @pytest.mark.gpu
 def test_native_blocked_cholesky():
-    """potrf.hip (64-column panels, two launches per panel) against
+    """potrf.hip (64-column panels, two launches per panel, one workgroup per
+    diagonal block) against
     torch.linalg.cholesky in float64: sizes around the panel width, the
     benchmark size, a non-contiguous row stride; a matrix that is not
     positive definite ends with NaN on the diagonal; the GPR uses it
@@ -377,6 +378,27 @@ def test_native_blocked_cholesky():
     assert Kc.stride(0) == 1
     L = torch.tril(cholesky_(Kc.clone()))
     assert float((L - torch.linalg.cholesky(K)).abs().max()) < 1e-12
+    # on a side stream, between torch operations of that stream, while another
+    # stream keeps the compute units busy (workgroups of one launch are then
+    # dispatched far apart in time: every diagonal block must still be read
+    # and written by exactly one workgroup -- round 2's panel kernel let late
+    # workgroups read the factor for the block)
+    n = 4000
+    A = torch.randn(n, n, dtype=torch.float64, device='cuda', generator=g)
+    K = A @ A.T / n + 0.1 * torch.eye(n, dtype=torch.float64, device='cuda')
+    ref = torch.linalg.cholesky(K)
+    hog, side = torch.cuda.Stream(), torch.cuda.Stream()
+    B1 = torch.randn(4096, 4096, device='cuda')
+    torch.cuda.synchronize()
+    for _ in range(3):
+        with torch.cuda.stream(hog):
+            for _ in range(40):
+                B1 @ B1
+        with torch.cuda.stream(side):
+            L = torch.tril(cholesky_(K.clone()))
+            resid = (L - ref).abs().max() / ref.abs().max()
+        torch.cuda.synchronize()
+        assert float(resid) < 1e-12, float(resid)
     # not positive definite
     K = torch.eye(100, dtype=torch.float64, device='cuda')
     K[70, 70] = -1.0
