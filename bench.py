@@ -222,20 +222,60 @@ def measure_api(graphs, knode, kedge, q, real, device, gradient, n_pairs):
             'note': 'host-, PCIe- and conversion-inclusive; never `value`'}
 
 
-def gpr_step_line(args):
+def init_ranks(world, local_rank):
+    """Process group of a multi-rank run: RCCL ("nccl") with one GPU per rank,
+    gloo on host memory when the ranks have to share devices (development
+    box).  Returns (torch, dist, host_collective, device ordinal)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 400))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    n_dev = torch.cuda.device_count()
+    host_collective = False
+    if n_dev >= world:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device(
+            'cuda', local_rank))
+    else:
+        # fewer GPUs than ranks (development box): ranks share devices
+        # and the all-gather goes through gloo on host memory
+        host_collective = True
+        local_rank = local_rank % max(n_dev, 1)
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('gloo')
+    return torch, dist, host_collective, local_rank
+
+
+def gpr_step_line(args, world, rank, local_rank):
     """`--gpr`: the caller of configuration 5 (SURVEY 8f rank 3,
-    graphdot/model/gaussian_process/gpr.py:222-268) on one GPU."""
+    graphdot/model/gaussian_process/gpr.py:222-268): one log marginal
+    likelihood + gradient evaluation per step.  On N ranks the kernel matrix
+    and its gradient are pair-sharded (`distributed_backend`), all-gathered
+    and reassembled on every rank's device, where the regressor picks them up
+    (`device_gram`): no host arrays on the way; the dense algebra (1-2 ms) is
+    replicated."""
     import torch                                    # noqa: F401  (first)
     import cases
     from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
     from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    from graphdot_amd.kernel.marginalized._sharded import distributed_backend
     from graphdot_amd.model.gaussian_process import GaussianProcessRegressor
     real = np.float32 if args.dtype == 'f32' else np.float64
     n = args.graphs or 1000
     graphs = cases.config3_graphs(n)
     knode, kedge, q = cases.config3_kernels()
-    kernel = MarginalizedGraphKernel(knode, kedge, q=q,
-                                     backend=HIPBackend(real=real))
+    dist, host_collective = None, False
+    if world > 1 or args.sharded:
+        torch, dist, host_collective, local_rank = init_ranks(world,
+                                                              local_rank)
+        backend = distributed_backend(real=real, device=local_rank,
+                                      shard_single_rank=True)
+    else:
+        backend = HIPBackend(real=real, device=local_rank)
+    kernel = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
     y = np.random.default_rng(0).normal(size=n)
     d = kernel.diag(graphs)
     gpr = GaussianProcessRegressor(kernel, alpha=float(1e-2 * d.mean()),
@@ -243,18 +283,48 @@ def gpr_step_line(args):
     gpr.X, gpr.y = graphs, y
     theta = np.array(kernel.theta)
     parts = {'kernel': 0.0, 'linalg': 0.0}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None and world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    value = None
     for w in range(max(args.warmup, 1)):
-        gpr.log_marginal_likelihood(theta + 1e-3 * w, eval_gradient=True)
+        value = gpr.log_marginal_likelihood(theta + 1e-3 * w,
+                                            eval_gradient=True)
+    barrier()
     t0 = time.perf_counter()
     for it in range(args.steps):
         gpr.log_marginal_likelihood(theta + 1e-3 * it, eval_gradient=True)
         for k in parts:
             parts[k] += gpr.last_timing[k]
-    dt = (time.perf_counter() - t0) / args.steps
+    barrier()
+    elapsed = time.perf_counter() - t0
+    on_device = getattr(backend, 'last_step', None) is not None \
+        or dist is None
+    if dist is not None and world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device='cpu' if host_collective else 'cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        # every rank evaluated the same objective from its own copy
+        v = torch.tensor([value[0]], dtype=torch.float64,
+                         device='cpu' if host_collective else 'cuda')
+        lo, hi = v.clone(), v.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert float(lo) == float(hi), 'ranks disagree on the likelihood'
+    if dist is not None:
+        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    dt = elapsed / args.steps
     n_pairs = n * (n + 1) // 2
     return {
         'metric': 'graph-pairs/sec (GPR likelihood + gradient step)',
-        'value': n_pairs / dt, 'unit': 'graph-pairs/s', 'n_gpus': 1,
+        'value': n_pairs / dt, 'unit': 'graph-pairs/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt,
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
@@ -263,24 +333,55 @@ def gpr_step_line(args):
                                'pairs, 7 hyperparameters): value + dK/dtheta '
                                'on the solver, Cholesky and the gradient '
                                'contractions in float64 torch on the same GPU',
-                   'graphs': n, 'pairs': n_pairs, 'parallelism': 'single'},
+                   'graphs': n, 'pairs': n_pairs,
+                   'parallelism': (f'pair-sharded x{world}, device-resident '
+                                   'reassembly, replicated dense algebra')
+                   if dist is not None else 'single'},
         'kernel_ms': 1e3 * parts['kernel'] / args.steps,
         'dense_algebra_ms': 1e3 * parts['linalg'] / args.steps,
+        'device_resident_kernel_matrix': bool(on_device),
+        'collective': None if dist is None else
+        ('gloo/host' if host_collective else 'nccl(RCCL)'),
         'roofline': None, 'cpu_baseline': None}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as
+    children (the driver's own launch line) and leave with their exit code.
+    Nothing in THIS process has touched the GPU yet."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] \
+        + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
     args = parse()
-    if args.gpr:
-        if args.dtype is None:
-            args.dtype = 'f32'
-        print(json.dumps(gpr_step_line(args)), flush=True)
-        return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.gpr:
+        if args.dtype is None:
+            args.dtype = 'f32'
+        line = gpr_step_line(args, world, rank, local_rank)
+        if line is not None:
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            print(json.dumps(line), flush=True)
+        return
     if args.dtype is None:
         args.dtype = 'f64' if args.config == 3 else 'f32'
     sharded = world > 1 or args.sharded
@@ -288,25 +389,8 @@ def main():
     dist = torch = None
     host_collective = False
     if sharded:
-        import torch
-        import torch.distributed as dist
-        if world == 1:
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 400))
-            os.environ.setdefault('RANK', '0')
-            os.environ.setdefault('WORLD_SIZE', '1')
-        n_dev = torch.cuda.device_count()
-        if n_dev >= world:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group('nccl', device_id=torch.device(
-                'cuda', local_rank))
-        else:
-            # fewer GPUs than ranks (development box): ranks share devices
-            # and the all-gather goes through gloo on host memory
-            host_collective = True
-            local_rank = local_rank % max(n_dev, 1)
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group('gloo')
+        torch, dist, host_collective, local_rank = init_ranks(world,
+                                                              local_rank)
 
     from graphdot_amd.hip import runtime
     from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
@@ -314,7 +398,10 @@ def main():
     from graphdot_amd.kernel.marginalized._sharded import ShardedStep
 
     real = np.float32 if args.dtype == 'f32' else np.float64
-    backend = HIPBackend(device=local_rank, real=real, record_iterations=True)
+    # sharded: no launch merging, like `distributed_backend` -- which solver
+    # variant a pair runs on must not depend on the rank count
+    backend = HIPBackend(device=local_rank, real=real, record_iterations=True,
+                         **({'min_launch': 0} if sharded else {}))
     graphs, knode, kedge, q, workload_name, (Fv, Fe) = workload(args)
     kernel = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
     n = len(graphs)

@@ -27,12 +27,15 @@ __device__ __forceinline__ float rsqrt(float x) { return __frsqrt_rn(x); }
 // (double: under -ffast-math `1.0 / sqrt(x)` becomes a bare v_rsq_f64, good
 // to ~1e-8 only; two Newton steps on the hardware estimate restore double
 // precision)
+// x = 0 and x = +inf keep the hardware result (inf, 0) like 1 / sqrt(x): the
+// refinement would turn them into 0 * inf * inf = NaN.  (v_cmp_class: an
+// `x == 0 || isinf(x)` test does not survive -ffast-math.)
 __device__ __forceinline__ double rsqrt(double x) {
-    double y = __builtin_amdgcn_rsq(x);
+    const double y0 = __builtin_amdgcn_rsq(x);
     const double h = 0.5 * x;
+    double y = y0 * (1.5 - h * y0 * y0);
     y = y * (1.5 - h * y * y);
-    y = y * (1.5 - h * y * y);
-    return y;
+    return __builtin_amdgcn_class(x, 0x20 | 0x40 | 0x200) ? y0 : y;   // -0, +0, +inf
 }
 
 // pow / log / exp in the arithmetic of their arguments.  The code generator

@@ -24,10 +24,15 @@ struct nz_t {            // one directed nonzero of the adjacency matrix
     std::uint16_t i, j;  // row (source), column (target), new numbering
 };
 
-struct graph_header_t {  // 32 bytes, see _devicegraph.HEADER_DTYPE
+struct graph_header_t {  // 64 bytes, see _devicegraph.HEADER_DTYPE
     std::int32_t n_node;
     std::int32_t n_nz;   // directed nonzeros (self loop counted once)
     std::uint32_t degree, node, rowptr, nz, edge, perm;  // byte offsets
+    // nodes per adjacency count 0..14 (hist[15]: 15 and above).  Nodes are
+    // stored by descending count, so this is all the owner-computes solver
+    // needs to lay out its degree-pair rectangles (mgk_oc.h) -- read with the
+    // header into scalar registers instead of counted per pair with ballots.
+    std::uint16_t hist[16];
 };
 
 template<class Node, class Edge> struct graph_t {

@@ -105,6 +105,41 @@ __device__ __forceinline__ void fill_tables(params_t<real, Graph, NodeK, EdgeK, 
     }
 }
 
+// Row-batch layouts.  A lane's S register slots are consumed by its R row
+// batches in order; where a batch ends is either known at run time only
+// (`dynamic_layout`: a wave-uniform flush mask tested after every slot, the
+// finished sum parked in a lane-private LDS cell because the row registers
+// are indexed at compile time) or fixed at compile time (`seg_layout<L...>`:
+// batch k owns exactly L[k] slots, so the slot -> row-register binding is
+// static: no mask, no test, no branch, no LDS round trip of the row sums --
+// per CG iteration 2 scalar instructions per slot and 2 LDS operations + ~3
+// vector instructions per row less).  The host assigns a pair to a static
+// layout when the degree product of the first row of every batch k is at most
+// L[k] (HIPBackend.oc_trips); the degree products of molecular graphs fall
+// into a handful of such profiles: (16, 4, 4, 1) ... on the QM7-like set.
+struct dynamic_layout {
+    constexpr static bool is_static = false;
+};
+template<int... L> struct seg_layout {
+    constexpr static bool is_static = true;
+    constexpr static int R = sizeof...(L);
+    constexpr static int S = (L + ... + 0);
+    struct tables_t {
+        int end[R > 0 ? R : 1];           // one past the last slot of batch k
+        bool last[S > 0 ? S : 1];         // slot s closes its batch
+        constexpr tables_t() : end{}, last{} {
+            constexpr int len[R > 0 ? R : 1] = {L...};
+            int e = 0;
+            for (int k = 0; k < R; ++k) {
+                e += len[k];
+                end[k] = e;
+                if (len[k] > 0) last[e - 1] = true;
+            }
+        }
+    };
+    constexpr static tables_t T{};
+};
+
 // Kernel parameters of the nodal finite-difference gradient solver (NGRAD):
 // the common block plus the perturbed hyperparameter sets
 // state(theta_j e^{+eps}), state(theta_j e^{-eps}) of every node / edge
@@ -179,8 +214,10 @@ template<class real, int W> struct alternating_reduce {
     }
 };
 
-template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB, bool NGRAD, bool MAXIMIN, class Graph, class NodeK, class EdgeK, class PStart>
+template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB, bool NGRAD, bool MAXIMIN, class LAY, class Graph, class NodeK, class EdgeK, class PStart>
 struct oc_solver {
+    constexpr static bool STATIC = LAY::is_static;
+    static_assert(!STATIC || W == 1, "static row-batch layouts are one-wave layouts");
     static_assert(!MAXIMIN || (NODAL && C == 1), "the maximin epilogue works on the nodal solution of a value solve");
     using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
     using PF = std::conditional_t<NGRAD, params_fd_t<real, Graph, NodeK, EdgeK, PStart>, P>;
@@ -213,7 +250,18 @@ struct oc_solver {
 #define GD_OC_GCH 8
 #endif
     constexpr static int GCH = GD_OC_GCH;       // gathers in flight
-    constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4;
+    constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4 && !STATIC;
+    template<class L> constexpr static bool layout_matches() {
+        if constexpr (L::is_static) return L::S == S && L::R == R;
+        else return true;
+    }
+    static_assert(layout_matches<LAY>(), "the static layout must have S slots in R batches");
+    // does slot s close its row batch?  Static layouts: a compile-time constant
+    // once the slot loops are unrolled; dynamic: bit s of the flush mask
+    template<class M> __device__ static __forceinline__ bool flush_at(int s, M const &m) {
+        if constexpr (STATIC) return LAY::T.last[s];
+        else return (m[s / 32] >> (s % 32)) & 1u;
+    }
     // The graph-level value K = sum_i pp_i x_i, pp = p1 (x) p2, needs no x:
     // x = sum_k alpha_k p_k, so K = sum_k alpha_k (pp . p_k) is accumulated
     // per lane.  Saves the R solution registers (2 R in double) -- for the
@@ -230,6 +278,7 @@ struct oc_solver {
         real red[2][2 * W];     // two halves: see alternating_reduce
         int tab_off[NTAB];      // sorted-row offset of rectangle d1 * NC + d2
         int tab_cls[64];        // [0..NC) start1, [16..) cnt2, [32..) start2
+        unsigned mm_cell[4];    // MAXIMIN: distance bits, hotspot, mirrored hotspot
     };
 
     __device__ static __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -272,9 +321,10 @@ struct oc_solver {
         const int tid = (W == 1) ? lane : (int)threadIdx.x;
         const int wv = (W == 1) ? 0 : uni((int)(threadIdx.x / 64));
         // dynamic LDS: [p: u_capacity * C reals][Y: NR * C reals][rowmap: NR u32][G1][G2]
+        // (static layouts keep the row sums in registers: no Y region)
         real *const lp = dyn;
         real *const lY = lp + (size_t)prm.u_capacity * C;
-        unsigned *const rowmap = reinterpret_cast<unsigned *>(lY + (size_t)NR * C);
+        unsigned *const rowmap = reinterpret_cast<unsigned *>(lY + (STATIC ? (size_t)0 : (size_t)NR * C));
         char *const lG1 = reinterpret_cast<char *>(rowmap + NR);
         char *const lG2 = lG1 + prm.g_capacity;
         real *const red0 = lds.red[0], *const red1 = lds.red[1];
@@ -326,10 +376,12 @@ struct oc_solver {
                     }
                 }
                 // lane-private row sums: rows of batches that own no slots read 0
+                if constexpr (!STATIC) {
 #pragma unroll
-                for (int k = 0; k < R; ++k)
+                    for (int k = 0; k < R; ++k)
 #pragma unroll
-                    for (int c = 0; c < C; ++c) lY[(k * T + tid) * C + c] = 0;
+                        for (int c = 0; c < C; ++c) lY[(k * T + tid) * C + c] = 0;
+                }
             }
             const Graph g1(lG1 + cb1 - h1.degree, h1);
             const Graph g2(lG2 + cb2 - h2.degree, h2);
@@ -354,24 +406,13 @@ struct oc_solver {
             // ---- degree histograms -> offsets of the degree-pair rectangles ---
             // (every wave computes the same wave-uniform numbers)
             {
+                // (the packer leaves the degree histogram of every graph in its
+                // header: scalar registers, no ballots over the row pointers)
                 int cnt1[NC], cnt2[NC];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) cnt1[c] = cnt2[c] = 0;
-#pragma nounroll
-                for (int base = 0; base < n1; base += 64) {
-                    const int i = base + lane;
-                    const int d = i < n1 ? (int)lrp1[i + 1] - (int)lrp1[i] : -1;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-                        cnt1[c] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d == c));
-                }
-#pragma nounroll
-                for (int base = 0; base < n2; base += 64) {
-                    const int i = base + lane;
-                    const int d = i < n2 ? (int)lrp2[i + 1] - (int)lrp2[i] : -1;
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-                        cnt2[c] += __builtin_popcountll(__builtin_amdgcn_ballot_w64(d == c));
+                for (int c = 0; c < NC; ++c) {
+                    cnt1[c] = (int)h1.hist[c];
+                    cnt2[c] = (int)h2.hist[c];
                 }
                 // nodes are stored by descending degree: class d starts after
                 // all classes of higher degree
@@ -453,12 +494,21 @@ struct oc_solver {
 
             // ---- nonzero slots owned by this thread ---------------------------
             real val[S];
-            unsigned adr[S];   // gather index into p (two-pass setup: first (a << 16) | b, or ~0u)
+            unsigned adr[S];   // LDS byte address of the gathered element of p (two-pass setup: first (a << 16) | b, or ~0u)
+            const unsigned lp_off = lds_offset(lp);
+            constexpr unsigned ELEM = C * sizeof(real);
             unsigned fm[NM];
 #pragma unroll
             for (int w = 0; w < NM; ++w) fm[w] = 0;
             int n_slots = 0;
             {
+                if constexpr (STATIC) {
+                    // batch k is live if it has rows: its slots end at a
+                    // compile-time position
+#pragma unroll
+                    for (int k = 0; k < R; ++k)
+                        if (k * T < N) n_slots = LAY::T.end[k];
+                } else {
                 // pass 0 (wave-uniform): trip count of every row batch of this
                 // wave = degree product of its first row -> flush mask
 #pragma unroll
@@ -479,6 +529,7 @@ struct oc_solver {
                     }
                 }
                 n_slots = n_slots > S ? S : n_slots;
+                }
                 if constexpr (ONE_PASS) {
                     // one unrolled pass over the slots (walk_t above)
                     int kb = 0;
@@ -503,6 +554,7 @@ struct oc_solver {
                         }
                         val[s] = ok ? e : real(0);
                         unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
+                        col = lp_off + col * ELEM;
 #if GD_OC_PIN
                         asm volatile("" : "+v"(val[s]), "+v"(col));
 #endif
@@ -514,7 +566,7 @@ struct oc_solver {
                         }
 #endif
                         cur.next();
-                        if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform: next row batch
+                        if (flush_at(s, fm) && s != S - 1) {   // wave-uniform: next row batch
                             ++kb;
                             cur = open_walk(kb);
                         }
@@ -561,6 +613,7 @@ struct oc_solver {
                         }
                         val[s] = ok ? e : real(0);
                         unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
+                        col = lp_off + col * ELEM;
                         asm volatile("" : "+v"(val[s]), "+v"(col));
                         adr[s] = col;
                     }
@@ -621,6 +674,13 @@ struct oc_solver {
                 job_sync<W>();   // p published
                 // row sums: sum over the slots of a batch, flushed to the
                 // lane-private cell Y[batch][lane] at wave-uniform positions
+                [[maybe_unused]] real ys[C][STATIC ? R : 1];   // static layouts: the row sums
+                if constexpr (STATIC) {
+#pragma unroll
+                    for (int k = 0; k < R; ++k)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) ys[c][k] = 0;
+                }
                 {
                     real acc[C];
 #pragma unroll
@@ -641,7 +701,7 @@ struct oc_solver {
                             real e[C];
 #pragma unroll
                             for (int c = 0; c < C; ++c) e[c] = 0;
-                            if (s0 + jj < S) load_elem<C>(lp, adr[s0 + jj], e);
+                            if (s0 + jj < S) load_elem_at<C>(adr[s0 + jj], e);
 #pragma unroll
                             for (int c = 0; c < C; ++c) g[c][jj] = e[c];
                         }
@@ -651,8 +711,14 @@ struct oc_solver {
                             if (s < S) {
 #pragma unroll
                                 for (int c = 0; c < C; ++c) acc[c] += val[s] * g[c][jj];
-                                if ((fmv[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
-                                    if constexpr (ADDTID) {
+                                if (flush_at(s, fmv)) {   // wave-uniform
+                                    if constexpr (STATIC) {
+#pragma unroll
+                                        for (int c = 0; c < C; ++c) {
+                                            ys[c][kb] = acc[c];
+                                            acc[c] = 0;
+                                        }
+                                    } else if constexpr (ADDTID) {
                                         store_lane_contiguous<0>(lY_off + kb * (T * 4), (float)acc[0]);
                                         acc[0] = 0;
                                     } else {
@@ -673,7 +739,12 @@ struct oc_solver {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     real y[C];
-                    load_elem<C>(lY, k * T + tid, y);
+                    if constexpr (STATIC) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) y[c] = ys[c][k];
+                    } else {
+                        load_elem<C>(lY, k * T + tid, y);
+                    }
 #pragma unroll
                     for (int c = 0; c < C; ++c) {
                         Ap[c][k] = dg[k] * p[c][k] - y[c];
@@ -776,9 +847,13 @@ struct oc_solver {
             [[maybe_unused]] unsigned mm_n1 = 0, mm_n2 = 0;   // node offsets of the graphs
             [[maybe_unused]] unsigned mm_hot = 0;             // flat index of the hotspot
             if constexpr (MAXIMIN) {
-                unsigned *const dmin1 = reinterpret_cast<unsigned *>(lY);
+                // row / column minima in the region of p (dead between the solve
+                // and the re-solves; n1 + n2 <= n1 (n2 | 1) + 1 <= u_capacity words
+                // for every n1, n2 >= 1 -- the row-sum region holds NR words in
+                // float, one short of a 1 x NR pair), the three cells static
+                unsigned *const dmin1 = reinterpret_cast<unsigned *>(lp);
                 unsigned *const dmin2 = dmin1 + n1;
-                unsigned *const cell = dmin2 + n2;      // [0] D bits, [1] hotspot, [2] mirrored hotspot
+                unsigned *const cell = lds.mm_cell;     // [0] D bits, [1] hotspot, [2] mirrored hotspot
                 const unsigned NS1 = prm.node_starts[job.i], NS2 = prm.node_starts[job.j];
                 mm_n1 = NS1;
                 mm_n2 = NS2;
@@ -847,7 +922,7 @@ struct oc_solver {
                         mm_rs = graphdot::rsqrt(mm_k1 * mm_k2);
                     }
                 }
-                job_sync<W>();   // lY is the row-sum scratch again below
+                job_sync<W>();   // the region of p is published to again below
             }
             if (!NODAL || !(flags & F_NODAL)) {
                 job_sync<W>();   // (the loop may have left through either half)
@@ -938,28 +1013,35 @@ struct oc_solver {
                 auto matvec = [&](real (&y)[R]) {
                     real acc = 0;
                     int kb = 0;
+                    if constexpr (STATIC) {
+#pragma unroll
+                        for (int k = 0; k < R; ++k) y[k] = 0;
+                    }
 #pragma unroll
                     for (int s0 = 0; s0 < S; s0 += GCH) {
                         if (s0 >= n_slots) break;
                         real g[GCH];
 #pragma unroll
                         for (int jj = 0; jj < GCH; ++jj)
-                            g[jj] = (s0 + jj < S) ? lp[adr[s0 + jj < S ? s0 + jj : 0]] : real(0);
+                            g[jj] = (s0 + jj < S) ? load_real_at<real>(adr[s0 + jj < S ? s0 + jj : 0]) : real(0);
 #pragma unroll
                         for (int jj = 0; jj < GCH; ++jj) {
                             const int s = s0 + jj;
                             if (s < S) {
                                 acc += val[s] * g[jj];
-                                if ((fm[s / 32] >> (s % 32)) & 1u) {
-                                    lY[kb * T + tid] = acc;
+                                if (flush_at(s, fm)) {
+                                    if constexpr (STATIC) y[kb] = acc;
+                                    else lY[kb * T + tid] = acc;
                                     acc = 0;
                                     ++kb;
                                 }
                             }
                         }
                     }
+                    if constexpr (!STATIC) {
 #pragma unroll
-                    for (int k = 0; k < R; ++k) y[k] = lY[k * T + tid];
+                        for (int k = 0; k < R; ++k) y[k] = lY[k * T + tid];
+                    }
                 };
                 auto publish1 = [&](real const (&v)[R]) {
 #pragma unroll
@@ -1000,7 +1082,7 @@ struct oc_solver {
                                 jb = 0;
                                 ++ja;
                             }
-                            if ((fm[s / 32] >> (s % 32)) & 1u) {
+                            if (flush_at(s, fm) && s != S - 1) {
                                 ++kb;
                                 j = ja = jb = 0;
                                 cur = open_row(kb);
@@ -1136,7 +1218,7 @@ struct oc_solver {
                         if (s < n_slots) {   // wave-uniform
                             const bool ok = cur.valid();
                             const unsigned a = cur.a(), b = cur.e2;
-                            real w = ok ? yrow * lp[adr[s] * 2 + 0] : real(0);
+                            real w = ok ? yrow * load_real_at<real>(adr[s]) : real(0);
                             if constexpr (TAB) {
                                 const unsigned cidx = __umul24((unsigned)ecls1[a], nec) + ecls2[b];
                                 if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
@@ -1152,7 +1234,7 @@ struct oc_solver {
                                 for (int jj = 0; jj < EdgeK::jac_dims; ++jj) jac[off_e + jj] += w * real(de[jj]);
                             }
                             cur.next();
-                            if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
+                            if (flush_at(s, fm) && s != S - 1) {   // wave-uniform
                                 ++kb;
                                 cur = open_walk(kb);
                                 yrow = lp[cur.row * 2 + 1];

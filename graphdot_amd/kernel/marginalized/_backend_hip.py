@@ -35,7 +35,15 @@ F_NODAL, F_DIAGONAL, F_SYMMETRIC, F_LMIN1, F_BLOCK, F_PACKED = \
 Variant = namedtuple('Variant', 'W S R')
 #: owner-computes solver (csrc/device/mgk_oc.h): S nonzero slots and R rows
 #: per lane, for pairs of graphs whose largest degree is at most D
-OCVariant = namedtuple('OCVariant', 'W S R D')
+#: L: None, or the static row-batch layout (seg_layout<L...> in mgk_oc.h):
+#: batch k of a lane owns exactly L[k] slots, S = sum(L), R = len(L)
+OCVariant = namedtuple('OCVariant', 'W S R D L', defaults=(None,))
+
+
+def OCStatic(*L, D=4):
+    """One-wave owner-computes variant with the static layout L."""
+    return OCVariant(1, int(sum(L)), len(L), D, tuple(int(x) for x in L))
+
 
 #: register-resident solver menu, cheapest first.  A pair fits a variant if
 #: its stage-1 walk needs <= S slots per lane and N = n1*n2 <= 64*W*R.
@@ -52,7 +60,19 @@ VARIANTS = [
 #: Strogatz graphs of configuration 2: 4..7) the D = 8 kernels with 1, 4, 8
 #: or 16 waves per pair.  S <= 64: larger slot arrays are not promoted to
 #: registers by the compiler (they would live in scratch memory).
-OC_VARIANTS = [
+#: Static layouts first: a pair whose per-batch degree products fit one takes
+#: it (no flush tests, row sums in registers); the dynamic variants behind
+#: them take what is left.  The layouts are the profiles of molecular graphs
+#: (degrees <= 4: the first batch holds the 16-term rows of two four-valent
+#: atoms, then 4 = 2 x 2 / 4 x 1, then hydrogens): on the QM7-like set 66
+#: distinct profiles, all under one of these.
+OC_STATIC_VARIANTS = [
+    OCStatic(16), OCStatic(16, 4), OCStatic(16, 4, 1), OCStatic(16, 4, 4),
+    OCStatic(16, 4, 4, 1), OCStatic(16, 4, 4, 1, 1), OCStatic(16, 4, 4, 3, 1),
+    OCStatic(16, 4, 4, 3, 1, 1), OCStatic(16, 4, 4, 4, 1, 1, 1),
+    OCStatic(16, 4, 4, 4, 3, 1, 1, 1), OCStatic(16, 4, 4, 4, 4, 1, 1, 1, 1),
+]
+OC_VARIANTS = OC_STATIC_VARIANTS + [
     OCVariant(1, 12, 2, 4), OCVariant(1, 16, 3, 4), OCVariant(1, 20, 3, 4),
     OCVariant(1, 20, 4, 4), OCVariant(1, 24, 4, 4), OCVariant(1, 28, 5, 4),
     OCVariant(1, 28, 6, 4), OCVariant(1, 32, 7, 4), OCVariant(1, 36, 9, 4),
@@ -335,8 +355,13 @@ class HIPBackend(Backend):
         if os.environ.get('GD_OC') == '0':        # experiments: two-stage only
             self.variants = [v for v in self.variants
                              if not isinstance(v, OCVariant)]
-        if os.environ.get('GD_VARIANTS'):     # experiments: "W:S:R[:D],..."
+        if os.environ.get('GD_OC_STATIC') == '0':  # experiments: dynamic only
+            self.variants = [v for v in self.variants
+                             if not (isinstance(v, OCVariant) and v.L)]
+        if os.environ.get('GD_VARIANTS'):  # experiments: "W:S:R[:D],L16x4x1,..."
             def parse(item):
+                if item.startswith('L'):
+                    return OCStatic(*map(int, item[1:].split('x')))
                 f = list(map(int, item.split(':')))
                 return OCVariant(*f) if len(f) == 4 else Variant(*f)
             self.variants = [parse(item) for item in
@@ -607,6 +632,7 @@ struct ${name}_t : ${name}_theta_t {
             return f'mgk_{f}_tables_C{C}'
         if isinstance(v, OCVariant):
             return f'mgk_{f}_oc{v.D}_W{v.W}_S{v.S}_R{v.R}_C{C}' + \
+                ('_L' + 'x'.join(map(str, v.L)) if v.L else '') + \
                 ('_nodal' if nodal else '') + ('_tab' if tab else '') + \
                 ('_ngrad' if ngrad else '') + ('_maximin' if maximin else '')
         return f'mgk_{f}_W{v.W}_S{v.S}_R{v.R}_C{C}' + \
@@ -699,7 +725,8 @@ struct ${name}_t : ${name}_theta_t {
         the publish address), the gathers in flight and ~24 others; a double
         takes two registers."""
         f64 = np.dtype(self.real) == np.float64
-        hit = self._OC_WAVES.get((f64, C), {}).get(tuple(v))
+        hit = self._OC_WAVES.get((f64, C), {}).get(
+            v.L if v.L else tuple(v)[:4])
         if hit and not ngrad:
             return hit
         w = 2 if f64 else 1
@@ -725,8 +752,8 @@ extern "C" __global__ __launch_bounds__(${threads})
 __attribute__((amdgpu_waves_per_eu(${waves})))
 void ${name}(${params} prm) {
     using solver = graphdot::mgk::oc_solver<real_t, ${S}, ${R}, ${W}, ${C},
-        ${nodal}, ${D}, ${tab}, ${ngrad}, ${maximin}, graph_t, node_kernel_t,
-        edge_kernel_t, p_start_t>;
+        ${nodal}, ${D}, ${tab}, ${ngrad}, ${maximin}, ${layout}, graph_t,
+        node_kernel_t, edge_kernel_t, p_start_t>;
     __shared__ typename solver::lds_t lds;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     solver::run(prm, lds, reinterpret_cast<real_t *>(dyn_lds));
@@ -734,6 +761,8 @@ void ${name}(${params} prm) {
 ''').render(threads=64 * v.W,
             name=self.kernel_name(v, C, nodal, tab, ngrad, maximin),
             maximin='true' if maximin else 'false',
+            layout=('graphdot::mgk::seg_layout<%s>' % ', '.join(map(str, v.L))
+                    if v.L else 'graphdot::mgk::dynamic_layout'),
             S=v.S, R=v.R, W=v.W, C=C, D=v.D,
             waves=self._oc_waves(v, C, ngrad) if ngrad
             else self.waves_per_eu(v, C),
@@ -810,8 +839,12 @@ void ${name}(params_t prm) {
             rs = np.dtype(self.real).itemsize
             NR = 64 * v.W * v.R
             pcap = -(-(np.asarray(ntask) + 1) // 4) * 4
-            return (pcap + NR) * C * rs + 4 * NR + 2 * np.asarray(gbytes) \
-                + 2 * v.W * rs + 4 * (128 if v.D > 6 else 64) + 256
+            if v.L:                 # row sums in registers: no Y region
+                NR_y = 0
+            else:
+                NR_y = NR
+            return (pcap + NR_y) * C * rs + 4 * NR + 2 * np.asarray(gbytes) \
+                + 4 * v.W * rs + 4 * (128 if v.D > 6 else 64) + 256 + 16
         wpb = WPB1 if v.W == 1 else 1
         T = 64 * v.W
         ucap = -(-np.asarray(ntask) // 64) * 64 + 64
@@ -842,6 +875,27 @@ void ${name}(params_t prm) {
                 total += np.where(live, d, 0)
             worst = np.maximum(worst, total)
         return worst
+
+    @staticmethod
+    def oc_trips(hist1, hist2, D, nb):
+        """Per-batch trip counts of the one-wave owner-computes walk: entry
+        [t, k] is the degree product of the first row of batch k (rows
+        64 k ...) of job t in the sorted row order, 0 for batches without
+        rows.  A static layout L fits job t iff trips[t, k] <= L[k] for all
+        k < len(L) and the job has no rows beyond 64 len(L)."""
+        order = sorted(((a, b) for a in range(D + 1) for b in range(D + 1)),
+                       key=lambda t: -t[0] * t[1])
+        prods = np.array([a * b for a, b in order] + [0], dtype=np.int64)
+        sizes = hist1[:, [a for a, _ in order]] * hist2[:, [b for _, b in order]]
+        cum = np.cumsum(sizes, axis=1)                   # (n, ncp)
+        n = len(cum)
+        if n == 0:
+            return np.zeros((0, nb), dtype=np.int64)
+        first = 64 * np.arange(nb, dtype=np.int64)
+        # rectangle of row `first`: number of cumulative sizes <= first
+        c = (cum[:, None, :] <= first[None, :, None]).sum(axis=2)
+        live = first[None, :] < cum[:, -1:]
+        return np.where(live, prods[np.minimum(c, len(order))], 0)
 
     @staticmethod
     def oc_slots_needed(hist1, hist2, W, D):
@@ -924,6 +978,34 @@ void ${name}(params_t prm) {
         pos[upk] = np.arange(len(upk), dtype=np.int32)
         return pos[pk], out
 
+    #: row batches the trip tables cover (static layouts have at most this many)
+    TRIP_BATCHES = 12
+
+    def _degree_hists(self, dgraphs, maxdeg, D, hists):
+        """(distinct degree histograms H, id of every graph's) for the graphs
+        of largest degree <= D (others: a zero row)."""
+        if D not in hists:
+            h = np.zeros((len(dgraphs), D + 1), dtype=np.int64)
+            for g_, dg_ in enumerate(dgraphs):
+                if maxdeg[g_] <= D:
+                    h[g_] = np.bincount(dg_.adjacency_count, minlength=D + 1)
+            H, hid = np.unique(h, axis=0, return_inverse=True)
+            hists[D] = (H, hid.reshape(-1))
+        return hists[D]
+
+    def _trip_table(self, ji, jj, dgraphs, maxdeg, pair_maxdeg, D, hists):
+        """(trips per distinct histogram pair in use, row of every job in
+        that table or -1 if a graph of the job exceeds degree D)."""
+        H, hid = self._degree_hists(dgraphs, maxdeg, D, hists)
+        nH = len(H)
+        row = np.full(len(ji), -1, dtype=np.int64)
+        idx = np.flatnonzero(pair_maxdeg <= D)
+        pk = hid[ji[idx]] * nH + hid[jj[idx]]
+        upk, inv = np.unique(pk, return_inverse=True)
+        row[idx] = inv.reshape(-1)
+        tr = self.oc_trips(H[upk // nH], H[upk % nH], D, self.TRIP_BATCHES)
+        return tr, row
+
     def _classify_pairs(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
                         oc_only=False):
         n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
@@ -951,7 +1033,7 @@ void ${name}(params_t prm) {
         gbytes_oc = np.maximum(image_oc[ji], image_oc[jj])
         maxdeg = np.array([g.max_degree for g in dgraphs], dtype=np.int64)
         pair_maxdeg = np.maximum(maxdeg[ji], maxdeg[jj])
-        oc_slots, hists = {}, {}
+        oc_slots, hists, trips = {}, {}, {}
         # `rem`: the jobs without a variant yet -- every test below runs on
         # that shrinking subset only (most jobs leave in the first variants)
         rem = np.arange(len(ji))
@@ -969,19 +1051,27 @@ void ${name}(params_t prm) {
                     continue
                 fits &= self.lds_bytes(v, C, NP[rem], gbytes_oc[rem]) \
                     <= LDS_LIMIT
+                if v.L:
+                    # static layout: the trip count of every batch under its
+                    # segment (looked up per pair of distinct histograms)
+                    if v.D not in trips:
+                        trips[v.D] = self._trip_table(
+                            ji, jj, dgraphs, maxdeg, pair_maxdeg, v.D, hists)
+                    tr, row = trips[v.D]
+                    idx = rem[fits]
+                    ok = row[idx] >= 0
+                    L = np.zeros(tr.shape[1], dtype=np.int64)
+                    L[:v.R] = v.L
+                    ok[ok] = (tr[row[idx[ok]]] <= L[None, :]).all(axis=1)
+                    choice[idx[ok]] = k
+                    fits[fits] = ok
+                    rem = rem[~fits]
+                    continue
                 if (v.W, v.D) not in oc_slots:
-                    if v.D not in hists:
-                        h = np.zeros((len(dgraphs), v.D + 1), dtype=np.int64)
-                        for g_, dg_ in enumerate(dgraphs):
-                            if maxdeg[g_] <= v.D:
-                                h[g_] = np.bincount(dg_.adjacency_count,
-                                                    minlength=v.D + 1)
-                        # the walk depends on the two degree histograms only,
-                        # and a set of graphs has few distinct ones: it is
-                        # evaluated once per pair of distinct histograms
-                        hists[v.D] = np.unique(h, axis=0, return_inverse=True)
-                    H, hid = hists[v.D]
-                    hid = hid.reshape(-1)
+                    # the walk depends on the two degree histograms only,
+                    # and a set of graphs has few distinct ones: it is
+                    # evaluated once per pair of distinct histograms
+                    H, hid = self._degree_hists(dgraphs, maxdeg, v.D, hists)
                     idx = rem[pair_maxdeg[rem] <= v.D]
                     pk = hid[ji[idx]] * len(H) + hid[jj[idx]]
                     seen = np.zeros(len(H) * len(H), dtype=bool)
@@ -1104,8 +1194,16 @@ void ${name}(params_t prm) {
                     continue
                 for k2 in used_[a_ + 1:]:
                     v2 = self.variants[k2]
-                    if (isinstance(v2, OCVariant) and v2.W == v.W
+                    if not (isinstance(v2, OCVariant) and v2.W == v.W
                             and v2.D == v.D and v2.S >= v.S and v2.R >= v.R):
+                        continue
+                    # a static layout takes the jobs of another static layout
+                    # it dominates batch by batch (never those of a dynamic
+                    # variant); a dynamic variant takes any total <= S
+                    if v2.L and not (v.L and all(
+                            a <= b for a, b in zip(v.L, v2.L))):
+                        continue
+                    if True:
                         choice = np.where(here, k2, choice)
                         break
         rank_of = np.empty(len(choice), dtype=np.int64)
@@ -1149,7 +1247,8 @@ void ${name}(params_t prm) {
                 pcap = int(-(-(NP[idx].max() + 1) // 4) * 4)
                 gcap = int(-(-gbytes_oc[idx].max() // 16) * 16)
                 NR = 64 * v.W * v.R
-                dyn = (pcap + NR) * C * rsize + 4 * NR + 2 * gcap
+                dyn = (pcap + (0 if v.L else NR)) * C * rsize + 4 * NR \
+                    + 2 * gcap
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=pcap, gcap=gcap,
                     dynamic_lds=dyn, count=count,

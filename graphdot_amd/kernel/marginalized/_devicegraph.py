@@ -31,13 +31,23 @@ from ...codegen.typetool import common_min_type, is_scalar_type
 
 _ALIGN = 16
 
-#: device-side header, mirrors graphdot::graph_header_t (32 bytes); the
-#: section fields are byte offsets from the arena base
+#: device-side header, mirrors graphdot::graph_header_t (64 bytes); the
+#: section fields are byte offsets from the arena base, `hist[d]` counts the
+#: nodes with d adjacency nonzeros (hist[15]: 15 or more)
 HEADER_DTYPE = np.dtype([
     ('n_node', np.int32), ('n_nz', np.int32), ('degree', np.uint32),
     ('node', np.uint32), ('rowptr', np.uint32), ('nz', np.uint32),
-    ('edge', np.uint32), ('perm', np.uint32)], align=True)
-assert HEADER_DTYPE.itemsize == 32
+    ('edge', np.uint32), ('perm', np.uint32), ('hist', np.uint16, (16,))],
+    align=True)
+assert HEADER_DTYPE.itemsize == 64
+HIST_BINS = 16
+
+
+def degree_histogram(adjacency_count):
+    """hist field of the header: nodes per adjacency count, the last bin
+    open-ended."""
+    c = np.minimum(np.asarray(adjacency_count, dtype=np.int64), HIST_BINS - 1)
+    return np.bincount(c, minlength=HIST_BINS).astype(np.uint16)
 SECTIONS = ('degree', 'node', 'rowptr', 'nz', 'edge', 'perm')
 
 NZ_DTYPE = np.dtype([('i', np.uint16), ('j', np.uint16)])
@@ -637,6 +647,7 @@ class GraphArena:
                 self.host[c1:c1 + g.n_nz] = ecls[k]
             hdr['n_node'][k] = g.n_node
             hdr['n_nz'][k] = g.n_nz
+            hdr['hist'][k] = degree_histogram(g.adjacency_count)
             for name in SECTIONS:
                 hdr[name][k] = s + g.offsets[name]   # arena-relative for now
             if len(g.relocs):

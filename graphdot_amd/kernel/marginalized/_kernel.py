@@ -252,10 +252,6 @@ class MarginalizedGraphKernel:
         backend = self.backend
         if not hasattr(backend, 'prepare'):
             raise TypeError('device_gram needs the HIP backend')
-        if getattr(backend, 'shards_over_ranks', lambda: False)():
-            # the sharded evaluation ends in host arrays on every rank
-            raise TypeError('device_gram is a single-GPU path; the '
-                            'distributed backend goes through __call__')
         pred = Graph.has_unified_types(X)
         if pred is not True:
             raise _type_error(
@@ -264,13 +260,30 @@ class MarginalizedGraphKernel:
         nx = len(X)
         traits = self.traits(symmetric=True, lmin=lmin,
                              eval_gradient=eval_gradient)
+        real = np.dtype(backend.real)
+        if getattr(backend, 'shards_over_ranks', lambda: False)():
+            # pair-sharded over the ranks: the all-gathered, reassembled
+            # matrix (and gradient planes) of `ShardedStep` stay on this
+            # rank's device -- every rank holds the full result, like the
+            # single-GPU path, and nothing goes through host memory
+            step = backend.sharded_step(
+                X, self.node_kernel, self.edge_kernel, self.p, self.q,
+                self.eps, self.ftol, self.gtol, self._pairwise_jobs(nx),
+                np.arange(nx + 1, dtype=np.uint32), nx, nx, self.n_dims,
+                traits)
+            base = step.result.data_ptr()
+            K = DeviceArray.fortran(base, (nx, nx), real, owner=step)
+            if not eval_gradient:
+                return K
+            dK = DeviceArray.fortran(base + nx * nx * real.itemsize,
+                                     (nx, nx, self.n_dims), real, owner=step)
+            return K, dK
         plan = backend.prepare(
             X, self.node_kernel, self.edge_kernel, self.p, self.q, self.eps,
             self.ftol, self.gtol, self._pairwise_jobs(nx),
             np.arange(nx + 1, dtype=np.uint32), nx, nx, self.n_dims, traits)
         backend.launch(plan)
         backend.synchronize()
-        real = np.dtype(backend.real)
         K = DeviceArray.fortran(plan.buffers['gramian'].ptr, (nx, nx), real,
                                 owner=plan)
         if not eval_gradient:

@@ -13,6 +13,7 @@ the shard (the HIP plan on a GPU, the oracle in the CPU tests) and
 ``all_gather(local)`` is ``torch.distributed.all_gather_into_tensor`` over RCCL
 (backend "nccl") on GPUs or gloo on CPU.
 """
+import json
 import os
 import numpy as np
 
@@ -20,6 +21,135 @@ import numpy as np
 def predict_cost(n_node, n_nz, ji, jj):
     """Relative cost of a pair: product-graph nonzeros plus vector work."""
     return n_nz[ji] * n_nz[jj] + 4 * n_node[ji] * n_node[jj]
+
+
+# --------------------------------------------------------------------------
+# measured cost model: time per pair by solver variant
+# --------------------------------------------------------------------------
+_COST_TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                'cost_table.json')
+_cost_table = None
+
+
+def cost_table(path=None, reload=False):
+    """{'f64/C1/oc4_W1_S25_R4_L16x4x4x1': [a_ns, b_ns], ..., 'tail_us': t}:
+    the time a pair adds to a launch of its solver variant on MI355X,
+    ``a + b (nnz1 nnz2 + 4 n1 n2)`` nanoseconds (throughput time: chip-wide
+    launch duration / pairs), fitted by scripts/calibrate_cost.py from timed
+    slices of the launches of the QM7-like benchmark set.  The time per pair
+    steps with the solver variant (registers -> waves per SIMD), which is why
+    one arithmetic-only weight for all pairs misses by up to 57 %
+    (scripts/fit_cost_model.py)."""
+    global _cost_table
+    if path is not None:
+        with open(path) as f:
+            return json.load(f)
+    if _cost_table is None or reload:
+        try:
+            with open(os.environ.get('GD_COST_TABLE', _COST_TABLE_PATH)) as f:
+                _cost_table = json.load(f)
+        except OSError:
+            _cost_table = {}
+    return _cost_table
+
+
+def variant_key(v):
+    """Name of a solver variant in the cost table."""
+    if getattr(v, 'L', None):
+        return f'oc{v.D}_W{v.W}_S{v.S}_R{v.R}_L' + 'x'.join(map(str, v.L))
+    if hasattr(v, 'D'):
+        return f'oc{v.D}_W{v.W}_S{v.S}_R{v.R}'
+    return f'W{v.W}_S{v.S}_R{v.R}'
+
+
+def job_times(variants, choice, arith, real, C, table=None):
+    """Predicted nanoseconds per job: the table entry of its variant, or --
+    for a variant that was never calibrated -- the arithmetic model scaled to
+    the mean of the calibrated ones."""
+    table = cost_table() if table is None else table
+    f = 'f64' if np.dtype(real) == np.float64 else 'f32'
+    arith = np.asarray(arith, dtype=np.float64)
+    t = np.zeros(len(arith))
+    known = [v for k, v in table.items()
+             if k.startswith(f'{f}/C{C}/') and isinstance(v, list)]
+    # fallback slope: ns per unit of arithmetic, mean over calibrated variants
+    ref = table.get(f'{f}/C{C}/mean_ns_per_arith')
+    if ref is None:
+        ref = float(np.mean([b for _, b in known])) if known else 1.0
+        if ref <= 0:
+            ref = 1.0
+    for k in np.unique(choice):
+        sel = choice == k
+        ab = table.get(f'{f}/C{C}/{variant_key(variants[k])}')
+        if ab is None:
+            t[sel] = ref * arith[sel] * (1.0 + 0.02 * getattr(
+                variants[k], 'S', 0))
+        else:
+            t[sel] = ab[0] + ab[1] * arith[sel]
+    return t
+
+
+def partition_blocks(times, group, world_size, tail=0.0, snap=0):
+    """Cut a job list that is already in launch order (by solver variant
+    `group`, then descending cost) into `world_size` contiguous blocks whose
+    predicted times -- the jobs' times plus `tail` per variant a block touches
+    (every launch ends in a tail during which the chip drains) -- have the
+    smallest possible maximum.  A rank then holds 1-3 variants, i.e. 1-3 large
+    launches, instead of a sliver of every variant.  Cuts within `snap` jobs of
+    a variant boundary move onto it (no launch of a few hundred pairs).
+    Returns the list of index ranges (start, stop)."""
+    n = len(times)
+    if n == 0:
+        return [(0, 0)] * world_size
+    c = np.concatenate(([0.0], np.cumsum(times, dtype=np.float64)))
+    gstart = np.flatnonzero(np.concatenate(([True], group[1:] != group[:-1])))
+    bounds = np.concatenate((gstart, [n]))
+
+    def fill(T):
+        """greedy: longest prefix of predicted time <= T per rank"""
+        cuts, a = [], 0
+        for _ in range(world_size):
+            if a >= n:
+                cuts.append((a, a))
+                continue
+            lo, hi = a + 1, n
+            # time of [a, e) = c[e] - c[a] + tail * (variants touched)
+            def cost(e):
+                nv = np.searchsorted(gstart, e - 1, side='right') \
+                    - np.searchsorted(gstart, a, side='right') + 1
+                return c[e] - c[a] + tail * nv
+            if cost(lo) > T:
+                return None
+            while lo < hi:
+                mid = (lo + hi + 1) // 2
+                if cost(mid) <= T:
+                    lo = mid
+                else:
+                    hi = mid - 1
+            cuts.append((a, lo))
+            a = lo
+        return cuts if a >= n else None
+
+    lo_T, hi_T = c[-1] / world_size, c[-1] + tail * len(bounds)
+    for _ in range(60):
+        mid = 0.5 * (lo_T + hi_T)
+        if fill(mid) is None:
+            lo_T = mid
+        else:
+            hi_T = mid
+    cuts = fill(hi_T)
+    if snap > 0:
+        out, a = [], 0
+        for r, (_, e) in enumerate(cuts):
+            if r < world_size - 1 and a < e < n:
+                k = int(np.argmin(np.abs(bounds - e)))
+                if abs(int(bounds[k]) - e) <= snap and bounds[k] > a:
+                    e = int(bounds[k])
+            e = max(e, a)
+            out.append((a, e if r < world_size - 1 else n))
+            a = out[-1][1]
+        cuts = out
+    return cuts
 
 
 def partition(cost, world_size, mode=None):
@@ -49,13 +179,32 @@ class ShardPlan:
     """Static description of one rank's share and of the reassembly."""
 
     def __init__(self, ji, jj, n_node, n_nz, nX, nY, symmetric, rank,
-                 world_size):
+                 world_size, launch_order=None, times=None, group=None,
+                 tail=0.0, snap=2048, mode=None):
+        """`launch_order`, `times`, `group` (optional): the job ids in the
+        backend's launch order (by solver variant, then descending cost), the
+        predicted time of every job (`job_times`) and its solver variant --
+        the shards are then contiguous blocks of that order with equal
+        predicted time (`partition_blocks`); without them jobs are dealt in
+        snake order by the arithmetic cost."""
         self.rank, self.world_size = rank, world_size
         self.ji, self.jj = np.asarray(ji), np.asarray(jj)
         self.nX, self.nY, self.symmetric = nX, nY, symmetric
         cost = predict_cost(np.asarray(n_node), np.asarray(n_nz),
                             self.ji, self.jj)
-        self.shards = partition(cost, world_size)
+        mode = mode or os.environ.get('GD_SHARD_MODE')
+        self.mode = 'snake'
+        if launch_order is not None and mode in (None, 'measured'):
+            lo = np.asarray(launch_order, dtype=np.int64)
+            cuts = partition_blocks(np.asarray(times)[lo],
+                                    np.asarray(group)[lo], world_size, tail,
+                                    snap)
+            self.shards = [lo[a:b] for a, b in cuts]
+            self.predicted = [float(np.asarray(times)[s].sum())
+                              for s in self.shards]
+            self.mode = 'measured'
+        else:
+            self.shards = partition(cost, world_size, mode)
         self.capacity = max(len(s) for s in self.shards) if len(cost) else 0
         self.local = self.shards[rank]
         # position of every job in the gathered [world_size, capacity] slab
@@ -123,6 +272,40 @@ class ShardPlan:
             out[mdst] = g[msrc]
         out = out.reshape(self.nY, self.nX, n_cols).transpose(1, 0, 2)
         return out[:, :, 0] if n_cols == 1 else out
+
+
+def measured_shard_plan(backend, graphs, node_kernel, edge_kernel, jobs, nX,
+                        nY, traits, rank, world):
+    """The ShardPlan of a job list on `backend`: the whole list is laid out
+    as one rank would launch it (solver variant per job, launch order:
+    HIPBackend._partition), every job gets the measured time of its variant
+    (`cost_table`), and the ranks take contiguous blocks of that order with
+    equal predicted time.  Host only and deterministic: every rank computes
+    the same plan."""
+    dgraphs, edge_kernel, C, fields = backend._graphs_and_kernels(
+        graphs, node_kernel, edge_kernel, traits)
+    arena = backend._arena(dgraphs, fields)[0]       # (cached per backend)
+    tab_bytes = backend._table_bytes(arena)
+    gtab = backend._global_tables(arena)
+    jobs = np.ascontiguousarray(jobs)
+    _, used, order_all, launches = backend._partition(
+        dgraphs, jobs, C, tab_bytes, gtab)
+    ji, jj = jobs['i'].astype(np.int64), jobs['j'].astype(np.int64)
+    n_node = np.array([g.n_node for g in dgraphs], np.int64)
+    n_nz = np.array([g.n_nz for g in dgraphs], np.int64)
+    group = np.zeros(len(jobs), dtype=np.int64)
+    for L in launches:
+        group[order_all[L['offset']:L['offset'] + L['count']]] = L['k']
+    table = cost_table()
+    times = job_times(backend.variants, group, predict_cost(
+        n_node, n_nz, ji, jj), backend.real, C, table)
+    f = 'f64' if np.dtype(backend.real) == np.float64 else 'f32'
+    tail = 1e3 * float(table.get(f'{f}/C{C}/tail_us',
+                                 table.get('tail_us', 12.0)))
+    return ShardPlan(ji, jj, n_node, n_nz, int(nX), int(nY),
+                     bool(traits.symmetric), rank, world,
+                     launch_order=order_all.astype(np.int64), times=times,
+                     group=group, tail=tail)
 
 
 def cuda_collective(group=None):
@@ -208,14 +391,10 @@ class ShardedStep:
         self.n_grad = int(nJ) if traits.eval_gradient is True else 0
         n_cols = self.n_cols = 1 + self.n_grad
         jobs = np.ascontiguousarray(jobs)
-        dgraphs = [backend._register_graph(g) for g in graphs]
         if shard_plan is None:
-            n_node = np.array([g.n_node for g in dgraphs], np.int64)
-            n_nz = np.array([g.n_nz for g in dgraphs], np.int64)
-            shard_plan = ShardPlan(
-                jobs['i'].astype(np.int64), jobs['j'].astype(np.int64),
-                n_node, n_nz, self.nX, self.nY, bool(traits.symmetric),
-                self.rank, self.world)
+            shard_plan = measured_shard_plan(
+                backend, graphs, node_kernel, edge_kernel, jobs, self.nX,
+                self.nY, traits, self.rank, self.world)
         self.shard = sp = shard_plan
         cap = self.capacity = sp.capacity
         rs = np.dtype(backend.real)
@@ -389,38 +568,43 @@ def distributed_backend(**kwargs):
             return (dist.is_available() and dist.is_initialized()
                     and (dist.get_world_size() > 1 or self.shard_single_rank))
 
-        def _shard_plan(self, dgraphs, jobs, nX, nY, symmetric, rank, world):
+        def _shard_plan(self, graphs, dgraphs, node_kernel, edge_kernel,
+                        jobs, nX, nY, traits, rank, world):
+            # (C: value and value + gradient launches have different
+            # variants and times per pair, hence different plans)
             key = (tuple(map(id, dgraphs)), id(jobs) if not
                    jobs.flags.writeable else hash(jobs.tobytes()),
-                   nX, nY, symmetric, rank, world)
+                   nX, nY, bool(traits.symmetric),
+                   traits.eval_gradient is True, rank, world)
             hit = self._shard_plans.get(key)
             if hit is None:
                 if len(self._shard_plans) > 8:
                     self._shard_plans.clear()
-                n_node = np.array([g.n_node for g in dgraphs], np.int64)
-                n_nz = np.array([g.n_nz for g in dgraphs], np.int64)
-                sp = ShardPlan(jobs['i'].astype(np.int64),
-                               jobs['j'].astype(np.int64), n_node, n_nz,
-                               nX, nY, symmetric, rank, world)
+                sp = measured_shard_plan(self, graphs, node_kernel,
+                                         edge_kernel, jobs, nX, nY, traits,
+                                         rank, world)
                 hit = self._shard_plans[key] = (sp, jobs, list(dgraphs))
             return hit
 
-        def __call__(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol,
-                     gtol, jobs, starts, gramian, gradient, nX, nY, nJ,
-                     traits, timer):
-            graph_level = (traits.nodal is False and not traits.diagonal)
-            if not (self.shards_over_ranks() and graph_level):
-                return super().__call__(
-                    graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
-                    jobs, starts, gramian, gradient, nX, nY, nJ, traits,
-                    timer)
+        def sharded_step(self, graphs, node_kernel, edge_kernel, p, q, eps,
+                         ftol, gtol, jobs, starts, nX, nY, nJ, traits,
+                         timer=None):
+            """Evaluate the graph-level job list over the ranks and leave the
+            reassembled result on this rank's device: returns the
+            `ShardedStep` (`.values` / `.gradient` / `.result`), enqueued and
+            synchronised.  Steps are cached per (graphs, jobs, traits): a
+            repeated evaluation with new hyperparameters only re-binds the
+            kernel arguments."""
             import torch.distributed as dist
             rank, world = dist.get_rank(), dist.get_world_size()
-            jobs = np.ascontiguousarray(jobs)
+            jobs = np.ascontiguousarray(jobs) if not isinstance(
+                jobs, np.ndarray) else jobs
+            if not isinstance(graphs, (list, tuple)):
+                graphs = list(graphs)
             dgraphs = [self._register_graph(g) for g in graphs]
             sp, _, _ = self._shard_plan(
-                dgraphs, jobs, int(nX), int(nY), bool(traits.symmetric), rank,
-                world)
+                graphs, dgraphs, node_kernel, edge_kernel, jobs, int(nX),
+                int(nY), traits, rank, world)
             key = (id(sp), int(nJ), traits)
             step = self._steps.get(key)
             if step is None:
@@ -434,12 +618,28 @@ def distributed_backend(**kwargs):
             else:
                 step.bind(node_kernel, edge_kernel, p, q, eps, ftol, gtol,
                           timer)
-            timer.tic('GPU kernel execution')
+            if timer is not None:
+                timer.tic('GPU kernel execution')
             step.enqueue()
             step.synchronize()
-            timer.toc('GPU kernel execution')
+            if timer is not None:
+                timer.toc('GPU kernel execution')
+            self.last_step = step
+            return step
+
+        def __call__(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol,
+                     gtol, jobs, starts, gramian, gradient, nX, nY, nJ,
+                     traits, timer):
+            graph_level = (traits.nodal is False and not traits.diagonal)
+            if not (self.shards_over_ranks() and graph_level):
+                return super().__call__(
+                    graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
+                    jobs, starts, gramian, gradient, nX, nY, nJ, traits,
+                    timer)
+            step = self.sharded_step(
+                graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol, jobs,
+                starts, nX, nY, nJ, traits, timer)
             step.download(gramian,
                           gradient if traits.eval_gradient is True else None)
-            self.last_step = step
 
     return DistributedHIPBackend(**kwargs)

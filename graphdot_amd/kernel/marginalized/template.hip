@@ -31,7 +31,7 @@ ${p_start}
 using graph_t = graphdot::graph_t<node_t, edge_t>;
 using params_t = graphdot::mgk::params_t<real_t, graph_t, node_kernel_t,
                                          edge_kernel_t, p_start_t>;
-static_assert(sizeof(graphdot::graph_header_t) == 32, "graph header layout");
+static_assert(sizeof(graphdot::graph_header_t) == 64, "graph header layout");
 static_assert(sizeof(node_t) == ${node_size}, "node_t layout differs from the host packer");
 static_assert(sizeof(edge_t) == ${edge_size}, "edge_t layout differs from the host packer");
 static_assert(sizeof(params_t) == ${params_size}, "params_t layout differs from the host packer");

@@ -2,7 +2,7 @@
 """Dump the gfx950 ISA of one solver variant built for the bench workload
 (QM7-like TensorProduct kernels) -- for instruction-count work on the CG loop.
 
-    python scripts/dump_isa.py W S R [C] [--f64] [--oc=D] [--tab|--tab=2] > out.s
+    python scripts/dump_isa.py W S R [C] [--f64] [--oc=D] [--layout=16x4x4x1] [--tab|--tab=2] > out.s
 """
 import os
 import subprocess
@@ -14,7 +14,7 @@ import cases                                                        # noqa: E402
 from graphdot_amd.hip import jit                                    # noqa: E402
 from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel  # noqa
 from graphdot_amd.kernel.marginalized._backend_hip import (         # noqa: E402
-    HIPBackend, Variant, OCVariant)
+    HIPBackend, Variant, OCVariant, OCStatic)
 
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 W, S, R = map(int, args[:3])
@@ -28,7 +28,10 @@ dgs = [backend._register_graph(g) for g in G]
 node_t, edge_t = dgs[0].node_t, dgs[0].edge_t
 ke2 = ke
 oc = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--oc=')]
+lay = [a.split('=')[1] for a in sys.argv if a.startswith('--layout=')]
 variant = OCVariant(W, S, R, oc[0]) if oc else Variant(W, S, R)
+if lay:       # --layout=16x4x4x1 (W S R are then ignored)
+    variant = OCStatic(*map(int, lay[0].split('x')))
 src = backend.render_source(kn, ke2, k.p, node_t, edge_t, [variant], C,
                             tab=2 if '--tab=2' in sys.argv else '--tab' in sys.argv)
 path = f'/tmp/_dump_isa_{W}_{S}_{R}_{C}_{int(real is np.float64)}.hip'

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Occupancy sweep of the owner-computes variants on the benchmark set:
 isolated launch time of every variant for every amdgpu_waves_per_eu target.
-    python scripts/oc_sweep.py [--f64] [--grad] [--config2] [--waves=3,4,5]"""
+    python scripts/oc_sweep.py [--f64] [--grad] [--config2] [--waves=3,4,5] [--precompile]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tests'))
@@ -29,6 +29,13 @@ table = {}
 wl = [a.split('=')[1] for a in sys.argv if a.startswith('--waves=')]
 wave_list = tuple(int(x) for x in wl[0].split(',')) if wl else \
     ((1, 2, 3, 4) if '--config2' in sys.argv else (2, 3, 4, 5, 6))
+if '--precompile' in sys.argv:      # no device: fill the JIT cache only
+    for waves in wave_list:
+        b = HIPBackend(real=real, occupancy={(v.W, v.S): waves for v in OC_VARIANTS})
+        k = MarginalizedGraphKernel(kn, ke, q=q, backend=b)
+        print(waves, len(b.precompile(G, kn, ke, k.p, jobs, k.traits(
+            symmetric=True, eval_gradient=grad))), flush=True)
+    sys.exit(0)
 for waves in wave_list:
     b = HIPBackend(real=real, occupancy={(v.W, v.S): waves for v in OC_VARIANTS})
     k = MarginalizedGraphKernel(kn, ke, q=q, backend=b)

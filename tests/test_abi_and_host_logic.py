@@ -148,6 +148,7 @@ def test_owner_computes_classification():
     i, j = np.triu_indices(len(G))
     choice, cost, ntask, gbytes, NP, gb_oc = backend.classify(i, j, dgs, 1)
     assert np.all(choice >= 0)
+    static_seen = set()
     for k, (a, b) in enumerate(zip(i, j)):
         v = backend.variants[choice[k]]
         assert isinstance(v, OCVariant) and v.W == 1
@@ -157,9 +158,24 @@ def test_owner_computes_classification():
         # ties in the rectangle order (d1, d2) ascending, then row-major
         rows = sorted(((-int(x) * int(y), int(x), int(y))
                        for x in d1 for y in d2))
-        need = sum(-rows[t][0] for t in range(0, len(rows), 64))   # (W = 1)
-        assert need <= v.S and len(rows) <= 64 * v.R
+        trips = [-rows[t][0] for t in range(0, len(rows), 64)]     # (W = 1)
+        assert sum(trips) <= v.S and len(rows) <= 64 * v.R
+        if v.L:
+            # static layout (seg_layout in mgk_oc.h): batch k owns exactly
+            # L[k] slots, so the first -- the heaviest -- row of every batch
+            # must fit its segment
+            static_seen.add(v.L)
+            assert len(trips) <= len(v.L)
+            assert all(t <= cap for t, cap in zip(trips, v.L))
+            assert sum(v.L) == v.S and len(v.L) == v.R
         assert backend.lds_bytes(v, 1, NP[k], gb_oc[k]) <= 160 * 1024
+    assert len(static_seen) >= 3          # the molecular profiles are static
+    # without the static layouts every pair still finds a dynamic variant
+    dyn = HIPBackend(variants=[v for v in backend.variants
+                               if not (isinstance(v, OCVariant) and v.L)])
+    cd, *_ = dyn.classify(i, j, dgs, 1)
+    assert all(isinstance(dyn.variants[c], OCVariant)
+               and dyn.variants[c].L is None for c in cd)
     # graphs with nodes of degree 5..8 take the D = 8 kernels, and the
     # two-stage solver when the owner-computes menu is switched off
     G2 = cases.config2_graphs(4, nmin=8, nmax=24, seed=1)
@@ -295,12 +311,17 @@ def test_label_classes_are_numbered_over_the_attributes_the_kernels_read():
     assert len(set(seen.values())) == len(seen) == used.classes['nv']
     # headers still address the blobs
     img = used.relocated(0)
-    hdr = img[:32 * len(dgs)].view(np.dtype([
+    hdr = img[:64 * len(dgs)].view(np.dtype([
         ('n_node', np.int32), ('n_nz', np.int32), ('degree', np.uint32),
         ('node', np.uint32), ('rowptr', np.uint32), ('nz', np.uint32),
-        ('edge', np.uint32), ('perm', np.uint32)]))
+        ('edge', np.uint32), ('perm', np.uint32), ('hist', np.uint16, (16,))]))
     assert np.array_equal(hdr['degree'], used.blob_start
                           + dgs[0].offsets['degree'])
+    # ... and carry the degree histogram the owner-computes solver lays its
+    # row rectangles out from (graph.h: hist[d] = nodes with d nonzeros)
+    for k, g in enumerate(dgs):
+        want = np.bincount(np.diff(g.rowptr.astype(np.int64)), minlength=16)
+        assert np.array_equal(hdr['hist'][k], want) and want.sum() == g.n_node
 
 
 @pytest.mark.parametrize('symmetric', [True, False])
