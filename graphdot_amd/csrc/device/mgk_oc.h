@@ -251,6 +251,15 @@ struct oc_solver {
 #endif
     constexpr static int GCH = GD_OC_GCH;       // gathers in flight
     constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4 && !STATIC;
+    // LEAN (static layouts, value + gradient): the solution x lives in a
+    // lane-private LDS region and p only in its published copy -- the update
+    // block re-reads p (once for A p, once for the x / p update) and
+    // read-modify-writes x, 3 R more LDS operations per iteration (about what
+    // the static layout saved on the row sums) for 4 R reals fewer in
+    // registers across the gather phase: the two-right-hand-side solver is
+    // what the register file limits to two waves per SIMD in double.
+    constexpr static bool LEAN = STATIC && C == 2 && !NODAL;
+    constexpr static bool HAS_Y = !STATIC || LEAN;   // the [Y] region exists
     template<class L> constexpr static bool layout_matches() {
         if constexpr (L::is_static) return L::S == S && L::R == R;
         else return true;
@@ -321,10 +330,11 @@ struct oc_solver {
         const int tid = (W == 1) ? lane : (int)threadIdx.x;
         const int wv = (W == 1) ? 0 : uni((int)(threadIdx.x / 64));
         // dynamic LDS: [p: u_capacity * C reals][Y: NR * C reals][rowmap: NR u32][G1][G2]
-        // (static layouts keep the row sums in registers: no Y region)
+        // (static layouts keep the row sums in registers: no Y region, except
+        // LEAN, which keeps the solution x there)
         real *const lp = dyn;
         real *const lY = lp + (size_t)prm.u_capacity * C;
-        unsigned *const rowmap = reinterpret_cast<unsigned *>(lY + (STATIC ? (size_t)0 : (size_t)NR * C));
+        unsigned *const rowmap = reinterpret_cast<unsigned *>(lY + (HAS_Y ? (size_t)NR * C : (size_t)0));
         char *const lG1 = reinterpret_cast<char *>(rowmap + NR);
         char *const lG2 = lG1 + prm.g_capacity;
         real *const red0 = lds.red[0], *const red1 = lds.red[1];
@@ -642,6 +652,10 @@ struct oc_solver {
                 const real b = ok ? dx * bscale : real(0);
                 if constexpr (KEEP_X) x[0][k] = 0;
                 else pp[k] = real(prm.p_start(v1)) * real(prm.p_start(v2));
+                if constexpr (LEAN) {
+                    const real zero[C] = {};
+                    store_elem<C>(lY, k * T + tid, zero);
+                }
                 r[0][k] = b;
                 p[0][k] = b * mi[k];
                 rTz += r[0][k] * p[0][k];
@@ -695,6 +709,10 @@ struct oc_solver {
 #pragma unroll
                     for (int s0 = 0; s0 < S; s0 += GCH) {
                         if (s0 >= n_slots) break;   // wave-uniform: no slots left
+                        // (static layouts have no branch between the chunks:
+                        // without the fence the scheduler merges their gathers
+                        // -- 16 instead of 8 vectors in flight, and spills)
+                        if constexpr (STATIC) __builtin_amdgcn_sched_barrier(0);
                         real g[C][GCH];
 #pragma unroll
                         for (int jj = 0; jj < GCH; ++jj) {
@@ -731,6 +749,57 @@ struct oc_solver {
                             }
                         }
                     }
+                }
+                if constexpr (LEAN) {
+                    // update block from LDS-resident p and x (one wave: its LDS
+                    // operations execute in order, no barriers)
+                    real pAp = 0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        real pk[C];
+                        load_elem<C>(lp, (unsigned)paddr[k], pk);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            ys[c][k] = dg[k] * pk[c] - ys[c][k];   // (A p)
+                            pAp += pk[c] * ys[c][k];
+                        }
+                    }
+                    pAp = reduce::sum(pAp, red0);
+                    if (pAp == real(0)) break;
+                    const real alpha = cg_ratio(rTz, pAp);
+                    real rTr = 0, rTz_next = 0;
+#pragma unroll
+                    for (int k = 0; k < R; ++k)
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            r[c][k] -= alpha * ys[c][k];
+                            rTr += r[c][k] * r[c][k];
+                            rTz_next += r[c][k] * (mi[k] * r[c][k]);
+                        }
+                    reduce::sum2(rTr, rTz_next, red1);
+                    real beta = cg_ratio(rTz_next, rTz);
+                    asm volatile("" : "+v"(beta));
+                    // x += alpha p (also in the iteration that ends the loop,
+                    // like the register form) and p = z + beta p, in place
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        real pk[C], xv[C];
+                        load_elem<C>(lp, (unsigned)paddr[k], pk);
+                        load_elem<C>(lY, k * T + tid, xv);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            xv[c] += alpha * pk[c];
+                            pk[c] = mi[k] * r[c][k] + beta * pk[c];
+                        }
+                        store_elem<C>(lY, k * T + tid, xv);
+                        store_elem<C>(lp, (unsigned)paddr[k], pk);
+                    }
+                    if (rTr < tol2) {   // sqrt(rTr) < tol
+                        ++it;
+                        break;
+                    }
+                    rTz = rTz_next;
+                    continue;
                 }
                 // (no barrier: a lane reads back what it wrote itself, and the
                 // LDS operations of one wave execute in order)
@@ -794,6 +863,15 @@ struct oc_solver {
                 rTz = rTz_next;
             }
             if (prm.iters != nullptr && tid == 0) prm.iters[prm.order[t]] = it;
+            if constexpr (LEAN) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    real xv[C];
+                    load_elem<C>(lY, k * T + tid, xv);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) x[c][k] = xv[c];
+                }
+            }
 
             // ---- output ------------------------------------------------------
             const unsigned flags = prm.flags;
@@ -844,6 +922,9 @@ struct oc_solver {
             // (graph-level output: I1, I2 are graph indices here)
             [[maybe_unused]] int mm_own[R];          // this lane's row k is the hotspot
             [[maybe_unused]] real mm_k12 = 0, mm_rs = 0, mm_k1 = 0, mm_k2 = 0, mm_D = 0;
+            // hotspot row of this lane: p1 p2, the lmin correction, and the
+            // raw solution of the last perturbed solve (reference_compat)
+            [[maybe_unused]] real mm_pp = 0, mm_corr = 0, mm_xlast = 0;
             [[maybe_unused]] unsigned mm_n1 = 0, mm_n2 = 0;   // node offsets of the graphs
             [[maybe_unused]] unsigned mm_hot = 0;             // flat index of the hotspot
             if constexpr (MAXIMIN) {
@@ -862,7 +943,7 @@ struct oc_solver {
                 if (tid < 3) cell[tid] = 0u;
                 job_sync<W>();
                 float dloc[R];
-                real k12v[R];
+                real k12v[R], ppv[R], corrv[R];
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     const int pos = row_pos(k, wv, lane);
@@ -873,6 +954,8 @@ struct oc_solver {
                     real xi = x[0][k];
                     if (flags & F_LMIN1) xi -= kappa_v(i1, i2, v1, v2) * bscale;
                     k12v[k] = xi * real(prm.p_start(v1)) * real(prm.p_start(v2));
+                    ppv[k] = real(prm.p_start(v1)) * real(prm.p_start(v2));
+                    corrv[k] = x[0][k] - xi;
                     const real k1 = prm.diag[NS1 + g1.perm[i1]], k2 = prm.diag[NS2 + g2.perm[i2]];
                     const real dd = real(0.9999995f) - k12v[k] * graphdot::rsqrt(k1 * k2);
                     dloc[k] = ok ? sqrtf((float)(dd > real(0) ? dd : real(0))) : 0.f;
@@ -917,6 +1000,9 @@ struct oc_solver {
                     mm_own[k] = pos < N && o1 * (unsigned)n2 + o2 == hot;
                     if (mm_own[k]) {
                         mm_k12 = k12v[k];
+                        mm_pp = ppv[k];
+                        mm_corr = corrv[k];
+                        mm_xlast = x[0][k];
                         mm_k1 = prm.diag[NS1 + o1];
                         mm_k2 = prm.diag[NS2 + o2];
                         mm_rs = graphdot::rsqrt(mm_k1 * mm_k2);
@@ -947,20 +1033,13 @@ struct oc_solver {
                 auto write_column = [&](int col, real const (&v)[R]) {
                     if constexpr (MAXIMIN) {
                         // v = d k12 / d theta_col per row: the hotspot's owner
-                        // turns it into the gradient of the distance
-                        // (_backend.cu:136-140,380-402)
+                        // parks it in the output; `maximin_gradient` below turns
+                        // the columns into the gradient of the distance once
+                        // every perturbed solve is done (_backend.cu:380-402)
 #pragma unroll
                         for (int k = 0; k < R; ++k)
-                            if (mm_own[k]) {
-                                const unsigned o1 = mm_hot / (unsigned)n2, o2 = mm_hot - o1 * (unsigned)n2;
-                                const real dk1 = prm.diag_grad[(size_t)(mm_n1 + o1) + (size_t)prm.diag_ld * col];
-                                const real dk2 = prm.diag_grad[(size_t)(mm_n2 + o2) + (size_t)prm.diag_ld * col];
-                                const real dnorm = v[k] * mm_rs - real(0.5) * mm_k12 * mm_rs * mm_rs * mm_rs *
-                                                   (dk1 * mm_k2 + mm_k1 * dk2);
-                                const real g = real(-0.5) * dnorm / (mm_D + real(1e-4f));
-                                prm.gradient[(size_t)I1 + (size_t)prm.nX * I2 + plane * col] = g;
-                                if (mirror) prm.gradient[(size_t)I2 + (size_t)prm.nX * I1 + plane * col] = g;
-                            }
+                            if (mm_own[k])
+                                prm.gradient[(size_t)I1 + (size_t)prm.nX * I2 + plane * col] = v[k];
                         return;
                     }
 #pragma unroll
@@ -1147,6 +1226,11 @@ struct oc_solver {
 #pragma unroll
                     for (int k = 0; k < R; ++k) xb[k] = x0[k];
                     pcg_warm(xb);
+                    if constexpr (MAXIMIN) {
+#pragma unroll
+                        for (int k = 0; k < R; ++k)
+                            if (mm_own[k]) mm_xlast = xb[k];
+                    }
                     const real inv = real(1) / denom;
 #pragma unroll
                     for (int k = 0; k < R; ++k) xa[k] = (xa[k] - xb[k]) * inv * ppr[k];
@@ -1167,6 +1251,40 @@ struct oc_solver {
                     difference(off_e + j, real(2) * prm.eps * full.edge_theta[j],
                                [&] { set_vals(full.edge_diff[2 * j]); },
                                [&] { set_vals(full.edge_diff[2 * j + 1]); });
+                // ---- gradient of the maximin distance at the hotspot ----------
+                //   -0.5 d(k12 / sqrt(k1 k2)) / dtheta / (d + 1e-4)
+                // from the parked d k12 / d theta (_backend.cu:136-140,380-402).
+                // F_REFCOMPAT reproduces the reference to the letter: its final
+                // loop re-reads k12 -- and with it the distance in the
+                // denominator -- from the solution buffer, which by then holds
+                // the LAST perturbed solve (theta_last e^-eps, _backend.cu:383),
+                // for every column from q on; the starting-probability columns
+                // were finished before the finite-difference loop (:222-250).
+                if constexpr (MAXIMIN) {
+                    bool own = false;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) own = own || mm_own[k];
+                    if (own) {
+                        const unsigned o1 = mm_hot / (unsigned)n2, o2 = mm_hot - o1 * (unsigned)n2;
+                        const real k12_last = (mm_xlast - mm_corr) * mm_pp;
+                        const real dd = real(0.9999995f) - k12_last * mm_rs;
+                        const real D_last = real(sqrtf((float)(dd > real(0) ? dd : real(0))));
+                        for (int col = 0; col < n_jac; ++col) {
+                            const bool compat = (flags & F_REFCOMPAT) && col >= off_q;
+                            const real k12u = compat ? k12_last : mm_k12;
+                            const real Du = compat ? D_last : mm_D;
+                            const size_t at = (size_t)I1 + (size_t)prm.nX * I2 + plane * col;
+                            const real dk12 = prm.gradient[at];   // (this lane's own store)
+                            const real dk1 = prm.diag_grad[(size_t)(mm_n1 + o1) + (size_t)prm.diag_ld * col];
+                            const real dk2 = prm.diag_grad[(size_t)(mm_n2 + o2) + (size_t)prm.diag_ld * col];
+                            const real dnorm = dk12 * mm_rs - real(0.5) * k12u * mm_rs * mm_rs * mm_rs *
+                                               (dk1 * mm_k2 + mm_k1 * dk2);
+                            const real g = real(-0.5) * dnorm / (Du + real(1e-4f));
+                            prm.gradient[at] = g;
+                            if (mirror) prm.gradient[(size_t)I2 + (size_t)prm.nX * I1 + plane * col] = g;
+                        }
+                    }
+                }
             }
 
             // ---- analytic gradient (graph-level), marginalized_kernel.h:806-997

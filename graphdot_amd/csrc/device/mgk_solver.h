@@ -55,6 +55,7 @@ enum : unsigned {
     F_LMIN1 = 8u,      // subtract the zero-step term kappa_v q^2/q0^2
     F_BLOCK = 16u,     // diag(nodal='block'): n x n block per graph
     F_PACKED = 32u,    // graph-level: out[job id] instead of K(I1, I2)
+    F_REFCOMPAT = 64u, // maximin gradient: k12 of the last perturbed solve (mgk_oc.h)
 };
 
 struct job_t {

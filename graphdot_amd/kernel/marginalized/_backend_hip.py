@@ -29,8 +29,8 @@ from ._devicegraph import DeviceGraph, GraphArena, class_bytes, pack_many
 _TEMPLATE = os.path.join(os.path.dirname(__file__), 'template.hip')
 
 # solver flags, mirror graphdot::mgk::F_* (mgk_solver.h)
-F_NODAL, F_DIAGONAL, F_SYMMETRIC, F_LMIN1, F_BLOCK, F_PACKED = \
-    1, 2, 4, 8, 16, 32
+F_NODAL, F_DIAGONAL, F_SYMMETRIC, F_LMIN1, F_BLOCK, F_PACKED, F_REFCOMPAT = \
+    1, 2, 4, 8, 16, 32, 64
 
 Variant = namedtuple('Variant', 'W S R')
 #: owner-computes solver (csrc/device/mgk_oc.h): S nonzero slots and R rows
@@ -719,6 +719,14 @@ struct ${name}_t : ${name}_theta_t {
                     (1, 28, 6, 4): 2, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2},
     }
 
+    #: static layouts that lose to the dynamic variants behind them in the
+    #: menu (measured, scripts/oc_sweep.py): (double?, C) -> {layout, ...}
+    _STATIC_OFF = {}
+
+    def _static_enabled(self, v, C):
+        f64 = np.dtype(self.real) == np.float64
+        return v.L not in self._STATIC_OFF.get((f64, C), ())
+
     def _oc_waves(self, v, C, ngrad=False):
         """Occupancy target of an owner-computes variant: per lane S values +
         S gather indices, 6 registers per row (x, r, p, diagonal, its inverse,
@@ -839,10 +847,9 @@ void ${name}(params_t prm) {
             rs = np.dtype(self.real).itemsize
             NR = 64 * v.W * v.R
             pcap = -(-(np.asarray(ntask) + 1) // 4) * 4
-            if v.L:                 # row sums in registers: no Y region
-                NR_y = 0
-            else:
-                NR_y = NR
+            # static layouts keep the row sums in registers: no Y region,
+            # except the value + gradient solvers, which keep x there
+            NR_y = 0 if (v.L and C != 2) else NR
             return (pcap + NR_y) * C * rs + 4 * NR + 2 * np.asarray(gbytes) \
                 + 4 * v.W * rs + 4 * (128 if v.D > 6 else 64) + 256 + 16
         wpb = WPB1 if v.W == 1 else 1
@@ -1044,6 +1051,8 @@ void ${name}(params_t prm) {
                 continue
             if isinstance(v, OCVariant):
                 if tab_bytes:           # the table kernels are two-stage only
+                    continue
+                if v.L and not self._static_enabled(v, C):
                     continue
                 fits = ((pair_maxdeg[rem] <= v.D) & (N[rem] <= 64 * v.W * v.R)
                         & (NP[rem] < 0xFFFF))
@@ -1247,8 +1256,8 @@ void ${name}(params_t prm) {
                 pcap = int(-(-(NP[idx].max() + 1) // 4) * 4)
                 gcap = int(-(-gbytes_oc[idx].max() // 16) * 16)
                 NR = 64 * v.W * v.R
-                dyn = (pcap + (0 if v.L else NR)) * C * rsize + 4 * NR \
-                    + 2 * gcap
+                dyn = (pcap + (0 if (v.L and C != 2) else NR)) * C * rsize \
+                    + 4 * NR + 2 * gcap
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=pcap, gcap=gcap,
                     dynamic_lds=dyn, count=count,
@@ -1442,6 +1451,8 @@ void ${name}(params_t prm) {
             flags |= F_LMIN1
         if packed:
             flags |= F_PACKED
+        if maximin and maximin.get('reference_compat'):
+            flags |= F_REFCOMPAT
         rsize = np.dtype(self.real).itemsize
         n_out = lay.n_jobs if packed else plan.nX * plan.nY
         plan.n_out = n_out
@@ -1710,7 +1721,8 @@ void ${name}(params_t prm) {
 
     # -- maximin graph distance, fused ------------------------------------------------
     def maximin_distance(self, graphs, node_kernel, edge_kernel, p, q, eps,
-                         ftol, gtol, jobs, nX, nY, nJ, traits, timer=None):
+                         ftol, gtol, jobs, nX, nY, nJ, traits, timer=None,
+                         reference_compat=False):
         """Maximin distances (+ hotspots, + gradients with
         `traits.eval_gradient`) of the graph pairs in `jobs` without the
         nodal Gram matrix ever leaving the compute units (reference:
@@ -1719,7 +1731,10 @@ void ${name}(params_t prm) {
         Jacobian) on the device, the pair launch reduces row minima / column
         minima / their maximum in LDS (mgk_oc.h, MAXIMIN).  `traits` are
         graph-level (`nodal=False`); nX, nY count graphs.  Owner-computes
-        solvers only: raises NotOwnerComputes otherwise.  Returns (distance
+        solvers only: raises NotOwnerComputes otherwise.  `reference_compat`:
+        the gradient columns from q on are formed with k12 (and the distance in
+        the denominator) of the last perturbed solve, as the reference's kernel
+        does (_backend.cu:383); default: the unperturbed solution.  Returns (distance
         [nX nY], hotspot int32 [nX nY], gradient [nX nY nJ] or None), flat
         column-major like the other outputs."""
         grad = traits.eval_gradient is True
@@ -1766,7 +1781,8 @@ void ${name}(params_t prm) {
             starts, nX, nY, nJ, mtraits, timer, ngrad=grad,
             maximin=dict(diag=b_diag.ptr,
                          diag_grad=b_dgrad.ptr if grad else 0,
-                         node_starts=b_ns.ptr, ld=total))
+                         node_starts=b_ns.ptr, ld=total,
+                         reference_compat=bool(reference_compat)))
         if grad:
             plan.buffers['gradient'].zero()
         self.launch(plan)

@@ -14,7 +14,7 @@ and the graph distance the Hausdorff-like
 with the *hotspot* the node pair that attains it (the largest flat index
 ``i1 n2 + i2`` among ties, _backend.cu:173-183) and the gradient
 ``-0.5 d(k12 / sqrt(k1 k2))/dtheta / (D + 1e-4)`` taken at the hotspot
-(_backend.cu:136-140,380-402; columns of the starting probability are zero).
+(_backend.cu:136-140,222-250,380-402).
 
 The reference fuses this into its solver kernel, and so does the HIP backend
 for graphs its owner-computes solvers cover (``HIPBackend.maximin_distance``:
@@ -41,9 +41,19 @@ class MaxiMin(MarginalizedGraphKernel):
     """Maximin distance between graphs; constructor arguments as for
     :class:`MarginalizedGraphKernel`."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *args, reference_compat=False, **kwargs):
+        """reference_compat: form the gradient exactly as the reference's
+        kernel does -- its final loop (_backend.cu:380-402) reads k12, and with
+        it the distance in the denominator, from the solution buffer *after*
+        the finite-difference loop has left the last perturbed solve
+        (theta_last e^-eps) there, for every column from q on.  Default
+        (False): the unperturbed solution, i.e. the formula the reference's
+        comments state.  The two differ by O(eps); the compat form needs the
+        fused device path (the host composition never sees the perturbed
+        solutions)."""
         kwargs['dtype'] = np.float32
         super().__init__(*args, **kwargs)
+        self.reference_compat = bool(reference_compat)
 
     def __call__(self, X, Y=None, eval_gradient=False, lmin=0,
                  return_hotspot=False, timing=False):
@@ -53,6 +63,11 @@ class MaxiMin(MarginalizedGraphKernel):
         fused = self._fused(X, Y, eval_gradient, lmin, return_hotspot)
         if fused is not None:
             return fused
+        if self.reference_compat and eval_gradient:
+            raise NotImplementedError(
+                'MaxiMin(reference_compat=True) gradients need the fused '
+                'device path (HIP backend, graphs the owner-computes solvers '
+                'cover)')
         mgk = super()
         Yl = X if Y is None else Y
         nx_, sx = _segments(X)
@@ -108,11 +123,8 @@ class MaxiMin(MarginalizedGraphKernel):
             dnorm = dk12 / np.sqrt(kk) - 0.5 * k12[..., None] * kk**-1.5 * (
                 dka * kb[..., None] + ka[..., None] * dkb)
             grad = -0.5 * dnorm / (D.astype(np.float64)[..., None] + _EPS)
-            # the distance does not respond to the starting probability in
-            # the reference either (_backend.cu:394: columns from q on)
-            n_p = int(np.count_nonzero(
-                np.asarray(self.active_theta_mask)[:self._n_p_theta()]))
-            grad[..., :n_p] = 0
+            # (the starting-probability columns take the same formula on the
+            # analytic d k12 / dp, _backend.cu:222-250)
             out.append(grad.astype(self.element_dtype))
         return out[0] if len(out) == 1 else tuple(out)
 
@@ -143,7 +155,7 @@ class MaxiMin(MarginalizedGraphKernel):
             d, hot, g = backend.maximin_distance(
                 graphs, self.node_kernel, self.edge_kernel, self.p, self.q,
                 self.eps, self.ftol, self.gtol, jobs, nx, ny, self.n_dims,
-                traits)
+                traits, reference_compat=self.reference_compat)
         except NotOwnerComputes:
             return None
         out = [d.reshape(nx, ny, order='F').astype(self.element_dtype)]
@@ -157,6 +169,3 @@ class MaxiMin(MarginalizedGraphKernel):
                 self.element_dtype))
         return out[0] if len(out) == 1 else tuple(out)
 
-    def _n_p_theta(self):
-        from ...util.iterable import flatten
-        return len(list(flatten(self.p.theta)))

@@ -3,7 +3,7 @@
 a world of 2 / 4 / 8 the local shard of the 1000-graph matrix is prepared and
 its step timed; max over ranks against (full step) / N is the compute part of
 the strong-scaling efficiency (the all-gather is not in it).
-    python scripts/shard_sim.py [--f32] [--mode=snake|blocks] [--gradient]"""
+    python scripts/shard_sim.py [--f32] [--mode=snake|blocks|measured] [--gradient] [--no-merge]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tests'))
@@ -12,15 +12,16 @@ import cases
 from graphdot_amd.hip import runtime
 from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
 from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend, LaunchSet
-from graphdot_amd.kernel.marginalized._sharded import ShardPlan, partition, predict_cost
+from graphdot_amd.kernel.marginalized._sharded import (
+    ShardPlan, partition, predict_cost, measured_shard_plan)
 
 real = np.float32 if '--f32' in sys.argv else np.float64
 grad = '--gradient' in sys.argv
-modes = [a.split('=')[1] for a in sys.argv if a.startswith('--mode=')] or ['snake', 'blocks']
+modes = [a.split('=')[1] for a in sys.argv if a.startswith('--mode=')] or ['snake', 'measured']
 n = 1000
 G = cases.config3_graphs(n)
 kn, ke, q = cases.config3_kernels()
-b = HIPBackend(real=real)
+b = HIPBackend(real=real, min_launch=0 if '--no-merge' in sys.argv else 8192)
 k = MarginalizedGraphKernel(kn, ke, q=q, backend=b)
 job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
 i, j = np.triu_indices(n)
@@ -51,7 +52,13 @@ full, nl = step_ms(jobs)
 print(f'full step {full:.3f} ms, {nl} launches')
 for world in (2, 4, 8):
     for mode in modes:
-        shards = partition(cost, world, mode)
+        if mode == 'measured':
+            # contiguous blocks of the launch order with equal measured time
+            # (_sharded.measured_shard_plan: what ShardedStep uses)
+            shards = measured_shard_plan(b, G, kn, ke, jobs, n, n, traits, 0,
+                                         world).shards
+        else:
+            shards = partition(cost, world, mode)
         t = [step_ms(np.ascontiguousarray(jobs[s])) for s in shards]
         ms = np.array([x[0] for x in t])
         print(f'world {world} {mode:6s}: max {ms.max():.3f} mean {ms.mean():.3f} '

@@ -28,15 +28,20 @@ def _worker(rank, world, port, tmp):
     K2, dK = k(G, eval_gradient=True)
     Kxy = k(G[:12], G[12:])
     d = k.diag(G)                                   # single-GPU path
-    # a GPR on top: the zero-copy device path steps aside, the likelihood
-    # goes through the sharded __call__ and is the same on every rank
+    # a GPR on top: the regressor takes the all-gathered, reassembled matrix
+    # and gradient planes from this rank's device (`device_gram` under the
+    # distributed backend) -- no host arrays between solver and Cholesky
     from graphdot_amd.model.gaussian_process import GaussianProcessRegressor
     gpr = GaussianProcessRegressor(k, alpha=float(0.1 * d.mean()))
     gpr.X, gpr.y = G, np.cos(np.arange(len(G)))
-    assert gpr._device_gramian(gpr._dense(), k, G, True) is None
+    on_device = gpr._device_gramian(gpr._dense(), k, G, True)
+    assert on_device is not None and on_device[0].is_cuda \
+        and on_device[1].is_cuda
+    assert on_device[1].shape == (len(G), len(G), len(k.theta))
     lml, glml = gpr.log_marginal_likelihood(eval_gradient=True)
+    loo, gloo = gpr.squared_loocv_error(eval_gradient=True)
     np.savez(os.path.join(tmp, f'rank{rank}.npz'), K=K, K2=K2, dK=dK,
-             Kxy=Kxy, d=d, lml=lml, glml=glml)
+             Kxy=Kxy, d=d, lml=lml, glml=glml, loo=loo, gloo=gloo)
     dist.destroy_process_group()
 
 
@@ -63,14 +68,28 @@ def test_two_ranks_through_the_kernel_api(tmp_path):
         assert np.array_equal(r['Kxy'], Kxy)
         assert np.array_equal(r['d'], d)
         assert np.array_equal(r['K'], r['K'].T)
+    # the likelihood + gradient step of the regressor: two ranks through the
+    # device-resident sharded path against one rank through the single-GPU
+    # device path -- the same matrix bit for bit, hence the same objective
     from graphdot_amd.model.gaussian_process import GaussianProcessRegressor
-    gpr = GaussianProcessRegressor(k, alpha=float(0.1 * d.mean()),
-                                   kernel_options={'lmin': 0})   # numpy path
+    gpr = GaussianProcessRegressor(k, alpha=float(0.1 * d.mean()))
     gpr.X, gpr.y = G, np.cos(np.arange(len(G)))
+    assert gpr._device_gramian(gpr._dense(), k, G, True) is not None
     lml, glml = gpr.log_marginal_likelihood(eval_gradient=True)
+    loo, gloo = gpr.squared_loocv_error(eval_gradient=True)
     r0, r1 = (np.load(tmp_path / f'rank{r}.npz') for r in range(2))
-    assert float(r0['lml']) == float(r1['lml']) == pytest.approx(lml, rel=1e-9)
-    assert np.allclose(r0['glml'], glml, rtol=1e-7)
+    assert float(r0['lml']) == float(r1['lml']) == lml
+    assert np.array_equal(r0['glml'], glml) and np.array_equal(r1['glml'], glml)
+    assert float(r0['loo']) == float(r1['loo']) == loo
+    assert np.array_equal(r0['gloo'], gloo)
+    # ... and against the numpy kernel protocol (host arrays, float64
+    # conversion on the host) to round-off
+    slow = GaussianProcessRegressor(k, alpha=float(0.1 * d.mean()),
+                                    kernel_options={'lmin': 0})
+    slow.X, slow.y = G, np.cos(np.arange(len(G)))
+    lml2, glml2 = slow.log_marginal_likelihood(eval_gradient=True)
+    assert lml == pytest.approx(lml2, rel=1e-9)
+    assert np.allclose(glml, glml2, rtol=1e-7)
 
 
 def _rccl_worker(rank, world, port, tmp):
@@ -175,3 +194,40 @@ def test_bench_sharded_step_single_rank():
     assert chk['collective'] == 'nccl(RCCL)' and chk['symmetric']
     assert chk['max_rel_diff_vs_oracle'] < 1e-5
     assert line['config']['parallelism'] == 'pair-sharded x1'
+
+
+def test_bench_spawns_its_ranks():
+    """`python bench.py --gpus 2` without a launcher starts its two ranks
+    itself (before anything touches the GPU in the parent) instead of running
+    one rank and printing n_gpus = 1; the ranks share the test GPU (gloo).
+    The same for the GPR step of configuration 5, whose kernel matrix stays
+    on the device on every rank."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT',
+                        'MASTER_ADDR')}
+    common = ['--gpus', '2', '--graphs', '120', '--steps', '2', '--warmup',
+              '1', '--dtype', 'f32']
+    r = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), *common,
+         '--no-cpu-baseline'],
+        capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2
+    assert line['config']['parallelism'] == 'pair-sharded x2'
+    assert line['sharded_check']['ranks'] == 2
+    assert line['sharded_check']['max_rel_diff_vs_oracle'] < 1e-5
+    r = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), *common, '--gpr'],
+        capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['device_resident_kernel_matrix']
+    # a mismatch between --gpus and the launcher's world size is an error
+    r = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'],
+        capture_output=True, text=True, env=dict(env, WORLD_SIZE='2'),
+        timeout=120)
+    assert r.returncode != 0

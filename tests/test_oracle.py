@@ -165,3 +165,72 @@ def test_c_gradient_restatement_vs_dense_oracle():
             assert np.allclose(g[t], J, rtol=1e-6, atol=1e-7 * np.abs(J).max())
         v32, g32, _ = batch.run_gradient(ii, jj, q=q, real='f32')
         assert np.allclose(v32, v, rtol=2e-5)
+
+
+def _maximin_from_oracle(fx, reference_compat):
+    """Distance, hotspots and gradient of every pair of the maximin fixture
+    from this repo's dense oracle (mgk.py) and the epilogue restatement
+    (oracle/maximin.py)."""
+    from oracle import maximin as omm
+    G = graphs_from(fx['graphs'])
+    knode, kedge = kernel_from_repr(fx['knode']), kernel_from_repr(fx['kedge'])
+    q, eps = fx['q'], fx['eps']
+
+    def raw(g1, g2, kn=knode, ke=kedge, qq=q):
+        # p = 1, lmin = 0: the nodal matrix IS the raw solution
+        return mgk.pair_value(g1, g2, kn, ke, q=qq, nodal=True, tol=1e-13)[0]
+
+    grid, denom = [(dict(qq=float(np.exp(np.log(q) + eps))),
+                    dict(qq=float(np.exp(np.log(q) - eps))))], [2 * eps * q]
+    for which, kern in (('kn', knode), ('ke', kedge)):
+        theta = mgk._flat_theta(kern)
+        for j, t in enumerate(theta):
+            tp, tm = theta.copy(), theta.copy()
+            tp[j], tm[j] = np.exp(np.log(t) + eps), np.exp(np.log(t) - eps)
+            grid.append(({which: mgk._with_theta(kern, tp)},
+                         {which: mgk._with_theta(kern, tm)}))
+            denom.append(2 * eps * t)
+    one = [np.ones(len(g.nodes)) for g in G]
+    selfs = [omm.nodal_self(raw(g, g), [raw(g, g, **a) for a, _ in grid],
+                            [raw(g, g, **b) for _, b in grid], denom,
+                            one[k], one[k][None, :])
+             for k, g in enumerate(G)]
+    out = []
+    for pr in fx['pairs']:
+        a, b = pr['i'], pr['j']
+        out.append(omm.pair_gradient(
+            raw(G[a], G[b]), [raw(G[a], G[b], **u) for u, _ in grid],
+            [raw(G[a], G[b], **v) for _, v in grid], denom, one[a], one[b],
+            one[a][None, :], one[b][None, :], selfs[a][0], selfs[a][1],
+            selfs[b][0], selfs[b][1], reference_compat=reference_compat))
+    return selfs, out
+
+
+def test_maximin_restatement_vs_reference_solutions():
+    """tests/golden/maximin.json (raw nodal solutions of the REFERENCE's CPU
+    solver M3._mlgk through the restated epilogue of its maximin kernel,
+    metric/maximin/_backend.cu:100-404) against the same epilogue on this
+    repo's dense oracle: distance, hotspot and mirrored hotspot, gradient in
+    both forms -- k12 re-read after the finite-difference loop as the
+    reference does (:383), and from the unperturbed solve -- and the nodal
+    self-similarities with their Jacobian."""
+    fx = load('maximin.json')
+    for compat, key in ((True, 'grad_reference'), (False, 'grad_unperturbed')):
+        selfs, got = _maximin_from_oracle(fx, compat)
+        for (k, dk), ref in zip(selfs, fx['nodal_self']):
+            assert np.allclose(k, ref['k'], rtol=2e-5)        # (M3: float32 parts)
+            assert np.allclose(dk, ref['dk'], rtol=5e-3,
+                               atol=2e-4 * np.abs(ref['dk']).max())
+        for (D, hot, hot_m, grad), ref in zip(got, fx['pairs']):
+            assert D == pytest.approx(ref['distance'], abs=2e-4)
+            if ref['runner_up_gap'] > 1e-4 and ref['i'] != ref['j']:
+                assert (hot, hot_m) == (ref['hotspot'],
+                                        ref['hotspot_mirrored'])
+                want = np.array(ref[key])
+                assert np.allclose(grad, want, rtol=2e-2,
+                                   atol=2e-3 * np.abs(want).max() + 1e-5)
+    # the two forms really differ (by O(eps)), most in the q column
+    d = [np.abs(np.array(p['grad_reference']) - np.array(p['grad_unperturbed']))
+         for p in fx['pairs'] if p['i'] != p['j']]
+    assert 1e-4 < max(x.max() for x in d) < 1e-2
+    assert all(x[0] == 0 for x in d)        # starting probability: same form

@@ -803,6 +803,71 @@ def test_maximin_distance(backend):
     assert np.all(np.abs(g[..., 0]) <= 2e-2 * np.abs(g).max())
 
 
+@pytest.mark.parametrize('real', [np.float32, np.float64])
+def test_maximin_pinned_to_the_reference(real):
+    """The fused maximin epilogue (mgk_oc.h MAXIMIN / NGRAD) against
+    tests/golden/maximin.json -- the REFERENCE's CPU solutions (M3._mlgk)
+    through the restated epilogue of its kernel (_backend.cu:100-404):
+    distance, hotspot, and the gradient in both forms: as the reference
+    computes it (`reference_compat=True`: k12 and the distance in the
+    denominator re-read after the finite-difference loop has left the last
+    perturbed solve in the solution buffer, :383) and from the unperturbed
+    solve (default).  The double-precision build resolves the O(eps)
+    difference between the two."""
+    from graphdot_amd.metric.maximin import MaxiMin
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    fx = load('maximin.json')
+    G = graphs_from(fx['graphs'])
+    knode, kedge = kernel_from_repr(fx['knode']), kernel_from_repr(fx['kedge'])
+    f64 = real is np.float64
+    tol = dict(ftol=1e-13, gtol=1e-12) if f64 else {}
+    got = {}
+    for compat, key in ((True, 'grad_reference'), (False, 'grad_unperturbed')):
+        be = HIPBackend(real=real)
+        mm = MaxiMin(knode, kedge, q=fx['q'], eps=fx['eps'], backend=be,
+                     reference_compat=compat, **tol)
+        assert list(mm.active_theta_mask) == [True] * 5
+        D, (h1, h2), g = mm(G, return_hotspot=True, eval_gradient=True)
+        assert be.last_plan.maximin and be.last_plan.ngrad      # fused
+        got[compat] = g
+        sizes = [len(x.nodes) for x in G]
+        for pr in fx['pairs']:
+            a, b = pr['i'], pr['j']
+            # (float32: the resolution of sqrt(1 - k) near k = 1)
+            assert D[a, b] == pytest.approx(pr['distance'],
+                                            abs=2e-5 if f64 else 3e-3)
+            assert D[b, a] == D[a, b]
+            if a == b or pr['runner_up_gap'] < (1e-4 if f64 else 3e-3):
+                continue            # (ties a float solver may break either way)
+            assert h1[a, b] * sizes[b] + h2[a, b] == pr['hotspot']
+            assert h1[b, a] * sizes[a] + h2[b, a] == pr['hotspot_mirrored']
+            want = np.array(pr[key])
+            scale = np.abs(want).max()
+            assert np.allclose(g[a, b], want, rtol=5e-3 if f64 else 5e-2,
+                               atol=(1e-3 if f64 else 2e-2) * scale), \
+                (a, b, compat, g[a, b], want)
+            assert np.array_equal(g[b, a], g[a, b])
+    if f64:
+        # the two forms differ by O(eps), most in the q column: the device
+        # reproduces the *difference* the reference's form makes
+        for pr in fx['pairs']:
+            a, b = pr['i'], pr['j']
+            if a == b or pr['runner_up_gap'] < 1e-4:
+                continue
+            want = np.array(pr['grad_reference']) \
+                - np.array(pr['grad_unperturbed'])
+            have = got[True][a, b] - got[False][a, b]
+            assert have[0] == 0.0 and want[0] == 0.0
+            assert np.allclose(have, want, rtol=0.1, atol=1e-4), (a, b, have,
+                                                                 want)
+    # without the fused path the reference's form is not available
+    from graphdot_amd.kernel.marginalized._backend_hip import VARIANTS, GENERAL
+    slow = MaxiMin(knode, kedge, q=fx['q'], reference_compat=True,
+                   backend=HIPBackend(variants=VARIANTS + [GENERAL]))
+    with pytest.raises(NotImplementedError):
+        slow(G[:2], eval_gradient=True)
+
+
 def test_maximin_at_full_size(backend):
     """Maximin distances of all 500 500 pairs of the 1000 QM7-like graphs in
     one fused evaluation (the host composition would need the 15 500 x 15 500
