@@ -302,8 +302,10 @@ def gpr_step_line(args, world, rank, local_rank):
             parts[k] += gpr.last_timing[k]
     barrier()
     elapsed = time.perf_counter() - t0
-    on_device = getattr(backend, 'last_step', None) is not None \
-        or dist is None
+    # (was the regressor handed device tensors -- device_gram -- or did it
+    # fall back to the numpy kernel protocol?)
+    on_device = gpr._device_gramian(gpr._dense(), kernel, graphs,
+                                    False) is not None
     if dist is not None and world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device='cpu' if host_collective else 'cuda')

@@ -1,0 +1,365 @@
+// libgdhost.so -- native host side of the MI355X marginalized-graph-kernel
+// path (include/gdhost.h): graph packer, label-class numbering, solver-variant
+// classification and job layout.  Host code only (g++), no HIP.
+//
+// The numpy implementations (_devicegraph.pack_many / _label_classes,
+// HIPBackend._classify_pairs / _partition) are the specification; every
+// function here reproduces their results byte for byte (tests/test_host_model
+// .py, tests/test_abi_and_host_logic.py).
+#include "gdhost.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+constexpr int64_t ALIGN = 16;
+inline int64_t pad(int64_t n) { return (n + ALIGN - 1) / ALIGN * ALIGN; }
+
+// (a, b) for a, b in [0, 15], sorted by descending a * b, ties row-major:
+// the order of the degree-pair rectangles in the sorted row space
+// (mgk_oc.h class_order; zero-size rectangles of a smaller degree bound do
+// not change the relative order of the others)
+struct rect_order_t {
+    int a[256], b[256], prod[257];
+    // the rectangles of classes <= d, in order, for every degree bound d
+    int n_upto[16], upto[16][256];
+    rect_order_t() {
+        int n = 0;
+        for (int p = 15 * 15; p >= 0; --p)
+            for (int x = 0; x <= 15; ++x)
+                for (int y = 0; y <= 15; ++y)
+                    if (x * y == p) {
+                        a[n] = x;
+                        b[n] = y;
+                        prod[n] = p;
+                        ++n;
+                    }
+        prod[256] = 0;
+        for (int d = 0; d < 16; ++d) {
+            n_upto[d] = 0;
+            for (int k = 0; k < 256; ++k)
+                if (a[k] <= d && b[k] <= d) upto[d][n_upto[d]++] = k;
+        }
+    }
+};
+const rect_order_t RECT;
+
+}  // namespace
+
+extern "C" {
+
+const char *gdh_version(void) { return "gdhost 3.0 (round 3)"; }
+
+int gdh_pack_graphs(int32_t G, const int64_t *node_off, const int64_t *edge_off,
+                    const int64_t *node_id, const int64_t *ei, const int64_t *ej,
+                    const float *w, const uint8_t *node_rec, int32_t node_size,
+                    const uint8_t *label_rec, int32_t label_size,
+                    int32_t edge_size, int32_t label_offset, int32_t weight_bytes,
+                    uint8_t *blob, int64_t blob_capacity, int64_t *blob_off,
+                    int64_t *sec_off, int64_t *nnz, uint16_t *perm, int64_t *rank,
+                    float *degree, int64_t *count, uint16_t *rowptr, uint16_t *nz,
+                    int64_t *eid, int64_t nz_capacity, int64_t *nz_off,
+                    int64_t *maxdeg) {
+    if (G < 0 || node_size < 0 || label_size < 0 || edge_size < 0) return -1;
+    if (weight_bytes != 0 && weight_bytes != 4 && weight_bytes != 8) return -1;
+    struct entry_t {
+        int64_t key;
+        int32_t src, dst, e;
+    };
+    std::vector<entry_t> ent, uniq;
+    std::vector<float> deg;
+    std::vector<int64_t> cnt;
+    std::vector<int32_t> order;
+    int64_t cursor = 0, zc = 0;
+    blob_off[0] = 0;
+    nz_off[0] = 0;
+    for (int32_t g = 0; g < G; ++g) {
+        const int64_t n0 = node_off[g], n = node_off[g + 1] - n0;
+        const int64_t e0 = edge_off[g], m = edge_off[g + 1] - e0;
+        if (n < 0 || m < 0 || n > 0xFFFF || 2 * m > 0xFFFF) return -1;
+        // ---- degrees: float32 sums in the order of the per-graph packer
+        // (ei pass, ej pass, self loops taken back once) --------------------
+        deg.assign((size_t)n, 0.f);
+        for (int64_t e = 0; e < m; ++e) deg[(size_t)ei[e0 + e]] += w ? w[e0 + e] : 1.f;
+        for (int64_t e = 0; e < m; ++e) deg[(size_t)ej[e0 + e]] += w ? w[e0 + e] : 1.f;
+        for (int64_t e = 0; e < m; ++e)
+            if (ei[e0 + e] == ej[e0 + e]) deg[(size_t)ei[e0 + e]] -= w ? w[e0 + e] : 1.f;
+        for (int64_t i = 0; i < n; ++i)
+            if (deg[(size_t)i] == 0.f) deg[(size_t)i] = 1.f;
+        // ---- directed nonzeros: both orientations, duplicates collapse onto
+        // their first occurrence (forward orientations first) ----------------
+        ent.resize((size_t)(2 * m));
+        for (int64_t e = 0; e < m; ++e) {
+            const int32_t a = (int32_t)ei[e0 + e], b = (int32_t)ej[e0 + e];
+            if (a < 0 || a >= n || b < 0 || b >= n) return -1;
+            ent[(size_t)e] = {a * n + b, a, b, (int32_t)e};
+            ent[(size_t)(m + e)] = {b * n + a, b, a, (int32_t)e};
+        }
+        std::stable_sort(ent.begin(), ent.end(),
+                         [](entry_t const &x, entry_t const &y) { return x.key < y.key; });
+        uniq.clear();
+        for (size_t k = 0; k < ent.size(); ++k)
+            if (k == 0 || ent[k].key != ent[k - 1].key) uniq.push_back(ent[k]);
+        const int64_t z = (int64_t)uniq.size();
+        if (zc + z > nz_capacity) return -2;
+        // ---- renumber the nodes by descending adjacency count (stable) ----
+        cnt.assign((size_t)n, 0);
+        for (auto const &u : uniq) ++cnt[(size_t)u.src];
+        order.resize((size_t)n);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(),
+                         [&](int32_t x, int32_t y) { return cnt[(size_t)x] > cnt[(size_t)y]; });
+        int64_t md = 0;
+        for (int64_t k = 0; k < n; ++k) {
+            const int32_t old = order[(size_t)k];
+            perm[n0 + k] = (uint16_t)old;
+            rank[n0 + old] = k;
+            degree[n0 + k] = deg[(size_t)old];
+            count[n0 + k] = cnt[(size_t)old];
+            md = std::max(md, cnt[(size_t)old]);
+        }
+        maxdeg[g] = md;
+        for (auto &u : uniq) {
+            u.src = (int32_t)rank[n0 + u.src];
+            u.dst = (int32_t)rank[n0 + u.dst];
+            u.key = (int64_t)u.src * n + u.dst;
+        }
+        std::sort(uniq.begin(), uniq.end(),
+                  [](entry_t const &x, entry_t const &y) { return x.key < y.key; });
+        // ---- flat views ----------------------------------------------------
+        uint16_t *rp = rowptr + n0 + g;
+        rp[0] = 0;
+        for (int64_t k = 0; k < n; ++k) rp[k + 1] = (uint16_t)(rp[k] + count[n0 + k]);
+        for (int64_t k = 0; k < z; ++k) {
+            nz[2 * (zc + k)] = (uint16_t)uniq[(size_t)k].src;
+            nz[2 * (zc + k) + 1] = (uint16_t)uniq[(size_t)k].dst;
+            eid[zc + k] = uniq[(size_t)k].e;
+        }
+        nnz[g] = z;
+        // ---- blob ----------------------------------------------------------
+        const int64_t sizes[6] = {4 * n, (int64_t)node_size * n, 2 * (n + 1), 4 * z,
+                                  (int64_t)edge_size * z, 2 * n};
+        int64_t off[6], c = 0;
+        for (int s = 0; s < 6; ++s) {
+            off[s] = c;
+            sec_off[(size_t)g * 6 + s] = c;
+            c += pad(sizes[s]);
+        }
+        const int64_t len = std::max<int64_t>(c, ALIGN);
+        if (cursor + len > blob_capacity) return -2;
+        uint8_t *B = blob + cursor;
+        std::memset(B, 0, (size_t)len);
+        std::memcpy(B + off[0], degree + n0, (size_t)(4 * n));
+        for (int64_t r = 0; r < n; ++r) {      // node row r -> its new index
+            const int64_t id = node_id[n0 + r];
+            if (id < 0 || id >= n) return -1;
+            std::memcpy(B + off[1] + rank[n0 + id] * node_size,
+                        node_rec + (size_t)(n0 + r) * node_size, (size_t)node_size);
+        }
+        std::memcpy(B + off[2], rp, (size_t)(2 * (n + 1)));
+        std::memcpy(B + off[3], nz + 2 * zc, (size_t)(4 * z));
+        for (int64_t k = 0; k < z; ++k) {
+            uint8_t *rec = B + off[4] + k * edge_size;
+            const int64_t e = e0 + eid[zc + k];
+            if (weight_bytes == 4) {
+                const float v = w ? w[e] : 1.f;
+                std::memcpy(rec, &v, 4);
+            } else if (weight_bytes == 8) {
+                const double v = (double)(w ? w[e] : 1.f);
+                std::memcpy(rec, &v, 8);
+            }
+            if (label_size > 0)
+                std::memcpy(rec + label_offset, label_rec + (size_t)e * label_size,
+                            (size_t)label_size);
+        }
+        std::memcpy(B + off[5], perm + n0, (size_t)(2 * n));
+        cursor += len;
+        zc += z;
+        blob_off[g + 1] = cursor;
+        nz_off[g + 1] = zc;
+    }
+    return 0;
+}
+
+int gdh_number_records(const uint8_t *rec, int64_t n, int32_t itemsize,
+                       const int32_t *part_off, const int32_t *part_len,
+                       int32_t n_parts, int32_t *cls, int64_t *first,
+                       int64_t *n_classes) {
+    if (n < 0 || itemsize < 0 || n_parts < 0) return -1;
+    int64_t klen = 0;
+    for (int32_t p = 0; p < n_parts; ++p) {
+        if (part_off[p] < 0 || part_len[p] < 0 || part_off[p] + part_len[p] > itemsize) return -1;
+        klen += part_len[p];
+    }
+    *n_classes = 0;
+    if (n == 0) return 0;
+    if (klen == 0) {      // no key bytes: one class
+        for (int64_t i = 0; i < n; ++i) cls[i] = 0;
+        first[0] = 0;
+        *n_classes = 1;
+        return 0;
+    }
+    const int64_t stride = klen <= 8 ? 8 : klen;
+    std::vector<uint8_t> keys((size_t)(n * stride), 0);
+    for (int64_t i = 0; i < n; ++i) {
+        uint8_t *k = keys.data() + i * stride;
+        for (int32_t p = 0; p < n_parts; ++p) {
+            std::memcpy(k, rec + i * itemsize + part_off[p], (size_t)part_len[p]);
+            k += part_len[p];
+        }
+    }
+    std::vector<int64_t> idx((size_t)n);
+    std::iota(idx.begin(), idx.end(), 0);
+    if (klen <= 8) {      // little-endian unsigned integers
+        const uint64_t *k64 = reinterpret_cast<const uint64_t *>(keys.data());
+        std::stable_sort(idx.begin(), idx.end(),
+                         [&](int64_t x, int64_t y) { return k64[x] < k64[y]; });
+        int64_t nc = 0;
+        for (int64_t t = 0; t < n; ++t) {
+            if (t == 0 || k64[idx[(size_t)t]] != k64[idx[(size_t)(t - 1)]]) first[nc++] = idx[(size_t)t];
+            cls[idx[(size_t)t]] = (int32_t)(nc - 1);
+        }
+        *n_classes = nc;
+    } else {              // byte rows, lexicographic
+        auto row = [&](int64_t i) { return keys.data() + i * stride; };
+        std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) {
+            return std::memcmp(row(x), row(y), (size_t)klen) < 0;
+        });
+        int64_t nc = 0;
+        for (int64_t t = 0; t < n; ++t) {
+            if (t == 0 || std::memcmp(row(idx[(size_t)t]), row(idx[(size_t)(t - 1)]), (size_t)klen) != 0)
+                first[nc++] = idx[(size_t)t];
+            cls[idx[(size_t)t]] = (int32_t)(nc - 1);
+        }
+        *n_classes = nc;
+    }
+    return 0;
+}
+
+int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
+                    const int32_t *n_node, const int32_t *n_nz,
+                    const int64_t *image_bytes, const int32_t *maxdeg,
+                    const uint16_t *hist, int32_t n_var, const int32_t *W,
+                    const int32_t *S, const int32_t *R, const int32_t *D,
+                    const int32_t *n_L, const int32_t *L, int32_t C,
+                    int32_t real_size, int64_t lds_limit, int32_t *choice,
+                    int64_t *NP) {
+    if (n_pairs < 0 || n_var < 0 || (C != 1 && C != 2)) return -1;
+    (void)n_nz;
+    constexpr int MAXL = 12;
+    for (int64_t t = 0; t < n_pairs; ++t) {
+        const int32_t a = ca[t], b = cb[t];
+        const int64_t n1 = n_node[a], n2 = n_node[b];
+        const int64_t N = n1 * n2, np_ = n1 * (n2 | 1);
+        NP[t] = np_;
+        choice[t] = -1;
+        const int pmd = std::max(maxdeg[a], maxdeg[b]);
+        if (pmd > 15) continue;
+        const int64_t gbytes = std::max(image_bytes[a], image_bytes[b]);
+        // cumulative sizes of the degree-pair rectangles in sorted row order
+        // (only the rectangles of classes <= pmd can be non-empty)
+        int64_t cum[256];
+        int prods[256], nr = 0;
+        {
+            const uint16_t *h1 = hist + (size_t)a * 16, *h2 = hist + (size_t)b * 16;
+            int64_t c = 0;
+            for (int u = 0; u < RECT.n_upto[pmd]; ++u) {
+                const int k = RECT.upto[pmd][u];
+                const int64_t sz = (int64_t)h1[RECT.a[k]] * h2[RECT.b[k]];
+                if (sz == 0) continue;
+                c += sz;
+                cum[nr] = c;
+                prods[nr] = RECT.prod[k];
+                ++nr;
+            }
+        }
+        auto trip_at = [&](int64_t first) -> int {   // product of sorted row `first`
+            if (first >= N) return 0;
+            int k = 0;
+            while (k < nr && cum[k] <= first) ++k;
+            return k < nr ? prods[k] : 0;
+        };
+        // one-wave walk (rows 0, 64, 128, ...): the trips of the first
+        // batches in one merged pass, shared by every W = 1 variant
+        int trips1[MAXL + 1];
+        {
+            int k = 0;
+            for (int bt = 0; bt <= MAXL; ++bt) {
+                const int64_t first = 64 * (int64_t)bt;
+                while (k < nr && cum[k] <= first) ++k;
+                trips1[bt] = (first < N && k < nr) ? prods[k] : 0;
+            }
+        }
+        for (int32_t v = 0; v < n_var; ++v) {
+            if (pmd > D[v]) continue;
+            const int64_t T = 64 * (int64_t)W[v];
+            if (N > T * R[v] || np_ >= 0xFFFF) continue;
+            const int64_t NR = T * R[v];
+            const int64_t pcap = (np_ + 1 + 3) / 4 * 4;
+            const int64_t NRy = (n_L[v] > 0 && C != 2) ? 0 : NR;
+            const int64_t lds = (pcap + NRy) * C * real_size + 4 * NR + 2 * gbytes +
+                                4 * (int64_t)W[v] * real_size + 4 * (D[v] > 6 ? 128 : 64) + 256 + 16;
+            if (lds > lds_limit) continue;
+            const int64_t nb = (N + T - 1) / T;
+            bool ok = true;
+            if (n_L[v] > 0) {      // static layout: every batch under its segment
+                for (int64_t k = 0; k < nb && ok; ++k) {
+                    const int cap = k < n_L[v] && k < MAXL ? L[(size_t)v * MAXL + k] : 0;
+                    ok = (W[v] == 1 && k <= MAXL ? trips1[k] : trip_at(k * T)) <= cap;
+                }
+            } else if (W[v] == 1 && nb <= MAXL + 1) {
+                int64_t total = 0;
+                for (int64_t k = 0; k < nb; ++k) total += trips1[k];
+                ok = total <= S[v];
+            } else {               // dynamic: the heaviest wave's slot total
+                int64_t worst = 0;
+                for (int32_t wv = 0; wv < W[v]; ++wv) {
+                    int64_t total = 0;
+                    for (int64_t k = 0; k < nb; ++k)
+                        total += trip_at(k * T + 64 * ((k & 1) ? W[v] - 1 - wv : wv));
+                    worst = std::max(worst, total);
+                }
+                ok = worst <= S[v];
+            }
+            if (ok) {
+                choice[t] = v;
+                break;
+            }
+        }
+    }
+    return 0;
+}
+
+int gdh_pair_keys(const uint32_t *jobs, int64_t n_jobs, const int32_t *cid,
+                  int32_t n_graphs, int32_t nc, int32_t *pk, int64_t *count) {
+    if (n_jobs < 0 || nc <= 0) return -1;
+    std::memset(count, 0, sizeof(int64_t) * (size_t)nc * (size_t)nc);
+    for (int64_t t = 0; t < n_jobs; ++t) {
+        const uint32_t i = jobs[2 * t], j = jobs[2 * t + 1];
+        if (i >= (uint32_t)n_graphs || j >= (uint32_t)n_graphs) return -1;
+        const int32_t k = cid[i] * nc + cid[j];
+        pk[t] = k;
+        ++count[k];
+    }
+    return 0;
+}
+
+int gdh_order_jobs(const int32_t *pk, int64_t n_jobs, const int32_t *rank_of_key,
+                   int64_t n_keys, int64_t n_ranks, uint32_t *order) {
+    if (n_jobs < 0 || n_keys < 0 || n_ranks < 0) return -1;
+    std::vector<int64_t> start((size_t)n_ranks + 1, 0);
+    for (int64_t t = 0; t < n_jobs; ++t) {
+        if (pk[t] < 0 || pk[t] >= n_keys) return -1;
+        const int32_t r = rank_of_key[pk[t]];
+        if (r < 0 || r >= n_ranks) return -1;
+        ++start[(size_t)r + 1];
+    }
+    for (int64_t r = 0; r < n_ranks; ++r) start[(size_t)r + 1] += start[(size_t)r];
+    for (int64_t t = 0; t < n_jobs; ++t) order[start[(size_t)rank_of_key[pk[t]]]++] = (uint32_t)t;
+    return 0;
+}
+
+}  // extern "C"

@@ -24,7 +24,8 @@ from ...hip import jit, runtime
 from ...microkernel import TensorProduct, Product
 from ...util.iterable import flatten, fold_like
 from ._backend import Backend
-from ._devicegraph import DeviceGraph, GraphArena, class_bytes, pack_many
+from ._devicegraph import (DeviceGraph, GraphArena, class_bytes,
+                           degree_histograms, pack_many)
 
 _TEMPLATE = os.path.join(os.path.dirname(__file__), 'template.hip')
 
@@ -186,6 +187,29 @@ def pack_theta(obj, real):
 # --------------------------------------------------------------------------
 # backend
 # --------------------------------------------------------------------------
+class ClassPairs:
+    """The jobs of a call by pair of graph classes: `pk[t]` the key of job t,
+    `upk` the sorted keys in use (position = index into the per-class-pair
+    results), `count[key]` the jobs per key."""
+
+    def __init__(self, pk, upk, count, nc):
+        self.pk, self.upk, self.count, self.nc = pk, upk, count, nc
+        self._sel = None
+
+    @property
+    def sel(self):
+        """index of every job's class pair in the per-class-pair results"""
+        if self._sel is None:
+            pos = np.zeros(self.nc * self.nc, dtype=np.int32)
+            pos[self.upk] = np.arange(len(self.upk), dtype=np.int32)
+            self._sel = pos[self.pk]
+        return self._sel
+
+    @property
+    def members(self):
+        return self.count[self.upk].astype(np.int64)
+
+
 class NotOwnerComputes(Exception):
     """Some pair of the call does not fit an owner-computes solver variant
     (raised when a feature only those solvers have was asked for)."""
@@ -328,6 +352,8 @@ class HIPBackend(Backend):
         0: never).
     nodal_gradient_in_kernel: bool
         Nodal Jacobians inside the launch (default) or by re-launches.
+    native: bool
+        Host side of a call in C++ (libgdhost.so, default) or in numpy.
     """
 
     @staticmethod
@@ -392,6 +418,14 @@ class HIPBackend(Backend):
             'min_launch', os.environ.get('GD_MIN_LAUNCH', 8192)))
         self.nodal_gradient_in_kernel = bool(kwargs.pop(
             'nodal_gradient_in_kernel', True))
+        # host side of a call (graph packing, label classes, variant per job,
+        # launch order): libgdhost.so (csrc/gdhost.cpp), or -- native=False --
+        # the numpy restatements it is tested against
+        self.native = bool(kwargs.pop(
+            'native', os.environ.get('GD_NATIVE_HOST', '1') != '0'))
+        if self.native:
+            from ...hip import hostlib
+            hostlib.lib()                  # fail loudly if it cannot be built
         if self.occupancy is None and os.environ.get('GD_OCCUPANCY'):
             # e.g. GD_OCCUPANCY="1:16:5,1:24:4"  (W:S:waves)
             self.occupancy = {
@@ -486,7 +520,8 @@ class HIPBackend(Backend):
 
     def _host_arena(self, dgraphs, fields):
         # (label classes are only numbered when the tables are in use)
-        return GraphArena(dgraphs, *fields, classes=bool(self.tables))
+        return GraphArena(dgraphs, *fields, classes=bool(self.tables),
+                          native=self.native)
 
     def _arena(self, dgraphs, fields=(None, None)):
         key = (_ids(dgraphs), fields if self.tables else None)
@@ -698,7 +733,13 @@ struct ${name}_t : ${name}_theta_t {
     #: (float (28, 5) at 5 waves is 2 % faster than at 4 but writes 2 KB of
     #: scratch per pair to HBM, profiles/r02_f32_pmc.csv: not taken)
     _OC_WAVES = {
-        (False, 1): {(1, 12, 2, 4): 6, (1, 16, 3, 4): 6, (1, 20, 3, 4): 6,
+        (False, 1): {(16,): 6, (16, 4): 6, (16, 4, 1): 5, (16, 4, 4): 5,
+                     (16, 4, 4, 1): 3, (16, 4, 4, 1, 1): 3,
+                     (16, 4, 4, 3, 1): 4, (16, 4, 4, 3, 1, 1): 4,
+                     (16, 4, 4, 4, 1, 1, 1): 3,
+                     (16, 4, 4, 4, 3, 1, 1, 1): 3,
+                     (16, 4, 4, 4, 4, 1, 1, 1, 1): 3,
+                     (1, 12, 2, 4): 6, (1, 16, 3, 4): 6, (1, 20, 3, 4): 6,
                      (1, 20, 4, 4): 4, (1, 24, 4, 4): 5, (1, 28, 5, 4): 4,
                      (1, 28, 6, 4): 4, (1, 32, 7, 4): 4, (1, 36, 9, 4): 2,
                      (1, 32, 3, 8): 2, (1, 48, 5, 8): 2, (1, 64, 9, 8): 2,
@@ -706,22 +747,46 @@ struct ${name}_t : ${name}_theta_t {
                      (4, 64, 5, 8): 3, (8, 40, 2, 8): 4, (8, 48, 3, 8): 4,
                      (8, 64, 4, 8): 2, (16, 32, 2, 8): 4, (16, 40, 2, 8): 4,
                      (16, 48, 3, 8): 4, (16, 64, 3, 8): 4},
-        (True, 1): {(1, 12, 2, 4): 4, (1, 16, 3, 4): 4, (1, 20, 3, 4): 4,
+        (True, 1): {(16,): 4, (16, 4): 4, (16, 4, 1): 3, (16, 4, 4): 3,
+                    (16, 4, 4, 1): 3, (16, 4, 4, 1, 1): 2,
+                    (16, 4, 4, 3, 1): 2, (16, 4, 4, 3, 1, 1): 2,
+                    (16, 4, 4, 4, 1, 1, 1): 2,
+                    (16, 4, 4, 4, 3, 1, 1, 1): 2,
+                    (16, 4, 4, 4, 4, 1, 1, 1, 1): 2,
+                    (1, 12, 2, 4): 4, (1, 16, 3, 4): 4, (1, 20, 3, 4): 4,
                     (1, 20, 4, 4): 3, (1, 24, 4, 4): 3, (1, 28, 5, 4): 3,
                     (1, 28, 6, 4): 3, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2,
                     (1, 64, 9, 8): 1, (4, 32, 3, 8): 3, (4, 40, 2, 8): 3,
                     (4, 64, 5, 8): 2, (8, 40, 2, 8): 2, (8, 64, 4, 8): 2},
-        (False, 2): {(1, 12, 2, 4): 4, (1, 16, 3, 4): 4, (1, 20, 3, 4): 3,
+        (False, 2): {(16,): 4, (16, 4): 4, (16, 4, 1): 4, (16, 4, 4): 2,
+                     (16, 4, 4, 1): 2, (16, 4, 4, 1, 1): 3,
+                     (16, 4, 4, 3, 1): 2, (16, 4, 4, 3, 1, 1): 3,
+                     (16, 4, 4, 4, 1, 1, 1): 3,
+                     (16, 4, 4, 4, 3, 1, 1, 1): 2,
+                     (16, 4, 4, 4, 4, 1, 1, 1, 1): 2,
+                     (1, 12, 2, 4): 4, (1, 16, 3, 4): 4, (1, 20, 3, 4): 3,
                      (1, 20, 4, 4): 2, (1, 24, 4, 4): 3, (1, 28, 5, 4): 3,
                      (1, 28, 6, 4): 2, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2},
-        (True, 2): {(1, 12, 2, 4): 3, (1, 16, 3, 4): 3, (1, 20, 3, 4): 3,
+        (True, 2): {(16,): 2, (16, 4): 2, (16, 4, 1): 2, (16, 4, 4): 2,
+                    (16, 4, 4, 1): 2, (16, 4, 4, 1, 1): 2,
+                    (16, 4, 4, 3, 1): 2, (16, 4, 4, 3, 1, 1): 2,
+                    (16, 4, 4, 4, 1, 1, 1): 1,
+                    (16, 4, 4, 4, 3, 1, 1, 1): 1,
+                    (16, 4, 4, 4, 4, 1, 1, 1, 1): 1,
+                    (1, 12, 2, 4): 3, (1, 16, 3, 4): 3, (1, 20, 3, 4): 3,
                     (1, 20, 4, 4): 2, (1, 24, 4, 4): 2, (1, 28, 5, 4): 2,
                     (1, 28, 6, 4): 2, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2},
     }
 
     #: static layouts that lose to the dynamic variants behind them in the
-    #: menu (measured, scripts/oc_sweep.py): (double?, C) -> {layout, ...}
-    _STATIC_OFF = {}
+    #: menu (measured, scripts/oc_sweep.py): (double?, C) -> {layout, ...}.
+    #: The two-right-hand-side solver in double moves 16 bytes per gathered
+    #: element: it runs at the LDS rate in either form (17-18 ns per pair for
+    #: the four-batch pairs, static or dynamic), and from six row batches on
+    #: the row-sum registers of the static form cost more than its tests save
+    #: (33.5 against 25.6 ns per pair).
+    _STATIC_OFF = {(True, 2): {(16, 4, 4, 3, 1, 1), (16, 4, 4, 4, 1, 1, 1),
+                               (16, 4, 4, 4, 3, 1, 1, 1)}}
 
     def _static_enabled(self, v, C):
         f64 = np.dtype(self.real) == np.float64
@@ -957,14 +1022,20 @@ void ${name}(params_t prm) {
         graph classes and looked up."""
         sel, out = self._classify_classes(ji, jj, dgraphs, C, tab_bytes, gtab,
                                           oc_only)
-        return out if sel is None else tuple(a[sel] for a in out)
+        return out if sel is None else tuple(a[sel.sel] for a in out)
 
     def _classify_classes(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
-                          oc_only=False):
+                          oc_only=False, jobs=None):
         """(sel, per-class-pair results): job t has the results of class pair
-        sel[t]; sel is None for short job lists (results are per job)."""
-        ji, jj = np.asarray(ji, dtype=np.int64), np.asarray(jj, dtype=np.int64)
-        if len(ji) < 4096:
+        sel.sel[t] (`ClassPairs`: class-pair key per job, jobs per key); sel is
+        None for short job lists (results are per job).  `jobs`: the job list
+        as the (u32, u32) record array ji, jj were taken from (native path)."""
+        n_jobs = len(jobs) if jobs is not None else len(ji)
+        if n_jobs < 4096:
+            if ji is None:
+                ji, jj = jobs['i'], jobs['j']
+            ji = np.asarray(ji, dtype=np.int64)
+            jj = np.asarray(jj, dtype=np.int64)
             return None, self._classify_pairs(ji, jj, dgraphs, C, tab_bytes,
                                               gtab, oc_only)
         width = max(g.max_degree for g in dgraphs) + 1
@@ -975,15 +1046,20 @@ void ${name}(params_t prm) {
         _, rep, cid = np.unique(key, axis=0, return_index=True,
                                 return_inverse=True)
         cid, nc = cid.reshape(-1).astype(np.int32), len(rep)
-        pk = cid[ji] * np.int32(nc) + cid[jj]
-        seen = np.zeros(nc * nc, dtype=bool)
-        seen[pk] = True
-        upk = np.flatnonzero(seen)
+        if self.native and jobs is not None:
+            from ...hip import hostlib
+            pk, count = hostlib.pair_keys(jobs, cid, nc)
+        else:
+            if ji is None:
+                ji, jj = jobs['i'], jobs['j']
+            ji = np.asarray(ji, dtype=np.int64)
+            jj = np.asarray(jj, dtype=np.int64)
+            pk = cid[ji] * np.int32(nc) + cid[jj]
+            count = np.bincount(pk, minlength=nc * nc)
+        upk = np.flatnonzero(count)
         out = self._classify_pairs(rep[upk // nc], rep[upk % nc], dgraphs, C,
                                    tab_bytes, gtab, oc_only)
-        pos = np.zeros(nc * nc, dtype=np.int32)
-        pos[upk] = np.arange(len(upk), dtype=np.int32)
-        return pos[pk], out
+        return ClassPairs(pk, upk, count, nc), out
 
     #: row batches the trip tables cover (static layouts have at most this many)
     TRIP_BATCHES = 12
@@ -1044,13 +1120,33 @@ void ${name}(params_t prm) {
         # `rem`: the jobs without a variant yet -- every test below runs on
         # that shrinking subset only (most jobs leave in the first variants)
         rem = np.arange(len(ji))
+        # the owner-computes menu natively (gdh_classify_oc restates the
+        # tests of the loop below), when it precedes every other variant
+        is_oc = [isinstance(v, OCVariant) for v in self.variants]
+        n_oc = sum(is_oc)
+        native_oc = (self.native and not tab_bytes and n_oc > 0
+                     and all(is_oc[:n_oc]) and len(ji) > 0
+                     and len(dgraphs) < 2**31)
+        if native_oc:
+            from ...hip import hostlib
+            menu = [(k, v) for k, v in enumerate(self.variants[:n_oc])
+                    if not v.L or self._static_enabled(v, C)]
+            hist = degree_histograms(dgraphs)
+            ch, _ = hostlib.classify_oc(
+                ji, jj, n_node, n_nz, image_oc, maxdeg, hist,
+                [(v.W, v.S, v.R, v.D, v.L) for _, v in menu], C,
+                np.dtype(self.real).itemsize, LDS_LIMIT)
+            idx = np.array([k for k, _ in menu], dtype=np.int64)
+            hit = ch >= 0
+            choice[hit] = idx[ch[hit]]
+            rem = rem[~hit]
         for k, v in enumerate(self.variants):
             if not len(rem):
                 break
             if v == GENERAL or (oc_only and not isinstance(v, OCVariant)):
                 continue
             if isinstance(v, OCVariant):
-                if tab_bytes:           # the table kernels are two-stage only
+                if tab_bytes or native_oc:  # (table kernels: two-stage only)
                     continue
                 if v.L and not self._static_enabled(v, C):
                     continue
@@ -1143,7 +1239,8 @@ void ${name}(params_t prm) {
             key = (self.uuid, np.dtype(self.real).str)
             new = [g for g in graphs if key not in g.cookie]
             if new:
-                for g, dg in zip(new, pack_many(new, real=self.real)):
+                for g, dg in zip(new, pack_many(new, real=self.real,
+                                                native=self.native)):
                     g.cookie[key] = dg
             dgraphs = _DeviceGraphList(g.cookie[key] for g in graphs)
             sig0 = dgraphs[0].signature
@@ -1173,11 +1270,9 @@ void ${name}(params_t prm) {
         """Host half of a layout: solver variant per job, launch order (by
         variant, then descending cost) and launch geometry.  No device."""
         jobs = np.ascontiguousarray(jobs)
-        ji = jobs['i'].astype(np.int64)
-        jj = jobs['j'].astype(np.int64)
         sel, (choice, cost, ntask, gbytes, NP, gbytes_oc) = \
-            self._classify_classes(ji, jj, dgraphs, C, tab_bytes, gtab,
-                                   oc_only)
+            self._classify_classes(None, None, dgraphs, C, tab_bytes, gtab,
+                                   oc_only, jobs=jobs)
         # Launch order: by variant, then descending cost, then job index.
         # `choice` ... `gbytes_oc` are per class pair (or per job when sel is
         # None); the jobs are ordered by the rank of their class pair with one
@@ -1192,7 +1287,7 @@ void ${name}(params_t prm) {
         # waves: -1 % on the full matrix, -2...8 % on 1/2...1/8 of it).
         if self.min_launch > 0:
             members_ = np.ones(len(choice), dtype=np.int64) if sel is None \
-                else np.bincount(sel, minlength=len(choice))
+                else sel.members
             used_ = sorted(set(choice.tolist()))
             for a_, k in enumerate(used_):
                 v = self.variants[k]
@@ -1226,12 +1321,20 @@ void ${name}(params_t prm) {
         if sel is None:
             order_all = by_rank.astype(np.uint32)   # (lexsort is stable)
             members = np.ones(len(choice), dtype=np.int64)
+        elif self.native:
+            # stable counting sort of the jobs by the rank of their class pair
+            from ...hip import hostlib
+            rank_of_key = np.full(sel.nc * sel.nc, -1, dtype=np.int32)
+            rank_of_key[sel.upk] = rank_of
+            order_all = hostlib.order_jobs(sel.pk, rank_of_key,
+                                           int(rank_of.max()) + 1)
+            members = sel.members
         else:
-            rank = rank_of[sel]
+            rank = rank_of[sel.sel]
             rank = rank.astype(np.uint16 if len(choice) <= 0xFFFF
                                else np.uint32)
             order_all = np.argsort(rank, kind='stable').astype(np.uint32)
-            members = np.bincount(sel, minlength=len(choice))
+            members = sel.members
         used = sorted(set(choice.tolist()))
         rsize = np.dtype(self.real).itemsize
         n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)

@@ -53,6 +53,19 @@ SECTIONS = ('degree', 'node', 'rowptr', 'nz', 'edge', 'perm')
 NZ_DTYPE = np.dtype([('i', np.uint16), ('j', np.uint16)])
 
 
+def degree_histograms(dgraphs):
+    """(n_graphs, 16) degree histograms of packed graphs in one pass."""
+    n = len(dgraphs)
+    hist = np.zeros((n, HIST_BINS), dtype=np.int64)
+    if n:
+        n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
+        gid = np.repeat(np.arange(n), n_node)
+        cnt = np.minimum(np.concatenate(
+            [g.adjacency_count for g in dgraphs]), HIST_BINS - 1)
+        np.add.at(hist, (gid, cnt), 1)
+    return hist
+
+
 @cpptype(ptr=np.intp, size=np.int32)
 class FrozenArray(np.ndarray):
     """An ndarray slice that packs as {pointer, length}; the pointer is a
@@ -292,6 +305,15 @@ class DeviceGraph:
             return self._max_degree
 
     @property
+    def degree_hist(self):
+        """hist field of the graph header (cached)."""
+        try:
+            return self._degree_hist
+        except AttributeError:
+            self._degree_hist = degree_histogram(self.adjacency_count)
+            return self._degree_hist
+
+    @property
     def state(self):
         raise AttributeError(
             'DeviceGraph has no absolute-address state; headers are produced '
@@ -309,8 +331,122 @@ def _scalar_frame(df):
     return tuple(out)
 
 
-def pack_many(graphs, real=np.float32):
-    """Pack a whole list of graphs in one vectorised pass.
+def pack_many(graphs, real=np.float32, native=True):
+    """Pack a whole list of graphs in one pass: the native packer
+    (`gdh_pack_graphs`, csrc/gdhost.cpp: degrees, directed nonzeros, degree
+    renumbering, CSR and the blobs of all graphs in C++; numpy only
+    concatenates the input tables and builds the AoS records), or with
+    `native=False` the vectorised numpy restatement below -- the
+    specification the native results are held to, byte for byte
+    (tests/test_host_model.py).  The batched counterpart of the reference's
+    per-graph ``OctileGraph.__init__``
+    (``graphdot/kernel/marginalized/_octilegraph.py:37-177``).  Graphs with
+    variable-length attributes, or whose tables differ in columns / types from
+    the first graph's, are packed one by one.  Returns the list of DeviceGraph
+    objects; their blobs are views into one shared buffer."""
+    if not native:
+        return pack_many_numpy(graphs, real)
+    from ...hip import hostlib
+    real = np.dtype(real).type
+    graphs = list(graphs)
+    if not graphs:
+        return []
+    sig_n, sig_e = _scalar_frame(graphs[0].nodes), _scalar_frame(graphs[0].edges)
+    # same tables as the first graph's: by the row types the kernel's type
+    # check left in the cookies (Graph.has_unified_types) when they are there
+    # -- equal row types are equal column names and types -- else column by
+    # column
+    rt0 = graphs[0].cookie.get('rowtypes') if hasattr(
+        graphs[0].cookie, 'get') else None
+
+    def same(g):
+        rt = g.cookie.get('rowtypes') if rt0 is not None else None
+        if rt is not None:
+            return (rt[0] is rt0[0] or rt[0] == rt0[0]) and \
+                (rt[1] is rt0[1] or rt[1] == rt0[1])
+        return _scalar_frame(g.nodes) == sig_n and \
+            _scalar_frame(g.edges) == sig_e
+    batch = [k for k, g in enumerate(graphs)
+             if sig_n is not None and sig_e is not None and same(g)
+             and len(g.nodes._data['!i']) <= 0xFFFF
+             and 2 * len(g.edges._data['!i']) <= 0xFFFF]
+    out = [None] * len(graphs)
+    for k in sorted(set(range(len(graphs))) - set(batch)):
+        out[k] = DeviceGraph(graphs[k], real=real)
+    if not batch:
+        return out
+    gs = [graphs[k] for k in batch]
+    G = len(gs)
+
+    def cat(frames, key):
+        return np.concatenate([f._data[key] for f in frames])
+
+    nframes, eframes = [g.nodes for g in gs], [g.edges for g in gs]
+    n = np.array([len(f._data['!i']) for f in nframes], dtype=np.int64)
+    m = np.array([len(f._data['!i']) for f in eframes], dtype=np.int64)
+    node0 = np.concatenate(([0], np.cumsum(n)))
+    edge0 = np.concatenate(([0], np.cumsum(m)))
+    Nn, Ne = int(node0[-1]), int(edge0[-1])
+    weighted = '!w' in eframes[0]
+    w = cat(eframes, '!w').astype(np.float32) if weighted else None
+    # record types from the first graph (phantom labels included)
+    nodes0 = nframes[0].copy(deep=False)
+    edges0 = eframes[0].copy(deep=False)
+    if len(nodes0.columns) == 1:
+        nodes0['labeled'] = np.zeros(len(nodes0), np.bool_)
+    if len(edges0.columns) == 2:
+        edges0['labeled'] = np.zeros(len(edges0), np.bool_)
+    node_t = _widen(nodes0.drop(['!i']).rowtype(), real)
+    label_t = _widen(edges0.drop(['!i', '!j', '!w']).rowtype(), real)
+    edge_t = (np.dtype([('weight', real), ('label', label_t)], align=True)
+              if weighted else label_t)
+    # AoS records in input row order (the packer moves them into place)
+    node_rec = np.zeros(Nn, dtype=node_t)
+    for name in node_t.names:
+        if name == 'labeled' and name not in nframes[0]:
+            continue
+        node_rec[name] = cat(nframes, name).astype(node_t.fields[name][0])
+    label_rec = np.zeros(Ne, dtype=label_t)
+    for name in label_t.names or ():
+        if name == 'labeled' and name not in eframes[0]:
+            continue
+        label_rec[name] = cat(eframes, name).astype(label_t.fields[name][0])
+    r = hostlib.pack_graphs(
+        node0, edge0, cat(nframes, '!i'), cat(eframes, '!i'),
+        cat(eframes, '!j'), w, node_rec, label_rec, edge_t.itemsize,
+        edge_t.fields['label'][1] if weighted else 0,
+        np.dtype(real).itemsize if weighted else 0)
+    signature = (weighted, str(node_t), str(edge_t))
+    nz_all = r['nz'].view(NZ_DTYPE)
+    buf, blob0, nz0 = r['blob'], r['blob_off'], r['nz_off']
+    offs = r['sec_off'].tolist()
+    maxdeg = r['maxdeg'].tolist()
+    nnz = r['nnz'].tolist()
+    nl, b0l, z0l, n0l = n.tolist(), blob0.tolist(), nz0.tolist(), node0.tolist()
+    for b_, k in enumerate(batch):
+        dg = DeviceGraph.__new__(DeviceGraph)
+        a, z = n0l[b_], n0l[b_ + 1]
+        za, zz = z0l[b_], z0l[b_ + 1]
+        dg.n_node, dg.n_nz, dg.weighted = nl[b_], nnz[b_], weighted
+        dg.perm = r['perm'][a:z]
+        dg.rank = r['rank'][a:z]
+        dg.degree = r['degree'][a:z]
+        dg.adjacency_count = r['count'][a:z]
+        dg.nz = nz_all[za:zz]
+        dg.rowptr = r['rowptr'][a + b_:z + b_ + 1]
+        dg.edge_index = r['eid'][za:zz]
+        dg.node_t, dg.edge_t, dg.signature = node_t, edge_t, signature
+        dg.offsets = dict(zip(SECTIONS, offs[b_]))
+        dg.image_bytes = _pad(dg.offsets['perm'] + 2 * dg.n_node)
+        dg.relocs = np.zeros(0, dtype=np.int64)
+        dg._max_degree = maxdeg[b_]
+        dg.blob = buf[b0l[b_]:b0l[b_ + 1]]
+        out[k] = dg
+    return out
+
+
+def pack_many_numpy(graphs, real=np.float32):
+    """Pack a whole list of graphs in one vectorised pass (numpy).
 
     Replaces one `DeviceGraph(graph)` call per graph (0.2-0.3 ms each, the
     dominant cost of a first kernel evaluation) by numpy operations over the
@@ -511,14 +647,15 @@ def class_bytes(n_node, n_nz):
         // _ALIGN * _ALIGN
 
 
-def _label_classes(dgraphs, vfields=None, efields=None, max_classes=255):
+def _label_classes(dgraphs, vfields=None, efields=None, max_classes=255,
+                   native=True):
     """Number the distinct node records and the distinct edge *labels* (the
     weight of a weighted edge is not part of its class) over all graphs,
     looking only at the attributes `vfields` / `efields` (None: all) -- the
     ones the microkernels read.  Returns None if some graph carries
     variable-length attributes or there are too many classes; else
-    (per-graph node class ids, per-graph edge class ids, representatives
-    node_t[NV], representatives edge_t[NE])."""
+    (node class ids of all graphs back to back, edge class ids likewise,
+    representatives node_t[NV], representatives edge_t[NE])."""
     if not dgraphs or any(len(g.relocs) for g in dgraphs):
         return None
     g0 = dgraphs[0]
@@ -536,6 +673,18 @@ def _label_classes(dgraphs, vfields=None, efields=None, max_classes=255):
             keys = records if dt.itemsize else None
         if keys is None or len(records) == 0 or keys.dtype.itemsize == 0:
             return np.zeros(len(records), np.int64), records[:1]
+        if native:
+            # gdh_number_records: the same numbering (np.unique order) from
+            # the key byte ranges of the records, no repacked copy
+            from ...hip import hostlib
+            parts = [(0, dt.itemsize)] if fields is None else \
+                [(dt.fields[f][1], dt.fields[f][0].itemsize)
+                 for f in sorted(fields)]
+            inv, first = hostlib.number_records(records, parts)
+            rec = np.ascontiguousarray(records).view(np.uint8).reshape(
+                len(records), dt.itemsize)[first]
+            return inv.astype(np.int64), \
+                np.ascontiguousarray(rec).view(dt).reshape(-1)
         raw = np.ascontiguousarray(keys).view(np.uint8).reshape(
             len(keys), keys.dtype.itemsize)
         if raw.shape[1] <= 8:
@@ -592,9 +741,8 @@ def _label_classes(dgraphs, vfields=None, efields=None, max_classes=255):
         return None
     n_node = np.array([g.n_node for g in dgraphs])
     n_nz = np.array([g.n_nz for g in dgraphs])
-    ncls = np.split(ncls.astype(np.uint8), np.cumsum(n_node)[:-1])
-    ecls = np.split(ecls.astype(np.uint8), np.cumsum(n_nz)[:-1])
-    return ncls, ecls, vrep, erep
+    # (flat: the node classes of all graphs back to back, likewise the edges)
+    return ncls.astype(np.uint8), ecls.astype(np.uint8), vrep, erep
 
 
 class GraphArena:
@@ -609,10 +757,12 @@ class GraphArena:
     with one contiguous copy.  `classes` is None when the labels cannot be
     numbered (`_label_classes`); the sections are then zero."""
 
-    def __init__(self, dgraphs, vfields=None, efields=None, classes=True):
+    def __init__(self, dgraphs, vfields=None, efields=None, classes=True,
+                 native=True):
         self.n = len(dgraphs)
         hdr_bytes = _pad(self.n * HEADER_DTYPE.itemsize)
-        cls = _label_classes(dgraphs, vfields, efields) if classes else None
+        cls = _label_classes(dgraphs, vfields, efields, native=native) \
+            if classes else None
         self.classes = None
         cursor = hdr_bytes
         if cls is not None:
@@ -638,24 +788,33 @@ class GraphArena:
                 erep.view(np.uint8).ravel() if erep.nbytes else []
         self._relocs = []
         hdr = np.zeros(self.n, dtype=HEADER_DTYPE)
-        for k, (g, s) in enumerate(zip(dgraphs, starts)):
+        n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
+        n_nz = np.array([g.n_nz for g in dgraphs], dtype=np.int64)
+        for g, s in zip(dgraphs, starts.tolist()):
             self.host[s:s + len(g.blob)] = g.blob
-            if cls is not None:
-                c0 = s - cbytes[k]
-                self.host[c0:c0 + g.n_node] = ncls[k]
-                c1 = c0 + (g.n_node + 3) // 4 * 4
-                self.host[c1:c1 + g.n_nz] = ecls[k]
-            hdr['n_node'][k] = g.n_node
-            hdr['n_nz'][k] = g.n_nz
-            hdr['hist'][k] = degree_histogram(g.adjacency_count)
-            for name in SECTIONS:
-                hdr[name][k] = s + g.offsets[name]   # arena-relative for now
             if len(g.relocs):
                 self._relocs.append(g.relocs + s)
                 words = self.host
                 for where in g.relocs + s:
                     word = words[where:where + 8].view(np.uint64)
                     word[0] += np.uint64(s)
+        if self.n:
+            hdr['n_node'], hdr['n_nz'] = n_node, n_nz
+            for name in SECTIONS:          # arena-relative for now
+                hdr[name] = starts + np.array(
+                    [g.offsets[name] for g in dgraphs], dtype=np.int64)
+            hdr['hist'] = degree_histograms(dgraphs)
+            if cls is not None:
+                # class ids in front of every blob: [node classes, padded to
+                # 4][edge classes], one scatter per kind
+                c0 = starts - cbytes
+                node0 = np.cumsum(n_node) - n_node
+                self.host[np.repeat(c0 - node0, n_node)
+                          + np.arange(int(n_node.sum()))] = ncls
+                c1 = c0 + (n_node + 3) // 4 * 4
+                nz0 = np.cumsum(n_nz) - n_nz
+                self.host[np.repeat(c1 - nz0, n_nz)
+                          + np.arange(int(n_nz.sum()))] = ecls
         self._hdr = hdr
         self._relocs = (np.concatenate(self._relocs) if self._relocs
                         else np.zeros(0, np.int64))

@@ -10,6 +10,9 @@ import numpy as np
 from .series import Series
 
 
+_ROWTYPES = {}
+
+
 class DataFrame:
 
     def __init__(self, data=None):
@@ -58,14 +61,29 @@ class DataFrame:
     def rowtype(self, pack=True):
         """Aligned struct dtype of one row; with ``pack`` the fields are
         ordered by decreasing item size (stable) to minimise padding."""
+        # (memoised on the columns' names and types: the graphs of a data set
+        # share one row type, and building a struct dtype takes ~30 us)
+        try:
+            key = (pack, tuple((k, c.concrete_type)
+                               for k, c in self._data.items()))
+            hit = _ROWTYPES.get(key)
+        except TypeError:                  # an unhashable concrete type
+            key = hit = None
+        if hit is not None:
+            return hit
         cols = self.columns
         ctypes = {k: np.dtype(self[k].concrete_type) for k in cols}
         if pack:
             order = np.argsort([-ctypes[k].itemsize for k in cols],
                                kind='stable')
             cols = [cols[i] for i in order]
-        return np.dtype([(k, ctypes[k].newbyteorder('=')) for k in cols],
-                        align=True)
+        out = np.dtype([(k, ctypes[k].newbyteorder('=')) for k in cols],
+                       align=True)
+        if key is not None:
+            if len(_ROWTYPES) > 256:
+                _ROWTYPES.clear()
+            _ROWTYPES[key] = out
+        return out
 
     def rows(self, rowname='row'):
         """Iterate rows as named tuples (columns whose names are not valid

@@ -35,6 +35,27 @@ def test_library_exports_every_declared_symbol():
     assert b'gfx950' in L.gd_version()
 
 
+def test_host_library_exports_every_declared_symbol():
+    """include/gdhost.h (packer, label classes, classification, job layout)
+    against libgdhost.so and its ctypes signatures; bad arguments are
+    reported, not crashed on."""
+    from graphdot_amd.hip import hostlib
+    text = open(os.path.join(ROOT, 'include', 'gdhost.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    names = sorted(set(re.findall(r'\b(gdh_[a-z0-9_]+)\s*\(', text)))
+    assert len(names) == 6
+    L = hostlib.lib()
+    for name in names:
+        assert hasattr(L, name), name
+        assert name in hostlib.SIGNATURES or name == 'gdh_version', name
+    assert b'gdhost' in L.gdh_version()
+    jobs = np.array([(0, 5)], dtype=[('i', np.uint32), ('j', np.uint32)])
+    with pytest.raises(hostlib.HostLibError):      # graph 5 of 2
+        hostlib.pair_keys(jobs, np.zeros(2, np.int32), 1)
+    with pytest.raises(hostlib.HostLibError):      # rank out of range
+        hostlib.order_jobs(np.zeros(3, np.int32), np.array([4], np.int32), 2)
+
+
 def test_device_calls_fail_loudly_without_a_gpu():
     """No silent CPU fallback: with no device the ABI reports an error."""
     L = runtime.lib()

@@ -318,7 +318,8 @@ def test_graph_list_identity_cache_dies_with_the_cookie_epoch():
 
 
 def test_batch_packer_is_byte_identical_to_the_per_graph_packer():
-    """`pack_many` (one vectorised pass over all graphs of a call, SURVEY 8f
+    """`pack_many` (all graphs of a call in one pass -- natively in
+    libgdhost.so, `gdh_pack_graphs`, or the numpy restatement; SURVEY 8f
     rank 1; reference: _octilegraph.py:37-177 once per graph) produces the
     very blobs, permutations and CSR arrays of `DeviceGraph(graph)`, for
     labeled / weighted / unlabeled graphs, self loops, both arithmetics, and
@@ -334,9 +335,21 @@ def test_batch_packer_is_byte_identical_to_the_per_graph_packer():
     M = load('mlgk_cases.json')
     sets += [graphs_from(M[name]['graphs']) for name in
              ('unlabeled', 'labeled', 'weighted', 'vario-features')]
+    # self loops and repeated edges (duplicates collapse onto their first
+    # occurrence), an isolated node (degree 0 -> 1)
+    from graphdot_amd.graph import Graph
+    odd = [Graph(nodes={'!i': [0, 1, 2, 3], 'f': [1.0, 2.0, 3.0, 4.0]},
+                 edges={'!i': [0, 1, 1, 0, 2], '!j': [1, 0, 1, 1, 2],
+                        '!w': [0.5, 2.0, 1.5, 4.0, 0.25],
+                        'len': [1.0, 2.0, 3.0, 4.0, 5.0]}),
+           Graph(nodes={'!i': [1, 0, 2], 'f': [1.0, 2.0, 3.0]},
+                 edges={'!i': [2, 0], '!j': [0, 1], '!w': [1.0, 3.0],
+                        'len': [0.5, 0.25]})]
+    sets.append(Graph.unify_datatype(odd))
     for G in sets:
         for real in (np.float32, np.float64):
-            a = pack_many(G, real)
+          for native in (True, False):      # libgdhost.so / numpy restatement
+            a = pack_many(G, real, native=native)
             b = [DeviceGraph(g, real) for g in G]
             for x, y in zip(a, b):
                 assert x.signature == y.signature
@@ -349,6 +362,61 @@ def test_batch_packer_is_byte_identical_to_the_per_graph_packer():
                 assert np.array_equal(x.adjacency_count, y.adjacency_count)
                 assert np.array_equal(x.edge_index, y.edge_index)
                 assert np.array_equal(x.relocs, y.relocs)
-            A, B = GraphArena(a), GraphArena(b)
+                assert np.array_equal(x.degree, y.degree)
+                assert np.array_equal(x.rowptr, y.rowptr)
+                assert np.array_equal(x.nz, y.nz)
+                assert x.max_degree == y.max_degree
+            # label classes numbered natively (gdh_number_records) and by
+            # numpy: the same arena, byte for byte
+            A, B = GraphArena(a, native=native), GraphArena(b, native=False)
             assert np.array_equal(A.relocated(1 << 20), B.relocated(1 << 20))
             assert (A.classes is None) == (B.classes is None)
+            assert A.classes == B.classes
+
+
+def test_native_job_layout_equals_the_numpy_restatement():
+    """The per-call host work in libgdhost.so (`gdh_classify_oc`: solver
+    variant per pair of graph classes; `gdh_pair_keys` / `gdh_order_jobs`:
+    class pair of every job and the launch order by a stable counting sort)
+    gives exactly the layout of the numpy implementation: the same variants
+    in use, the same launch geometry, the same job order -- for the molecular
+    set (static layouts), configuration 2 (dynamic one- and multi-wave
+    variants), both arithmetics, value and value + gradient, full and X x Y
+    job lists, and for a menu the native classifier does not cover."""
+    import cases
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._backend_hip import (
+        HIPBackend, VARIANTS, OC_VARIANTS, GENERAL)
+    job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
+
+    def triu(n):
+        i, j = np.triu_indices(n)
+        return np.column_stack((i, j)).astype(np.uint32).ravel().view(job_t)
+
+    def cross(nx, ny):
+        i, j = np.indices((nx, ny))
+        return np.column_stack((i.ravel(), j.ravel() + nx)).astype(
+            np.uint32).ravel().view(job_t)
+
+    sets = [(cases.config3_graphs(150, seed=4), cases.config3_kernels()),
+            (cases.config2_graphs(100, seed=2), cases.config2b_kernels())]
+    for G, (kn, ke, q) in sets:
+        # (>= 4096 jobs: classified per pair of graph classes; fewer: per job)
+        for jobs in (triu(len(G)), cross(50, len(G) - 50)):
+            for real in (np.float32, np.float64):
+                for C in (1, 2):
+                    for menu in (None, VARIANTS + OC_VARIANTS + [GENERAL]):
+                        out = []
+                        for native in (True, False):
+                            kw = {} if menu is None else {'variants': menu}
+                            b = HIPBackend(real=real, native=native, **kw)
+                            k = MarginalizedGraphKernel(kn, ke, q=q, backend=b)
+                            dgs, _, _, fields = b._graphs_and_kernels(
+                                G, kn, ke, k.traits(symmetric=True))
+                            arena = b._host_arena(dgs, fields)
+                            out.append(b._partition(
+                                dgs, jobs, C, 0, b._global_tables(arena)))
+                        (_, ua, oa, La), (_, ub, ob, Lb) = out
+                        assert ua == ub and La == Lb
+                        assert np.array_equal(oa, ob)
+                        assert sorted(oa.tolist()) == list(range(len(jobs)))
