@@ -227,6 +227,9 @@ class Layout:
 
 #: code objects loaded in this process, by JIT cache key (shared by backends)
 _MODULES = {}
+#: rendered translation units, by (code signature, variant, build options):
+#: pure text work on hyperparameter-independent inputs, shared by backends
+_SOURCES = {}
 #: HIP streams / events are expensive to create (milliseconds each): every
 #: LaunchSet draws from this process-wide pool, in order
 _STREAM_POOL, _EVENT_POOL = [], []
@@ -440,7 +443,7 @@ class HIPBackend(Backend):
         self._pool = {}                    # name -> DeviceBuffer (grow-only)
         self._dgraph_lists = IdentityCache()
         self._layouts = OrderedDict()      # job-list key -> Layout (LRU)
-        self._source_cache = {}            # (code signature, variant) -> text
+        self._source_cache = _SOURCES      # (code signature, variant) -> text
         self.layout_cache_size = 8
         self._props = None
         self.last_plan = None
@@ -1403,8 +1406,14 @@ void ${name}(params_t prm) {
         todo = [(k, self.variants[k]) for k in used]
         if gtab and any(isinstance(v, OCVariant) for _, v in todo):
             todo.append(('tables', TABLES))
+        opts = (np.dtype(self.real).str, tuple(self.hipcc_extra), WPB1,
+                self.tables)
         for k, v in todo:
-            key = (sig, k)
+            # (the entry point also carries the variant's occupancy target)
+            waves = None if v in (GENERAL, TABLES) else (
+                self._oc_waves(v, C, ngrad) if ngrad and isinstance(
+                    v, OCVariant) else self.waves_per_eu(v, C))
+            key = (sig, tuple(v), waves, opts)
             if key not in self._source_cache:
                 self._source_cache[key] = self.render_source(
                     node_kernel, edge_kernel, p, dgraphs[0].node_t,
