@@ -58,7 +58,10 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', type=int, default=3, choices=[2, 3])
+    ap.add_argument('--config', default='3',
+                    choices=['2', '3', 'nws48', 'tang2019'])
+    ap.add_argument('--batch', default='1,16,128',
+                    help='--config nws48: batch sizes of the reference harness')
     ap.add_argument('--graphs', type=int, default=None,
                     help='number of graphs (default: 1000 for config 3, '
                          '256 for config 2)')
@@ -108,6 +111,23 @@ def algorithmic_bytes(arena, ji, jj, rsize, n_cols):
     return (blob[ji] + blob[jj] + 64 + rsize * n_cols).astype(np.int64)
 
 
+def survey_bytes_per_graph(graphs):
+    """the compulsory HBM bytes of one graph in the
+    REFERENCE's device layout -- 32-byte header, per node the AoS record
+    (fp32 attributes) + 4-byte degree, per directed nonzero the edge record,
+    32 bytes per non-empty 8 x 8 adjacency tile (octile header)."""
+    from graphdot_amd.kernel.marginalized._devicegraph import pack_many
+    dgs = pack_many(graphs, real=np.float32)
+    out = np.zeros(len(dgs), dtype=np.int64)
+    for k, g in enumerate(dgs):
+        oi = g.perm[g.nz['i']].astype(np.int64)     # original node ids
+        oj = g.perm[g.nz['j']].astype(np.int64)
+        n_octile = len(np.unique((oi // 8) * 65536 + oj // 8))
+        out[k] = 32 + g.n_node * (np.dtype(g.node_t).itemsize + 4) \
+            + g.n_nz * np.dtype(g.edge_t).itemsize + 32 * n_octile
+    return out
+
+
 def algorithmic_flops(n_node, n_nz, ji, jj, iters, Fv=9, Fe=8):
     """k (2 nnzx + 17 N) + nnzx F_e + N F_v (cached edge/node values)."""
     N = n_node[ji] * n_node[jj]
@@ -142,6 +162,17 @@ class LocalStep:
 
 def workload(args):
     import cases
+    if args.config == 'tang2019':
+        n = args.graphs or 256
+        graphs = cases.tang2019_graphs(n)
+        knode, kedge, q = cases.tang2019_kernels()
+        name = (f'Tang2019-style dense molecular graphs ({n} from_ase-like '
+                'molecules, <= 23 atoms, tent-weighted adjacency within '
+                '3 sqrt(r_i r_j): 88 % dense, degree up to 22; seed 2019, '
+                f'{n * (n + 1) // 2} pairs incl. diagonal), '
+                'Tang2019MolecularKernel: KroneckerDelta(0.2) element x '
+                'SquareExponential(0.05) length, q=0.01')
+        return graphs, knode, kedge, q, name, (2, 6)
     if args.config == 3:
         n = args.graphs or 1000
         graphs = cases.config3_graphs(n)
@@ -363,8 +394,102 @@ def spawn_ranks(n):
     return subprocess.call(cmd)
 
 
+def nws48_line(args):
+    """`--config nws48`: the reference's own benchmark harness
+    (benchmark/kernel/marginalized/time_kernel.py:43-72): `batch` graphs of 48
+    nodes (one Newman-Watts-Strogatz topology, random labels and weights),
+    KroneckerDelta label kernels; first launch = a fresh kernel object's first
+    evaluation (graph packing, job layout, code-object load from the JIT
+    cache -- the reference compiles CUDA here -- upload, solve, download),
+    second launch = the same evaluation again; numpy in, numpy out."""
+    import cases
+    from graphdot_amd.hip import runtime
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    real = np.float32 if args.dtype == 'f32' else np.float64
+    runtime.ensure_device()
+    runtime.DeviceBuffer(1 << 20)             # context and allocator are up
+    knode, kedge, q = cases.nws48_kernels()
+    rows = []
+    for batch in [int(b) for b in args.batch.split(',')]:
+        graphs = cases.nws48_graphs(batch)
+        first, second = [], []
+        for rnd in range(4):                  # (round 0 loads the code objects)
+            for g in graphs:
+                for key in [k_ for k_ in g.cookie if k_ != 'rowtypes']:
+                    del g.cookie[key]
+            kernel = MarginalizedGraphKernel(
+                knode, kedge, q=q, backend=HIPBackend(real=real))
+            t0 = time.perf_counter()
+            K = kernel(graphs, nodal=False)
+            first.append(time.perf_counter() - t0)
+            for _ in range(3):
+                t0 = time.perf_counter()
+                kernel(graphs, nodal=False)
+                second.append(time.perf_counter() - t0)
+        plan = kernel.backend.last_plan
+        n_pairs = batch * (batch + 1) // 2
+        rows.append({
+            'batch': batch, 'pairs': n_pairs,
+            'first_launch_cold_ms': 1e3 * first[0],
+            'first_launch_ms': 1e3 * float(np.median(first[1:])),
+            'second_launch_ms': 1e3 * float(np.median(second[3:])),
+            'launches': [[L['variant'].W, L['variant'].S, L['variant'].R,
+                          int(L['count'])] for L in plan.launches],
+            'finite': bool(np.all(np.isfinite(K))),
+            'symmetric': bool(np.array_equal(K, K.T))})
+    big = rows[-1]
+    return {
+        'metric': 'graph-pairs/sec (Gram matrix, 2nd launch, numpy in/out)',
+        'value': big['pairs'] / (1e-3 * big['second_launch_ms']),
+        'unit': 'graph-pairs/s', 'n_gpus': 1, 'steps': 9, 'warmup': 1,
+        'ms_per_step': big['second_launch_ms'], 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': args.dtype,
+        'data': 'synthetic',
+        'config': {'workload': 'reference benchmark harness '
+                               '(time_kernel.py:14-72): batches of 48-node '
+                               'NWS graphs (k=5, p=0.05, seed 0), integer '
+                               'node / edge labels, weights 1..4, '
+                               'KroneckerDelta(0.5) kernels, q=0.01; '
+                               f'value: batch {big["batch"]}, 2nd launch',
+                   'graphs': big['batch'], 'pairs': big['pairs'],
+                   'parallelism': 'single'},
+        'latency': rows,
+        'note': 'host-, PCIe- and conversion-inclusive latencies of the '
+                'public API; first_launch_cold_ms also loads the code '
+                'objects from the on-disk JIT cache',
+        'roofline': None, 'cpu_baseline': None}
+
+
+def effective_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the
+    container's CPU quota (cgroup v2 cpu.max / v1 cfs quota)."""
+    n = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return n, quota
+
+
 def main():
     args = parse()
+    if args.config in ('2', '3'):
+        args.config = int(args.config)
+    if args.config == 'nws48':
+        if args.dtype is None:
+            args.dtype = 'f32'
+        print(json.dumps(nws48_line(args)), flush=True)
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -400,10 +525,10 @@ def main():
     from graphdot_amd.kernel.marginalized._sharded import ShardedStep
 
     real = np.float32 if args.dtype == 'f32' else np.float64
-    # sharded: no launch merging, like `distributed_backend` -- which solver
-    # variant a pair runs on must not depend on the rank count
-    backend = HIPBackend(device=local_rank, real=real, record_iterations=True,
-                         **({'min_launch': 0} if sharded else {}))
+    # (sharded: launch merging is decided on the whole job list and applied
+    # by every rank -- ShardPlan.merge_map -- so which solver variant a pair
+    # runs on does not depend on the rank count)
+    backend = HIPBackend(device=local_rank, real=real, record_iterations=True)
     graphs, knode, kedge, q, workload_name, (Fv, Fe) = workload(args)
     kernel = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
     n = len(graphs)
@@ -524,18 +649,21 @@ def main():
     # ---- per-launch algorithmic work ---------------------------------------------
     arena = plan.keep[0]
     iters_all = backend.iterations(plan).astype(np.int64)
-    per_kernel, tot = [], dict(bytes=0, flops=0, lds=0)
+    sbytes = survey_bytes_per_graph(graphs)
+    per_kernel, tot = [], dict(bytes=0, flops=0, lds=0, image=0)
     for k, L in enumerate(plan.launches):
         ids = plan.order_host[L['offset']:L['offset'] + L['count']]
         lj = local_jobs[ids]
         lji, ljj = lj['i'].astype(np.int64), lj['j'].astype(np.int64)
         it_ = iters_all[ids]
         ab = int(algorithmic_bytes(arena, lji, ljj, rsize, n_cols).sum())
+        sb = int((sbytes[lji] + sbytes[ljj] + rsize * n_cols).sum())
         af = int(algorithmic_flops(n_node, n_nz, lji, ljj, it_, Fv, Fe).sum()
                  * mult)
         al = int(algorithmic_lds_reals(n_node, n_nz, lji, ljj, it_).sum()
                  * rsize * mult)
-        tot['bytes'] += ab
+        tot['bytes'] += sb
+        tot['image'] += ab
         tot['flops'] += af
         tot['lds'] += al
         per_kernel.append({
@@ -545,7 +673,8 @@ def main():
             'avg_ms': float(kernel_ms[k]),
             'isolated_ms': float(isolated_ms[k]) if isolated_ms is not None
             else None,
-            'algorithmic_bytes': ab, 'algorithmic_flops': af,
+            'algorithmic_bytes': sb, 'image_bytes': ab,
+            'algorithmic_flops': af,
             'algorithmic_lds_bytes': al,
             'mean_cg_iterations': float(it_.mean()) if len(it_) else 0.0})
 
@@ -560,7 +689,17 @@ def main():
         'unit': 'GB/s',
         'frac': D['algorithmic_bytes'] / dur / 1e9 / HBM_PEAK_GBS,
         'traffic': None,
+        'achieved_is': 'ALGORITHMIC bytes / launch duration (SURVEY.md 8d: '
+                       'both graphs in the reference\'s device layout -- '
+                       '32 B header, node records + 4 B degrees, edge '
+                       'records, 32 B per octile -- plus the result), not a '
+                       'measured rate: see achieved_measured_GBs',
+        'achieved_measured_GBs': None,
         'algorithmic_bytes_per_launch': D['algorithmic_bytes'],
+        'image_bytes_per_launch': D['image_bytes'],
+        'image_bytes_note': 'what this build actually stages per pair: its '
+                            'own packed images (CSR + label-class ids, fp64 '
+                            'attributes in the fp64 build) + 2 x 64 B headers',
         'pairs_per_launch': D['pairs'],
         'avg_launch_ms': float(basis[dom]),
         'duration_basis': 'isolated: the launch alone on one stream, HIP '
@@ -588,6 +727,8 @@ def main():
             # FETCH_SIZE counts at half its bytes on gfx950
             # (MI355X_MICROARCH.md, HBM): 2 x FETCH_SIZE + WRITE_SIZE
             roofline['traffic'] = tr['hbm_bytes_per_launch_fetch_x2']
+            roofline['achieved_measured_GBs'] = \
+                tr['hbm_bytes_per_launch_fetch_x2'] / dur / 1e9
             roofline['traffic_source'] = 'profiles/traffic.json (rocprofv3 ' \
                 '2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)'
     except (OSError, KeyError, ValueError):
@@ -609,6 +750,7 @@ def main():
         'ms_per_step': ms_per_step, 'launches': nL,
         'pairs': int(sum(d['pairs'] for d in per_kernel)),
         'hbm': {'algorithmic_bytes': tot['bytes'],
+                'image_bytes': tot['image'],
                 'achieved_GBs': tot['bytes'] / st / 1e9,
                 'frac_step': tot['bytes'] / st / 1e9 / HBM_PEAK_GBS},
         'compute': {'algorithmic_flops': tot['flops'],
@@ -619,6 +761,13 @@ def main():
                 'frac_step': tot['lds'] / st / 1e12 / lds_peak},
         'sum_isolated_ms': float(isolated_ms.sum())
         if isolated_ms is not None else None}
+
+    # (before the CPU baseline: its OpenMP team keeps spinning on every core
+    # for a while after its last parallel region)
+    api = None
+    if world == 1 and not args.no_api and not sharded:
+        api = measure_api(graphs, knode, kedge, q, real, local_rank,
+                          args.gradient, n_pairs)
 
     # ---- CPU baseline (oracle, 1 core, bounded sample), N = 1 only -----------
     cpu = None
@@ -650,19 +799,35 @@ def main():
                'sample': f'{size} uniformly sampled pairs of the same '
                          f'{n}-graph set, oracle/mgk_oracle.c '
                          f'{fn}{args.dtype}, 1 thread'}
-        # same restatement, OpenMP over the pairs, every core of this host
+        # same restatement, OpenMP over the pairs (one work buffer per
+        # thread, graphs packed outside the timed call), on every CPU this
+        # process may use: the affinity mask capped by the container's CPU
+        # quota -- threads beyond the quota only time-share
         try:
-            ncore = len(os.sched_getaffinity(0))
-            size_all = int(min(n_pairs, max(2000, 0.25 * ncore * rate
-                                            * args.cpu_seconds)))
-            sample_all = rng.choice(n_pairs, size=size_all, replace=False)
+            n_aff, quota = effective_cpus()
+            ncore = max(1, min(n_aff, int(quota + 0.5) if quota else n_aff))
+            os.environ['OMP_NUM_THREADS'] = str(ncore)  # (read at load time)
+            run(probe, omp=True)                        # threads are up
+            t1 = time.perf_counter()
             run(probe, omp=True)
+            rate_all = len(probe) / (time.perf_counter() - t1)
+            # a sample of >= 6 s: the pair list repeated if it is too short
+            size_all = int(max(2000, rate_all * 6.0))
+            sample_all = rng.choice(n_pairs, size=min(size_all, n_pairs),
+                                    replace=False)
+            sample_all = np.resize(sample_all, size_all)
             t1 = time.perf_counter()
             run(sample_all, omp=True)
+            dt_all = time.perf_counter() - t1
             cpu['all_cores'] = {
-                'value': size_all / (time.perf_counter() - t1),
-                'unit': 'graph-pairs/s', 'cores': ncore,
-                'sample': f'{size_all} pairs, OpenMP dynamic schedule'}
+                'value': size_all / dt_all, 'unit': 'graph-pairs/s',
+                'cores': ncore, 'affinity_cpus': n_aff,
+                'cgroup_cpu_quota': quota, 'seconds': dt_all,
+                'parallel_efficiency': size_all / dt_all / cpu['value']
+                / ncore,
+                'sample': f'{size_all} pairs ({min(size_all, n_pairs)} '
+                          'distinct), OpenMP dynamic schedule, one work '
+                          'buffer per thread'}
         except Exception as e:                      # no libgomp etc.
             cpu['all_cores'] = {'error': str(e)}
         # the reference's own Python CPU path cannot travel to this host; its
@@ -690,11 +855,6 @@ def main():
             cpu['gradient_bound'] = f'|d| <= {rt} |ref| + {at} colscale'
             cpu['gradient_max_diff_over_colscale'] = float(np.max(
                 np.abs(dg - gref) / scale))
-
-    api = None
-    if world == 1 and not args.no_api and not sharded:
-        api = measure_api(graphs, knode, kedge, q, real, local_rank,
-                          args.gradient, n_pairs)
 
     other = None
     if world == 1 and not args.no_f32 and not args.gradient and not sharded:

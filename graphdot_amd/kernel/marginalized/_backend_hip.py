@@ -1269,7 +1269,7 @@ void ${name}(params_t prm) {
         return dgraphs, edge_kernel, C, fields
 
     def _partition(self, dgraphs, jobs, C, tab_bytes=0, gtab=False,
-                   oc_only=False):
+                   oc_only=False, merge_map=None):
         """Host half of a layout: solver variant per job, launch order (by
         variant, then descending cost) and launch geometry.  No device."""
         jobs = np.ascontiguousarray(jobs)
@@ -1288,7 +1288,14 @@ void ${name}(params_t prm) {
         # -- fewer, fuller launches, which matters most for the shards of a
         # multi-GPU run (scripts/minlaunch_experiment.sh: 8192 against 2048
         # waves: -1 % on the full matrix, -2...8 % on 1/2...1/8 of it).
-        if self.min_launch > 0:
+        self._last_merge_map = {}
+        if merge_map is not None:
+            # decided elsewhere, on a larger job list this one is a shard of
+            # (_sharded.ShardPlan.merge_map)
+            for k, k2 in merge_map.items():
+                choice = np.where(choice == k, k2, choice)
+            self._last_merge_map = dict(merge_map)
+        elif self.min_launch > 0:
             members_ = np.ones(len(choice), dtype=np.int64) if sel is None \
                 else sel.members
             used_ = sorted(set(choice.tolist()))
@@ -1312,6 +1319,11 @@ void ${name}(params_t prm) {
                         continue
                     if True:
                         choice = np.where(here, k2, choice)
+                        # (chains collapse: what rode in k now rides in k2)
+                        for k0, k1 in list(self._last_merge_map.items()):
+                            if k1 == k:
+                                self._last_merge_map[k0] = k2
+                        self._last_merge_map[k] = k2
                         break
         rank_of = np.empty(len(choice), dtype=np.int64)
         by_rank = np.lexsort((-cost, choice))
@@ -1451,7 +1463,7 @@ void ${name}(params_t prm) {
         return jit.compile_many(list(sources.values()), self.hipcc_extra)
 
     def _layout(self, dgraphs, jobs, starts, C, fields=(None, None),
-                timer=None, ngrad=False, maximin=False):
+                timer=None, ngrad=False, maximin=False, merge_map=None):
         """Everything of a plan that depends only on WHICH pairs of WHICH
         graphs are evaluated: variant per job, launch order and geometry, and
         the device copies of the job list, the order and `starts`.  Cached
@@ -1467,7 +1479,8 @@ void ${name}(params_t prm) {
             ('crc', zlib.crc32(jobs.view(np.uint8)))
         key = (_ids(dgraphs), len(jobs), jobs_id,
                zlib.crc32(starts.view(np.uint8)), C, fields, self.tables,
-               ngrad, maximin)
+               ngrad, maximin,
+               None if merge_map is None else tuple(sorted(merge_map.items())))
         hit = self._layouts.get(key)
         if hit is not None:
             self._layouts.move_to_end(key)
@@ -1486,7 +1499,7 @@ void ${name}(params_t prm) {
             lay.tab_bytes = 0
         jobs, lay.used, lay.order_host, lay.launches = self._partition(
             dgraphs, jobs, C, lay.tab_bytes, lay.gtab,
-            oc_only=ngrad or maximin)
+            oc_only=ngrad or maximin, merge_map=merge_map)
         lay.n_jobs = len(jobs)
         lay.b_jobs = runtime.DeviceBuffer(max(jobs.nbytes, 8))
         lay.b_order = runtime.DeviceBuffer(max(lay.order_host.nbytes, 4))
@@ -1508,7 +1521,7 @@ void ${name}(params_t prm) {
     def prepare(self, graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
                 jobs, starts, nX, nY, nJ, traits, timer=None, packed=False,
                 gramian_ptr=None, gradient_ptr=None, ngrad=False,
-                maximin=None):
+                maximin=None, merge_map=None):
         """Upload graphs / jobs, generate + compile code, partition the jobs.
         Returns a Plan whose launches can be replayed.  `gramian_ptr` /
         `gradient_ptr` (device addresses) make the kernels write into
@@ -1518,7 +1531,9 @@ void ${name}(params_t prm) {
         some pair does not fit one).  `maximin`: dict(diag=, diag_grad=,
         node_starts=, ld=) of device addresses -- the launch writes the
         maximin distance, its hotspot (and with `ngrad` its gradient) per
-        pair instead of the nodal matrix (`maximin_distance`)."""
+        pair instead of the nodal matrix (`maximin_distance`).  `merge_map`:
+        {variant index: variant index} launch merging decided on a larger job
+        list that `jobs` is a shard of (instead of by this list's counts)."""
         tic = timer.tic if timer else (lambda *_: None)
         toc = timer.toc if timer else (lambda *_: None)
         runtime.ensure_device(self.device)
@@ -1526,7 +1541,7 @@ void ${name}(params_t prm) {
         dgraphs, edge_kernel, C, fields = self._graphs_and_kernels(
             graphs, node_kernel, edge_kernel, traits, timer, ngrad)
         lay = self._layout(dgraphs, jobs, starts, C, fields, timer, ngrad,
-                           maximin is not None)
+                           maximin is not None, merge_map)
         tab = lay.tab_bytes > 0
 
         tic('code generation')

@@ -89,7 +89,8 @@ def job_times(variants, choice, arith, real, C, table=None):
     return t
 
 
-def partition_blocks(times, group, world_size, tail=0.0, snap=0):
+def partition_blocks(times, group, world_size, tail=0.0, snap=0,
+                     group_tail=None):
     """Cut a job list that is already in launch order (by solver variant
     `group`, then descending cost) into `world_size` contiguous blocks whose
     predicted times -- the jobs' times plus `tail` per variant a block touches
@@ -97,13 +98,19 @@ def partition_blocks(times, group, world_size, tail=0.0, snap=0):
     smallest possible maximum.  A rank then holds 1-3 variants, i.e. 1-3 large
     launches, instead of a sliver of every variant.  Cuts within `snap` jobs of
     a variant boundary move onto it (no launch of a few hundred pairs).
-    Returns the list of index ranges (start, stop)."""
+    `group_tail`: {variant: tail} overrides `tail` per variant (a launch of a
+    large-pair variant drains for longer).  Returns the list of index ranges
+    (start, stop)."""
     n = len(times)
     if n == 0:
         return [(0, 0)] * world_size
     c = np.concatenate(([0.0], np.cumsum(times, dtype=np.float64)))
     gstart = np.flatnonzero(np.concatenate(([True], group[1:] != group[:-1])))
     bounds = np.concatenate((gstart, [n]))
+    # tails of the variants up to (and including) the one at each start
+    gt = np.array([(group_tail or {}).get(int(group[g]), tail)
+                   for g in gstart], dtype=np.float64)
+    ct = np.concatenate(([0.0], np.cumsum(gt)))
 
     def fill(T):
         """greedy: longest prefix of predicted time <= T per rank"""
@@ -115,9 +122,11 @@ def partition_blocks(times, group, world_size, tail=0.0, snap=0):
             lo, hi = a + 1, n
             # time of [a, e) = c[e] - c[a] + tail * (variants touched)
             def cost(e):
-                nv = np.searchsorted(gstart, e - 1, side='right') \
-                    - np.searchsorted(gstart, a, side='right') + 1
-                return c[e] - c[a] + tail * nv
+                # variants touched by [a, e): those whose segment holds a
+                # ... e - 1
+                v0 = np.searchsorted(gstart, a, side='right') - 1
+                v1 = np.searchsorted(gstart, e - 1, side='right') - 1
+                return c[e] - c[a] + ct[v1 + 1] - ct[v0]
             if cost(lo) > T:
                 return None
             while lo < hi:
@@ -130,7 +139,7 @@ def partition_blocks(times, group, world_size, tail=0.0, snap=0):
             a = lo
         return cuts if a >= n else None
 
-    lo_T, hi_T = c[-1] / world_size, c[-1] + tail * len(bounds)
+    lo_T, hi_T = c[-1] / world_size, c[-1] + ct[-1]
     for _ in range(60):
         mid = 0.5 * (lo_T + hi_T)
         if fill(mid) is None:
@@ -180,7 +189,8 @@ class ShardPlan:
 
     def __init__(self, ji, jj, n_node, n_nz, nX, nY, symmetric, rank,
                  world_size, launch_order=None, times=None, group=None,
-                 tail=0.0, snap=2048, mode=None):
+                 tail=0.0, snap=2048, mode=None, group_tail=None,
+                 merge_map=None):
         """`launch_order`, `times`, `group` (optional): the job ids in the
         backend's launch order (by solver variant, then descending cost), the
         predicted time of every job (`job_times`) and its solver variant --
@@ -190,6 +200,10 @@ class ShardPlan:
         self.rank, self.world_size = rank, world_size
         self.ji, self.jj = np.asarray(ji), np.asarray(jj)
         self.nX, self.nY, self.symmetric = nX, nY, symmetric
+        #: launch merging decided on the WHOLE job list ({variant index:
+        #: variant index it rides in}): every rank applies it to its shard,
+        #: so which solver a pair runs on does not depend on the rank count
+        self.merge_map = merge_map
         cost = predict_cost(np.asarray(n_node), np.asarray(n_nz),
                             self.ji, self.jj)
         mode = mode or os.environ.get('GD_SHARD_MODE')
@@ -198,7 +212,7 @@ class ShardPlan:
             lo = np.asarray(launch_order, dtype=np.int64)
             cuts = partition_blocks(np.asarray(times)[lo],
                                     np.asarray(group)[lo], world_size, tail,
-                                    snap)
+                                    snap, group_tail)
             self.shards = [lo[a:b] for a, b in cuts]
             self.predicted = [float(np.asarray(times)[s].sum())
                               for s in self.shards]
@@ -290,6 +304,7 @@ def measured_shard_plan(backend, graphs, node_kernel, edge_kernel, jobs, nX,
     jobs = np.ascontiguousarray(jobs)
     _, used, order_all, launches = backend._partition(
         dgraphs, jobs, C, tab_bytes, gtab)
+    merge_map = dict(getattr(backend, '_last_merge_map', {}))
     ji, jj = jobs['i'].astype(np.int64), jobs['j'].astype(np.int64)
     n_node = np.array([g.n_node for g in dgraphs], np.int64)
     n_nz = np.array([g.n_nz for g in dgraphs], np.int64)
@@ -302,10 +317,16 @@ def measured_shard_plan(backend, graphs, node_kernel, edge_kernel, jobs, nX,
     f = 'f64' if np.dtype(backend.real) == np.float64 else 'f32'
     tail = 1e3 * float(table.get(f'{f}/C{C}/tail_us',
                                  table.get('tail_us', 12.0)))
+    group_tail = {}
+    for L in launches:
+        t_ = table.get(f'{f}/C{C}/{variant_key(L["variant"])}/tail_us')
+        if t_ is not None:
+            group_tail[int(L['k'])] = 1e3 * float(t_)
     return ShardPlan(ji, jj, n_node, n_nz, int(nX), int(nY),
                      bool(traits.symmetric), rank, world,
                      launch_order=order_all.astype(np.int64), times=times,
-                     group=group, tail=tail)
+                     group=group, tail=tail, group_tail=group_tail,
+                     merge_map=merge_map)
 
 
 def cuda_collective(group=None):
@@ -451,7 +472,8 @@ class ShardedStep:
             graphs, node_kernel, edge_kernel, p, q, eps, ftol, gtol,
             self.local_jobs, starts, nX, nY, nJ, traits, timer, packed=True,
             gramian_ptr=out.data_ptr(),
-            gradient_ptr=out.data_ptr() + self.capacity * rs.itemsize)
+            gradient_ptr=out.data_ptr() + self.capacity * rs.itemsize,
+            merge_map=self.shard.merge_map)
             for out in self.local_outs]
         self.plan = self.plans[0]
 
@@ -551,10 +573,11 @@ def distributed_backend(**kwargs):
                      pipeline=False, **kw):
             # Which solver variant a pair runs on must not depend on the
             # shard it falls into: the variants are different instantiations
-            # (compiled with fast-math) and agree to round-off only.  Without
-            # launch merging the results are bit-identical for any number of
-            # ranks (and to HIPBackend(min_launch=0) on one GPU).
-            kw.setdefault('min_launch', 0)
+            # (compiled with fast-math) and agree to round-off only.  Launch
+            # merging is therefore decided once, on the whole job list
+            # (`ShardPlan.merge_map`), and applied by every rank: the results
+            # are bit-identical for any number of ranks, and to a plain
+            # HIPBackend on one GPU.
             super().__init__(**kw)
             self.shard_single_rank = shard_single_rank
             self.collective = collective

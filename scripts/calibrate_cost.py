@@ -4,8 +4,10 @@
 _sharded.cost_table): for every solver variant the QM7-like benchmark set
 uses, in both arithmetics, value and value + gradient, the launch is cut into
 contiguous slices of its cost-sorted job list, every slice is timed as a
-launch of its own, and  t_slice - tail = a * pairs + b * sum(nnz1 nnz2 + 4 n1 n2)
-is fitted per variant (a, b >= 0).  Needs the GPU.
+launch of its own, and  t_slice - tail_v = a * pairs + b * sum(nnz1 nnz2 + 4 n1 n2)
+is fitted per variant (a, b >= 0); tail_v is the measured duration of a
+256-pair launch of the variant (one pair's latency: what the ramp and the
+drain of every launch cost together).  Needs the GPU.
 
     python scripts/calibrate_cost.py [--out path] [--tail-us 12]"""
 import json
@@ -79,8 +81,10 @@ for real, f in ((np.float64, 'f64'), (np.float32, 'f32')):
                 jj = local['j'].astype(np.int64)
                 arith = _sharded.predict_cost(n_node, n_nz, ji, jj)
                 A.append([len(part), float(arith.sum())])
-                t.append(timed(b, k, traits, local) - 1e3 * tail_us)
-            A, t = np.array(A), np.maximum(np.array(t), 1.0)
+                t.append(timed(b, k, traits, local))
+            few = np.ascontiguousarray(jobs[ids[:min(256, len(ids))]])
+            lat = timed(b, k, traits, few)
+            A, t = np.array(A), np.maximum(np.array(t) - lat, 1.0)
             if Q >= 2:
                 x = np.linalg.lstsq(A, t, rcond=None)[0]
             else:
@@ -89,11 +93,16 @@ for real, f in ((np.float64, 'f64'), (np.float32, 'f32')):
                 x = np.array([0.0, t.sum() / A[:, 1].sum()])
             key = f'{f}/C{C}/{_sharded.variant_key(L["variant"])}'
             table[key] = [float(x[0]), float(x[1])]
+            # what a launch of this variant costs beyond its pairs: the time
+            # of a launch too small to fill the chip (one pair's latency --
+            # the ramp and the tail of every launch add up to about that)
+            table[key + '/tail_us'] = float(lat) * 1e-3
             slopes.append(t.sum() / A[:, 1].sum())
             resid = (A @ x - t) / t
             print(f'{key:44s} {L["count"]:7d} pairs  '
                   f'{t.sum() / A[:, 0].sum():7.2f} ns/pair  a {x[0]:7.3f} '
-                  f'b {x[1]:8.5f}  resid {np.round(resid, 3)}', flush=True)
+                  f'b {x[1]:8.5f}  tail {lat * 1e-3:5.1f} us  '
+                  f'resid {np.round(resid, 3)}', flush=True)
         table[f'{f}/C{C}/mean_ns_per_arith'] = float(np.mean(slopes))
 with open(out, 'w') as fh:
     json.dump(table, fh, indent=1, sort_keys=True)

@@ -35,9 +35,10 @@ cost = predict_cost(n_node, n_nz, i.astype(np.int64), j.astype(np.int64))
 ls = LaunchSet()
 
 
-def step_ms(local_jobs, steps=30):
+def step_ms(local_jobs, steps=30, merge_map=None):
     plan = b.prepare(G, kn, ke, k.p, k.q, k.eps, k.ftol, k.gtol, local_jobs,
-                     starts, n, n, k.n_dims, traits, packed=True)
+                     starts, n, n, k.n_dims, traits, packed=True,
+                     merge_map=merge_map)
     for _ in range(3):
         ls.enqueue(plan)
     runtime.synchronize()
@@ -52,14 +53,18 @@ full, nl = step_ms(jobs)
 print(f'full step {full:.3f} ms, {nl} launches')
 for world in (2, 4, 8):
     for mode in modes:
+        mm = None
         if mode == 'measured':
-            # contiguous blocks of the launch order with equal measured time
+            # contiguous blocks of the launch order with equal measured time,
+            # launch merging decided on the whole list
             # (_sharded.measured_shard_plan: what ShardedStep uses)
-            shards = measured_shard_plan(b, G, kn, ke, jobs, n, n, traits, 0,
-                                         world).shards
+            sp = measured_shard_plan(b, G, kn, ke, jobs, n, n, traits, 0,
+                                     world)
+            shards, mm = sp.shards, sp.merge_map
         else:
             shards = partition(cost, world, mode)
-        t = [step_ms(np.ascontiguousarray(jobs[s])) for s in shards]
+        t = [step_ms(np.ascontiguousarray(jobs[s]), merge_map=mm)
+             for s in shards]
         ms = np.array([x[0] for x in t])
         print(f'world {world} {mode:6s}: max {ms.max():.3f} mean {ms.mean():.3f} '
               f'ideal {full / world:.3f}  efficiency {full / world / ms.max():.2f}  '

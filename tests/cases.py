@@ -189,3 +189,86 @@ def config3_kernels():
     edge = TensorProduct(order=SquareExponential(0.5),
                          conjugated=KroneckerDelta(0.5))
     return node, edge, 0.01
+
+
+# -- the reference's own benchmark shapes ------------------------------------------
+def nws48_graphs(batch, size=48):
+    """`make_graphs(batch, 48)` of the reference's benchmark harness
+    (benchmark/kernel/marginalized/time_kernel.py:14-29): `batch` copies of
+    ONE Newman-Watts-Strogatz topology (k = 5, p = 0.05, seed 0) with random
+    integer node labels 0..8, edge labels 0..8 and edge weights 1..4."""
+    rng = np.random.RandomState(0)
+    out = []
+    for _ in range(batch):
+        g = nx.newman_watts_strogatz_graph(size, k=5, p=0.05, seed=0)
+        for i in range(size):
+            g.nodes[i]['label'] = int(rng.randint(0, 9))
+        for ij in g.edges:
+            g.edges[ij]['label'] = int(rng.randint(0, 9))
+            g.edges[ij]['weight'] = int(rng.randint(1, 5))
+        out.append(Graph.from_networkx(g, weight='weight'))
+    return Graph.unify_datatype(out)
+
+
+def nws48_kernels():
+    """time_kernel.py:48-49,62-63; q is the kernel's default."""
+    return (TensorProduct(label=KroneckerDelta(0.5)),
+            TensorProduct(label=KroneckerDelta(0.5)), 0.01)
+
+
+# -- dense, from_ase-like molecular graphs (Tang2019MolecularKernel) --------------------
+#: van der Waals radii in Angstrom (the `vdw_radius` column the reference's
+#: AtomicAdjacency reads from mendeleev, graph/adjacency/atomic.py:32-37)
+_VDW = {1: 1.10, 6: 1.70, 7: 1.55, 8: 1.52, 16: 1.80}
+
+
+def tang2019_graphs(n_graphs=256, seed=2019):
+    """Spatial molecular graphs as `Graph.from_ase` builds them
+    (graph/_from_ase.py:33-77 with the default AtomicAdjacency,
+    graph/adjacency/atomic.py:80-125, euclidean.py:19-31): nodes carry
+    `element`, every pair of atoms closer than 3 sqrt(r_i r_j) (van der Waals
+    radii) is an edge of weight 1 - d / (3 sqrt(r_i r_j)) with the attribute
+    `length` = d.  The molecules are the QM7-like ones above, embedded in 3D
+    by a random self-avoiding growth (bond lengths 1.09 / 1.45 A): at most 23
+    atoms, 10-20 neighbours per atom -- the near-complete weighted adjacency
+    of the reference's flagship molecular kernel (kernel/molecular.py:47-66)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_graphs):
+        mol = qm7_like_molecule(rng)
+        n = mol.number_of_nodes()
+        Z = np.array([mol.nodes[v]['atomic_number'] for v in range(n)])
+        x = np.zeros((n, 3))
+        placed = {0}
+        order = list(nx.bfs_edges(mol, 0))
+        for u, v in order:
+            bond = 1.09 if 1 in (Z[u], Z[v]) else 1.45
+            for attempt in range(200):
+                d = rng.normal(size=3)
+                cand = x[u] + bond * d / np.linalg.norm(d)
+                others = np.array([x[w] for w in placed if w != u])
+                if len(others) == 0 or np.min(np.linalg.norm(
+                        others - cand, axis=1)) > (0.9 if attempt < 150
+                                                   else 0.5):
+                    break
+            x[v] = cand
+            placed.add(v)
+        g = nx.Graph()
+        for v in range(n):
+            g.add_node(v, element=int(Z[v]))
+        for i in range(n):
+            for j in range(i + 1, n):
+                d = float(np.linalg.norm(x[i] - x[j]))
+                cut = 3.0 * np.sqrt(_VDW[int(Z[i])] * _VDW[int(Z[j])])
+                w = 1.0 - d / cut
+                if w > 0:
+                    g.add_edge(i, j, w=float(np.float32(w)),
+                               length=float(np.float32(d)))
+        out.append(Graph.from_networkx(g, weight='w'))
+    return Graph.unify_datatype(out)
+
+
+def tang2019_kernels():
+    """Tang2019MolecularKernel's defaults (kernel/molecular.py:36-56)."""
+    return (TensorProduct(element=KroneckerDelta(0.2)),
+            TensorProduct(length=SquareExponential(0.05)), 0.01)

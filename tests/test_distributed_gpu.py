@@ -53,10 +53,10 @@ def test_two_ranks_through_the_kernel_api(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     G = cases.config3_graphs(30, seed=6)
     knode, kedge, q = cases.config3_kernels()
-    # (bit for bit: same solver variant per pair, i.e. no launch merging)
+    # (bit for bit: the same solver variant per pair -- launch merging is
+    # decided on the whole job list and applied by every rank)
     from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
-    k = MarginalizedGraphKernel(knode, kedge, q=q,
-                                backend=HIPBackend(min_launch=0))
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=HIPBackend())
     K = k(G)
     K2, dK = k(G, eval_gradient=True)
     Kxy = k(G[:12], G[12:])
@@ -162,8 +162,7 @@ def test_rccl_process_group_of_one_rank(tmp_path):
     G = cases.config3_graphs(40, seed=6)
     knode, kedge, q = cases.config3_kernels()
     from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
-    k = MarginalizedGraphKernel(knode, kedge, q=q,
-                                backend=HIPBackend(min_launch=0))
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=HIPBackend())
     K2, dK = k(G, eval_gradient=True)
     assert np.array_equal(r['K'], k(G))
     assert np.array_equal(r['K2'], K2) and np.array_equal(r['dK'], dK)
