@@ -549,6 +549,19 @@ def main():
                            kernel.eps, kernel.ftol, kernel.gtol, all_jobs,
                            starts, n, n, nJ, traits,
                            pipeline=args.pipeline)
+        if world > 1:
+            # the ranks time their shards and take the cuts again, as
+            # `distributed_backend` does when it first builds a step
+            from graphdot_amd.kernel.marginalized._sharded import \
+                balance_by_measurement
+            step, _ = balance_by_measurement(
+                step, step.shard,
+                lambda sp_: ShardedStep(
+                    backend, graphs, knode, kedge, kernel.p, kernel.q,
+                    kernel.eps, kernel.ftol, kernel.gtol, all_jobs, starts,
+                    n, n, nJ, traits, pipeline=args.pipeline,
+                    shard_plan=sp_),
+                rounds=int(os.environ.get('GD_SHARD_REBALANCE', 2)))
         plan, local_jobs, shard = step.plan, step.local_jobs, step.shard
     else:
         plan = backend.prepare(graphs, knode, kedge, kernel.p, kernel.q,
@@ -811,14 +824,20 @@ def main():
             t1 = time.perf_counter()
             run(probe, omp=True)
             rate_all = len(probe) / (time.perf_counter() - t1)
-            # a sample of >= 6 s: the pair list repeated if it is too short
-            size_all = int(max(2000, rate_all * 6.0))
-            sample_all = rng.choice(n_pairs, size=min(size_all, n_pairs),
-                                    replace=False)
-            sample_all = np.resize(sample_all, size_all)
-            t1 = time.perf_counter()
-            run(sample_all, omp=True)
-            dt_all = time.perf_counter() - t1
+            # a sample of >= 5 s: the pair list repeated if it is too short
+            # (the short probe under-estimates the steady rate: grow until
+            # the timed call is long enough)
+            size_all, dt_all = int(max(2000, rate_all * 6.0)), 0.0
+            for _ in range(4):
+                sample_all = rng.choice(n_pairs, size=min(size_all, n_pairs),
+                                        replace=False)
+                sample_all = np.resize(sample_all, size_all)
+                t1 = time.perf_counter()
+                run(sample_all, omp=True)
+                dt_all = time.perf_counter() - t1
+                if dt_all >= 5.0:
+                    break
+                size_all = int(size_all * 6.5 / max(dt_all, 1e-3))
             cpu['all_cores'] = {
                 'value': size_all / dt_all, 'unit': 'graph-pairs/s',
                 'cores': ncore, 'affinity_cpus': n_aff,

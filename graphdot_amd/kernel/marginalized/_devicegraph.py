@@ -120,8 +120,10 @@ class DeviceGraph:
         edges = graph.edges.copy(deep=False)
         self.n_node = n = len(nodes)
         if n > 0xFFFF or 2 * len(edges) > 0xFFFF:
-            raise ValueError('graphs with more than 65535 nodes are not '
-                             'supported by the device format')
+            raise ValueError(
+                f'graph with {n} nodes and {2 * len(edges)} directed '
+                'adjacency nonzeros: the device format indexes both with 16 '
+                'bits (at most 65535 each)')
 
         varlen = []     # (payload ndarray) in blob order
         for df in (nodes, edges):
@@ -417,32 +419,58 @@ def pack_many(graphs, real=np.float32, native=True):
         edge_t.fields['label'][1] if weighted else 0,
         np.dtype(real).itemsize if weighted else 0)
     signature = (weighted, str(node_t), str(edge_t))
-    nz_all = r['nz'].view(NZ_DTYPE)
-    buf, blob0, nz0 = r['blob'], r['blob_off'], r['nz_off']
+    r['nz'] = r['nz'].view(NZ_DTYPE)
+    r['no_relocs'] = np.zeros(0, dtype=np.int64)
+    r['blob_off'], r['nz_off'] = r['blob_off'].tolist(), r['nz_off'].tolist()
+    r['node_off'] = node0.tolist()
     offs = r['sec_off'].tolist()
     maxdeg = r['maxdeg'].tolist()
     nnz = r['nnz'].tolist()
-    nl, b0l, z0l, n0l = n.tolist(), blob0.tolist(), nz0.tolist(), node0.tolist()
+    nl = n.tolist()
     for b_, k in enumerate(batch):
-        dg = DeviceGraph.__new__(DeviceGraph)
-        a, z = n0l[b_], n0l[b_ + 1]
-        za, zz = z0l[b_], z0l[b_ + 1]
+        # (the per-graph array views are cut on first use: _BatchMember)
+        dg = _BatchMember.__new__(_BatchMember)
+        dg._b, dg._k = r, b_
         dg.n_node, dg.n_nz, dg.weighted = nl[b_], nnz[b_], weighted
-        dg.perm = r['perm'][a:z]
-        dg.rank = r['rank'][a:z]
-        dg.degree = r['degree'][a:z]
-        dg.adjacency_count = r['count'][a:z]
-        dg.nz = nz_all[za:zz]
-        dg.rowptr = r['rowptr'][a + b_:z + b_ + 1]
-        dg.edge_index = r['eid'][za:zz]
         dg.node_t, dg.edge_t, dg.signature = node_t, edge_t, signature
-        dg.offsets = dict(zip(SECTIONS, offs[b_]))
-        dg.image_bytes = _pad(dg.offsets['perm'] + 2 * dg.n_node)
-        dg.relocs = np.zeros(0, dtype=np.int64)
+        o = offs[b_]
+        dg.offsets = dict(zip(SECTIONS, o))
+        dg.image_bytes = _pad(o[5] + 2 * nl[b_])
         dg._max_degree = maxdeg[b_]
-        dg.blob = buf[b0l[b_]:b0l[b_ + 1]]
         out[k] = dg
     return out
+
+
+class _BatchMember(DeviceGraph):
+    """One graph of a natively packed batch: its arrays are views into the
+    batch's flat arrays, made when first asked for (most calls only need the
+    sizes and the blob)."""
+
+    def _nodes(self, key):
+        a, z = self._b['node_off'][self._k], self._b['node_off'][self._k + 1]
+        return self._b[key][a:z]
+
+    def _nonzeros(self, key):
+        a, z = self._b['nz_off'][self._k], self._b['nz_off'][self._k + 1]
+        return self._b[key][a:z]
+
+    perm = property(lambda self: self._nodes('perm'))
+    rank = property(lambda self: self._nodes('rank'))
+    degree = property(lambda self: self._nodes('degree'))
+    adjacency_count = property(lambda self: self._nodes('count'))
+    nz = property(lambda self: self._nonzeros('nz'))
+    edge_index = property(lambda self: self._nonzeros('eid'))
+    relocs = property(lambda self: self._b['no_relocs'])
+
+    @property
+    def rowptr(self):
+        a, z = self._b['node_off'][self._k], self._b['node_off'][self._k + 1]
+        return self._b['rowptr'][a + self._k:z + self._k + 1]
+
+    @property
+    def blob(self):
+        o = self._b['blob_off']
+        return self._b['blob'][o[self._k]:o[self._k + 1]]
 
 
 def pack_many_numpy(graphs, real=np.float32):

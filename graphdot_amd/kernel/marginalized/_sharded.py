@@ -210,12 +210,20 @@ class ShardPlan:
         self.mode = 'snake'
         if launch_order is not None and mode in (None, 'measured'):
             lo = np.asarray(launch_order, dtype=np.int64)
-            cuts = partition_blocks(np.asarray(times)[lo],
-                                    np.asarray(group)[lo], world_size, tail,
-                                    snap, group_tail)
+            self._model = dict(launch_order=lo, times=np.asarray(
+                times, dtype=np.float64), group=np.asarray(group), tail=tail,
+                snap=snap, group_tail=group_tail, n_node=n_node, n_nz=n_nz)
+            cuts = partition_blocks(self._model['times'][lo],
+                                    self._model['group'][lo], world_size,
+                                    tail, snap, group_tail)
             self.shards = [lo[a:b] for a, b in cuts]
-            self.predicted = [float(np.asarray(times)[s].sum())
-                              for s in self.shards]
+            # predicted nanoseconds per rank: pairs + launch tails
+            self.predicted = []
+            for s in self.shards:
+                tails = sum((group_tail or {}).get(int(v), tail)
+                            for v in np.unique(self._model['group'][s]))
+                self.predicted.append(
+                    float(self._model['times'][s].sum()) + tails)
             self.mode = 'measured'
         else:
             self.shards = partition(cost, world_size, mode)
@@ -225,6 +233,35 @@ class ShardPlan:
         self.slot = np.empty(len(cost), dtype=np.int64)
         for r, s in enumerate(self.shards):
             self.slot[s] = r * self.capacity + np.arange(len(s))
+
+    def rebalanced(self, measured):
+        """A new plan after the ranks have timed their shards: `measured[r]`
+        (any unit) is what rank r's solver launches took.  The predicted time
+        of every job of shard r is scaled by measured[r] / predicted[r]
+        (normalised so that the total stays), the cuts are taken again.  What
+        the cost table misses on a particular set of graphs -- it was fitted
+        on the QM7-like benchmark set -- is corrected from the only
+        measurement that matters; two rounds bring the ranks within a few
+        percent of each other (scripts/shard_sim.py).  Every rank computes the
+        same new plan from the same all-gathered numbers."""
+        if self.mode != 'measured':
+            return self
+        m = np.asarray(measured, dtype=np.float64)
+        p = np.asarray(self.predicted, dtype=np.float64)
+        ok = (m > 0) & (p > 0)
+        if not ok.all() or len(m) != self.world_size:
+            return self
+        f = (m / p) / np.mean(m / p)
+        md = self._model
+        times = md['times'].copy()
+        for r, s in enumerate(self.shards):
+            times[s] *= f[r]
+        return ShardPlan(self.ji, self.jj, md['n_node'], md['n_nz'], self.nX,
+                         self.nY, self.symmetric, self.rank, self.world_size,
+                         launch_order=md['launch_order'], times=times,
+                         group=md['group'], tail=md['tail'], snap=md['snap'],
+                         group_tail=md['group_tail'],
+                         merge_map=self.merge_map)
 
     def scatter_index(self, starts_x, starts_y):
         """Flat F-order destinations (and mirrored destinations) of the
@@ -327,6 +364,27 @@ def measured_shard_plan(backend, graphs, node_kernel, edge_kernel, jobs, nX,
                      launch_order=order_all.astype(np.int64), times=times,
                      group=group, tail=tail, group_tail=group_tail,
                      merge_map=merge_map)
+
+
+def balance_by_measurement(step, plan, build, rounds=2, group=None):
+    """Re-balance a sharded step from the ranks' own timings: every rank
+    times its solver launches, the times are all-gathered (one number per
+    rank) and the cuts are taken again (`ShardPlan.rebalanced`); `build(plan)`
+    makes the step of a plan.  Returns (step, plan)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    for _ in range(max(0, rounds)):
+        if plan.mode != 'measured':
+            break
+        t = torch.tensor([step.time_local()], dtype=torch.float64)
+        if cuda_collective(group):
+            t = t.to(step.device)
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t, group=group)
+        plan = plan.rebalanced([float(x.item()) for x in ts])
+        step = build(plan)
+    return step, plan
 
 
 def cuda_collective(group=None):
@@ -520,6 +578,20 @@ class ShardedStep:
         runtime.synchronize()
         torch.cuda.synchronize(self.device)
 
+    def time_local(self, steps=5):
+        """Milliseconds of this rank's solver launches alone (no collective,
+        no reassembly): what `ShardPlan.rebalanced` balances."""
+        import time
+        from ...hip import runtime
+        for _ in range(2):
+            self.launch_set.enqueue(self.plans[0])
+        runtime.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.launch_set.enqueue(self.plans[0])
+        runtime.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / steps
+
     @property
     def values(self):
         """(nX, nY) column-major device tensor view of the matrix."""
@@ -570,7 +642,7 @@ def distributed_backend(**kwargs):
     class DistributedHIPBackend(HIPBackend):
 
         def __init__(self, shard_single_rank=False, collective='torch',
-                     pipeline=False, **kw):
+                     pipeline=False, rebalance=2, **kw):
             # Which solver variant a pair runs on must not depend on the
             # shard it falls into: the variants are different instantiations
             # (compiled with fast-math) and agree to round-off only.  Launch
@@ -582,6 +654,11 @@ def distributed_backend(**kwargs):
             self.shard_single_rank = shard_single_rank
             self.collective = collective
             self.pipeline = pipeline
+            #: rounds of measured re-balancing when a sharded step is first
+            #: built (every rank times its shard, the times are all-gathered,
+            #: the cuts are taken again: ShardPlan.rebalanced)
+            self.rebalance = int(os.environ.get('GD_SHARD_REBALANCE',
+                                                rebalance))
             self._shard_plans = {}
             self._steps = {}      # (shard plan, nJ, traits) -> ShardedStep
 
@@ -633,11 +710,23 @@ def distributed_backend(**kwargs):
             if step is None:
                 if len(self._steps) > 4:
                     self._steps.clear()
-                step = self._steps[key] = ShardedStep(
-                    self, graphs, node_kernel, edge_kernel, p, q, eps, ftol,
-                    gtol, jobs, starts, nX, nY, nJ, traits, timer=timer,
-                    shard_plan=sp, collective=self.collective,
-                    pipeline=self.pipeline)
+
+                def build(plan):
+                    return ShardedStep(
+                        self, graphs, node_kernel, edge_kernel, p, q, eps,
+                        ftol, gtol, jobs, starts, nX, nY, nJ, traits,
+                        timer=timer, shard_plan=plan,
+                        collective=self.collective, pipeline=self.pipeline)
+                step = build(sp)
+                if world > 1 and len(jobs) >= 4096 * world:
+                    step, sp = balance_by_measurement(step, sp, build,
+                                                      self.rebalance)
+                    # (later calls find the tuned plan)
+                    for k_, v_ in list(self._shard_plans.items()):
+                        if v_[1] is jobs and k_[-1] == world:
+                            self._shard_plans[k_] = (sp, v_[1], v_[2])
+                    key = (id(sp), int(nJ), traits)
+                self._steps[key] = step
             else:
                 step.bind(node_kernel, edge_kernel, p, q, eps, ftol, gtol,
                           timer)

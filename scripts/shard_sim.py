@@ -66,6 +66,19 @@ for world in (2, 4, 8):
         t = [step_ms(np.ascontiguousarray(jobs[s]), merge_map=mm)
              for s in shards]
         ms = np.array([x[0] for x in t])
+        if mode == 'measured':
+            print('      predicted  ', np.round(np.array(sp.predicted) * 1e-6, 3))
+            # what DistributedHIPBackend does when it builds a step: the ranks
+            # time their shards, all-gather the times, take the cuts again
+            for rnd in range(2):
+                sp = sp.rebalanced(ms)
+                shards = sp.shards
+                t = [step_ms(np.ascontiguousarray(jobs[s]), merge_map=mm)
+                     for s in shards]
+                ms = np.array([x[0] for x in t])
+                print(f'      rebalance round {rnd + 1}: max {ms.max():.3f} '
+                      f'mean {ms.mean():.3f} efficiency '
+                      f'{full / world / ms.max():.2f}', np.round(ms, 3))
         print(f'world {world} {mode:6s}: max {ms.max():.3f} mean {ms.mean():.3f} '
               f'ideal {full / world:.3f}  efficiency {full / world / ms.max():.2f}  '
               f'launches {[x[1] for x in t]}  pairs {[len(s) for s in shards]}')

@@ -391,3 +391,50 @@ def test_reassembly_index_rebuilds_matrix_and_gradient_planes(symmetric):
     out1[dst1] = g1[src1]
     assert np.array_equal(out1.reshape(nX, nY, order='F'),
                           plans[0].assemble(g1))
+
+
+def test_block_sharding_and_measured_rebalancing():
+    """`partition_blocks`: contiguous blocks of the launch order, balanced on
+    predicted job times plus a tail per solver variant a block touches, cuts
+    snapped onto nearby variant boundaries; `ShardPlan.rebalanced`: when the
+    ranks' measured times disagree with the prediction (here: one variant is
+    really 40 % slower than the table says) the cuts move until the *real*
+    times are balanced."""
+    from graphdot_amd.kernel.marginalized._sharded import (
+        ShardPlan, partition_blocks)
+    rng = np.random.default_rng(5)
+    n = 40000
+    group = np.sort(rng.choice([3, 5, 6, 9], size=n, p=[.2, .4, .3, .1]))
+    times = np.sort(rng.uniform(4, 12, n))[::-1] * (1 + 0.1 * group)
+    order = np.arange(n)
+    for world in (2, 4, 8):
+        cuts = partition_blocks(times, group, world, tail=2000.0, snap=64)
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        cost = [times[a:b].sum() + 2000.0 * len(np.unique(group[a:b]))
+                for a, b in cuts]
+        assert max(cost) <= 1.03 * np.mean(cost)
+    # a cut that falls next to a variant boundary moves onto it
+    g2 = np.repeat([1, 2], [1000, 1010])
+    cuts = partition_blocks(np.ones(2010), g2, 2, snap=64)
+    assert cuts[0] == (0, 1000)
+    # measured feedback
+    ji = jj = np.zeros(n, dtype=np.int64)
+    real = times * np.where(group == 5, 1.4, 1.0)      # what the GPU does
+    world = 8
+    sp = ShardPlan(ji, jj, np.ones(1), np.ones(1), 1, 1, False, 0, world,
+                   launch_order=order, times=times, group=group, tail=2000.0,
+                   snap=64)
+    assert sp.mode == 'measured' and sorted(
+        np.concatenate(sp.shards).tolist()) == list(range(n))
+
+    def measure(plan):
+        return np.array([real[s].sum() + 2000.0 * len(np.unique(group[s]))
+                         for s in plan.shards])
+    before = measure(sp)
+    for _ in range(2):
+        sp = sp.rebalanced(measure(sp))
+    after = measure(sp)
+    assert before.max() / before.mean() > 1.15
+    assert after.max() / after.mean() < 1.04
+    assert sorted(np.concatenate(sp.shards).tolist()) == list(range(n))

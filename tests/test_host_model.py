@@ -420,3 +420,32 @@ def test_native_job_layout_equals_the_numpy_restatement():
                         assert ua == ub and La == Lb
                         assert np.array_equal(oa, ob)
                         assert sorted(oa.tolist()) == list(range(len(jobs)))
+
+
+def test_graphs_beyond_the_u16_device_format_are_refused():
+    """The device format indexes nodes and directed nonzeros with 16 bits
+    (graph.h; DESIGN.md 2, "Limits"): a graph with more than 65 535 nodes, or
+    more than 65 535 directed nonzeros, raises ValueError -- from the
+    per-graph packer and from the batch packer, natively and in numpy --
+    instead of wrapping around.  (The reference has no such limit; its octile
+    format indexes with 32 bits.)"""
+    from graphdot_amd.graph import Graph
+    from graphdot_amd.kernel.marginalized._devicegraph import (
+        DeviceGraph, pack_many)
+    n = 65536 + 4
+    ring = Graph(nodes={'!i': np.arange(n), 'f': np.zeros(n, np.float32)},
+                 edges={'!i': np.arange(n - 1), '!j': np.arange(1, n)})
+    m = 32768 + 8                               # 2 m > 65 535 nonzeros
+    rng = np.random.default_rng(0)
+    dense = Graph(nodes={'!i': np.arange(400), 'f': np.zeros(400, np.float32)},
+                  edges={'!i': rng.integers(0, 200, m),
+                         '!j': rng.integers(200, 400, m)})
+    ok = Graph(nodes={'!i': np.arange(5), 'f': np.zeros(5, np.float32)},
+               edges={'!i': [0, 1, 2, 3], '!j': [1, 2, 3, 4]})
+    for bad in (ring, dense):
+        with pytest.raises(ValueError, match='65535'):
+            DeviceGraph(bad)
+        for native in (True, False):
+            with pytest.raises(ValueError, match='65535'):
+                pack_many(Graph.unify_datatype([ok, bad]), native=native)
+    assert len(pack_many([ok])) == 1
