@@ -251,6 +251,19 @@ struct oc_solver {
 #endif
     constexpr static int GCH = GD_OC_GCH;       // gathers in flight
     constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4 && !STATIC;
+#ifndef GD_OC_PACK
+#define GD_OC_PACK 1
+#endif
+    // Two 16-bit LDS addresses per register (PACK): the 64-slot variants of
+    // the 8- and 16-wave workgroups hold S values + S addresses = 128
+    // registers per lane in float, the whole budget of a 1024-thread
+    // workgroup -- everything else spilled (268 B of scratch per lane,
+    // profiles/r02_c2_pmc.csv).  Packed, a slot costs one extra VALU per
+    // iteration (the unpack, kept inside the loop) and half an address
+    // register.  The one-pass float value solvers only.
+    constexpr static bool PACK = GD_OC_PACK != 0 && sizeof(real) == 4 && C == 1 && !NODAL && !STATIC &&
+                                 ((S >= 64 && W >= 8) || GD_OC_PACK == 2);
+    constexpr static int NADR = PACK ? (S + 1) / 2 : S;
     // LEAN (static layouts, value + gradient): the solution x lives in a
     // lane-private LDS region and p only in its published copy -- the update
     // block re-reads p (once for A p, once for the x / p update) and
@@ -504,7 +517,7 @@ struct oc_solver {
 
             // ---- nonzero slots owned by this thread ---------------------------
             real val[S];
-            unsigned adr[S];   // LDS byte address of the gathered element of p (two-pass setup: first (a << 16) | b, or ~0u)
+            unsigned adr[NADR];   // LDS byte address of the gathered element of p (two-pass setup: first (a << 16) | b, or ~0u; PACK: two per register)
             const unsigned lp_off = lds_offset(lp);
             constexpr unsigned ELEM = C * sizeof(real);
             unsigned fm[NM];
@@ -568,11 +581,20 @@ struct oc_solver {
 #if GD_OC_PIN
                         asm volatile("" : "+v"(val[s]), "+v"(col));
 #endif
-                        adr[s] = col;
+                        if constexpr (PACK) {
+                            // (byte addresses below 64 KB: host-checked)
+                            if (s % 2 == 0) adr[s / 2] = col;
+                            else adr[s / 2] |= col << 16;
+                        } else {
+                            adr[s] = col;
+                        }
 #if !GD_OC_PIN
                         if (s % SETUP_CHUNK == SETUP_CHUNK - 1 || s == S - 1) {
 #pragma unroll
-                            for (int u = s - s % SETUP_CHUNK; u <= s; ++u) asm volatile("" : "+v"(val[u]), "+v"(adr[u]));
+                            for (int u = s - s % SETUP_CHUNK; u <= s; ++u) {
+                                if constexpr (PACK) asm volatile("" : "+v"(val[u]), "+v"(adr[u / 2]));
+                                else asm volatile("" : "+v"(val[u]), "+v"(adr[u]));
+                            }
                         }
 #endif
                         cur.next();
@@ -719,7 +741,17 @@ struct oc_solver {
                             real e[C];
 #pragma unroll
                             for (int c = 0; c < C; ++c) e[c] = 0;
-                            if (s0 + jj < S) load_elem_at<C>(adr[s0 + jj], e);
+                            if (s0 + jj < S) {
+                                if constexpr (PACK) {
+                                    // (the pin keeps the unpack -- one VALU --
+                                    // in the loop instead of S hoisted registers)
+                                    unsigned pk = adr[(s0 + jj) / 2];
+                                    asm volatile("" : "+v"(pk));
+                                    load_elem_at<C>(((s0 + jj) & 1) ? pk >> 16 : pk & 0xFFFFu, e);
+                                } else {
+                                    load_elem_at<C>(adr[s0 + jj], e);
+                                }
+                            }
 #pragma unroll
                             for (int c = 0; c < C; ++c) g[c][jj] = e[c];
                         }

@@ -348,7 +348,8 @@ int gdh_pair_keys(const uint32_t *jobs, int64_t n_jobs, const int32_t *cid,
 }
 
 int gdh_order_jobs(const int32_t *pk, int64_t n_jobs, const int32_t *rank_of_key,
-                   int64_t n_keys, int64_t n_ranks, uint32_t *order) {
+                   int64_t n_keys, int64_t n_ranks, uint32_t *order,
+                   const uint32_t *jobs, uint32_t *jobs_sorted) {
     if (n_jobs < 0 || n_keys < 0 || n_ranks < 0) return -1;
     std::vector<int64_t> start((size_t)n_ranks + 1, 0);
     for (int64_t t = 0; t < n_jobs; ++t) {
@@ -358,7 +359,14 @@ int gdh_order_jobs(const int32_t *pk, int64_t n_jobs, const int32_t *rank_of_key
         ++start[(size_t)r + 1];
     }
     for (int64_t r = 0; r < n_ranks; ++r) start[(size_t)r + 1] += start[(size_t)r];
-    for (int64_t t = 0; t < n_jobs; ++t) order[start[(size_t)rank_of_key[pk[t]]]++] = (uint32_t)t;
+    for (int64_t t = 0; t < n_jobs; ++t) {
+        const int64_t at = start[(size_t)rank_of_key[pk[t]]]++;
+        order[at] = (uint32_t)t;
+        if (jobs && jobs_sorted) {     // the job list in launch order, as uploaded
+            jobs_sorted[2 * at] = jobs[2 * t];
+            jobs_sorted[2 * at + 1] = jobs[2 * t + 1];
+        }
+    }
     return 0;
 }
 

@@ -28,7 +28,7 @@ SIGNATURES = {
     'gdh_classify_oc': [_i64] + [_vp] * 7 + [_i32] + [_vp] * 6
     + [_i32, _i32, _i64, _vp, _vp],
     'gdh_pair_keys': [_vp, _i64, _vp, _i32, _i32, _vp, _vp],
-    'gdh_order_jobs': [_vp, _i64, _vp, _i64, _i64, _vp],
+    'gdh_order_jobs': [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp],
 }
 
 
@@ -192,12 +192,19 @@ def pair_keys(jobs, cid, nc):
     return pk, count
 
 
-def order_jobs(pk, rank_of_key, n_ranks):
-    """Job ids in launch order: stable counting sort by rank_of_key[pk]."""
+def order_jobs(pk, rank_of_key, n_ranks, jobs=None):
+    """Job ids in launch order: stable counting sort by rank_of_key[pk].
+    With `jobs` also returns the job records in that order."""
     pk = _c(pk, np.int32)
     rank_of_key = _c(rank_of_key, np.int32)
     order = np.zeros(len(pk), np.uint32)
-    _check(lib().gdh_order_jobs(_p(pk), len(pk), _p(rank_of_key),
-                                len(rank_of_key), int(n_ranks), _p(order)),
-           'gdh_order_jobs')
-    return order
+    raw = out = None
+    if jobs is not None:
+        jobs = np.ascontiguousarray(jobs)
+        raw = jobs.view(np.uint32)
+        out = np.empty_like(jobs)
+    _check(lib().gdh_order_jobs(
+        _p(pk), len(pk), _p(rank_of_key), len(rank_of_key), int(n_ranks),
+        _p(order), _p(raw), None if out is None else _p(out.view(np.uint32))),
+        'gdh_order_jobs')
+    return order if jobs is None else (order, out)

@@ -1273,6 +1273,7 @@ void ${name}(params_t prm) {
         """Host half of a layout: solver variant per job, launch order (by
         variant, then descending cost) and launch geometry.  No device."""
         jobs = np.ascontiguousarray(jobs)
+        self._jobs_sorted = None       # (set by the native ordering)
         sel, (choice, cost, ntask, gbytes, NP, gbytes_oc) = \
             self._classify_classes(None, None, dgraphs, C, tab_bytes, gtab,
                                    oc_only, jobs=jobs)
@@ -1341,8 +1342,8 @@ void ${name}(params_t prm) {
             from ...hip import hostlib
             rank_of_key = np.full(sel.nc * sel.nc, -1, dtype=np.int32)
             rank_of_key[sel.upk] = rank_of
-            order_all = hostlib.order_jobs(sel.pk, rank_of_key,
-                                           int(rank_of.max()) + 1)
+            order_all, self._jobs_sorted = hostlib.order_jobs(
+                sel.pk, rank_of_key, int(rank_of.max()) + 1, jobs)
             members = sel.members
         else:
             rank = rank_of[sel.sel]
@@ -1505,8 +1506,10 @@ void ${name}(params_t prm) {
         lay.b_order = runtime.DeviceBuffer(max(lay.order_host.nbytes, 4))
         lay.b_starts = runtime.DeviceBuffer(max(starts.nbytes, 4))
         # jobs travel in launch order: the kernel reads jobs[t] directly
-        lay.b_jobs.upload(np.ascontiguousarray(
-            jobs[lay.order_host]).view(np.uint32))
+        sorted_jobs = self._jobs_sorted if self._jobs_sorted is not None \
+            else np.ascontiguousarray(jobs[lay.order_host])
+        self._jobs_sorted = None
+        lay.b_jobs.upload(sorted_jobs.view(np.uint32))
         lay.b_order.upload(lay.order_host)
         lay.b_starts.upload(starts)
         # uploads were issued on the null stream; solver launches may go to

@@ -113,9 +113,11 @@ int gdh_pair_keys(const uint32_t *jobs, int64_t n_jobs, const int32_t *cid,
 /* Launch order of the jobs: a stable counting sort of the job ids by
  * rank_of_key[pk[t]] (ranks 0 .. n_ranks - 1: solver variant, then descending
  * cost; jobs of one rank keep their order).  order [n_jobs] receives the job
- * ids. */
+ * ids; with jobs / jobs_sorted (both or neither NULL) the (i, j) records are
+ * written in that order too -- the list the solver kernels read. */
 int gdh_order_jobs(const int32_t *pk, int64_t n_jobs, const int32_t *rank_of_key,
-                   int64_t n_keys, int64_t n_ranks, uint32_t *order);
+                   int64_t n_keys, int64_t n_ranks, uint32_t *order,
+                   const uint32_t *jobs, uint32_t *jobs_sorted);
 
 #ifdef __cplusplus
 }

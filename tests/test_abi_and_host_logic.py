@@ -54,6 +54,13 @@ def test_host_library_exports_every_declared_symbol():
         hostlib.pair_keys(jobs, np.zeros(2, np.int32), 1)
     with pytest.raises(hostlib.HostLibError):      # rank out of range
         hostlib.order_jobs(np.zeros(3, np.int32), np.array([4], np.int32), 2)
+    # the job records travel in launch order
+    jobs = np.array([(0, 1), (2, 3), (4, 5), (6, 7)],
+                    dtype=[('i', np.uint32), ('j', np.uint32)])
+    order, moved = hostlib.order_jobs(np.array([1, 0, 1, 0], np.int32),
+                                      np.array([1, 0], np.int32), 2, jobs)
+    assert order.tolist() == [0, 2, 1, 3]
+    assert np.array_equal(moved, jobs[order])
 
 
 def test_device_calls_fail_loudly_without_a_gpu():
