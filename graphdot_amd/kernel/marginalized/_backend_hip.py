@@ -746,9 +746,9 @@ struct ${name}_t : ${name}_theta_t {
                      (1, 20, 4, 4): 4, (1, 24, 4, 4): 5, (1, 28, 5, 4): 4,
                      (1, 28, 6, 4): 4, (1, 32, 7, 4): 4, (1, 36, 9, 4): 2,
                      (1, 32, 3, 8): 2, (1, 48, 5, 8): 2, (1, 64, 9, 8): 2,
-                     (4, 32, 3, 8): 3, (4, 40, 2, 8): 2, (4, 48, 4, 8): 2,
+                     (4, 32, 3, 8): 4, (4, 40, 2, 8): 4, (4, 48, 4, 8): 2,
                      (4, 64, 5, 8): 3, (8, 40, 2, 8): 4, (8, 48, 3, 8): 4,
-                     (8, 64, 4, 8): 2, (16, 32, 2, 8): 4, (16, 40, 2, 8): 4,
+                     (8, 64, 4, 8): 4, (16, 32, 2, 8): 4, (16, 40, 2, 8): 4,
                      (16, 48, 3, 8): 4, (16, 64, 3, 8): 4},
         (True, 1): {(16,): 4, (16, 4): 4, (16, 4, 1): 3, (16, 4, 4): 3,
                     (16, 4, 4, 1): 3, (16, 4, 4, 1, 1): 2,

@@ -335,7 +335,7 @@ def measured_shard_plan(backend, graphs, node_kernel, edge_kernel, jobs, nX,
     the same plan."""
     dgraphs, edge_kernel, C, fields = backend._graphs_and_kernels(
         graphs, node_kernel, edge_kernel, traits)
-    arena = backend._arena(dgraphs, fields)[0]       # (cached per backend)
+    arena = backend._host_arena(dgraphs, fields)     # (host only: no upload)
     tab_bytes = backend._table_bytes(arena)
     gtab = backend._global_tables(arena)
     jobs = np.ascontiguousarray(jobs)

@@ -445,3 +445,50 @@ def test_block_sharding_and_measured_rebalancing():
     assert before.max() / before.mean() > 1.15
     assert after.max() / after.mean() < 1.04
     assert sorted(np.concatenate(sp.shards).tolist()) == list(range(n))
+
+
+def test_measured_shard_plan_is_host_only_and_covers_every_job():
+    """`_sharded.measured_shard_plan` (what ShardedStep builds its shards
+    from) needs no device: the whole job list is laid out as one rank would
+    launch it, every job gets the table time of its solver variant, the ranks
+    take contiguous blocks of the launch order.  Every job lands in exactly one
+    shard, every shard holds few solver variants, the predicted times are
+    balanced, the plan is the same on every rank, and the merge map is the
+    single-GPU one."""
+    from graphdot_amd.kernel.marginalized._sharded import (
+        measured_shard_plan, cost_table, variant_key)
+    # (large enough that the pairs, not the launch tails, are what is dealt:
+    # on a few thousand pairs the minimax plan rightly leaves ranks idle)
+    G = cases.config3_graphs(400, seed=9)
+    kn, ke, q = cases.config3_kernels()
+    b = HIPBackend(real=np.float64)
+    k = MarginalizedGraphKernel(kn, ke, q=q, backend=b)
+    jobs = k._pairwise_jobs(len(G))
+    table = cost_table()
+    assert any(key.startswith('f64/C1/oc4_') for key in table)   # shipped
+    plans = [measured_shard_plan(b, G, kn, ke, jobs, len(G), len(G),
+                                 k.traits(symmetric=True), r, 4)
+             for r in range(4)]
+    sp = plans[0]
+    assert sp.mode == 'measured'
+    assert sorted(np.concatenate(sp.shards).tolist()) == list(range(len(jobs)))
+    for other in plans[1:]:
+        assert all(np.array_equal(a, c) for a, c in zip(sp.shards,
+                                                        other.shards))
+    assert max(sp.predicted) <= 1.15 * np.mean(sp.predicted)
+    # the merge map is what a single GPU applies to the whole list
+    dgs, ek, C, fields = b._graphs_and_kernels(G, kn, ke,
+                                               k.traits(symmetric=True))
+    arena = b._host_arena(dgs, fields)
+    b._partition(dgs, jobs, C, 0, b._global_tables(arena))
+    assert sp.merge_map == b._last_merge_map
+    # a shard laid out with that map uses only variants the whole list uses
+    _, used_all, _, _ = b._partition(dgs, jobs, C, 0,
+                                     b._global_tables(arena))
+    for s in sp.shards:
+        _, used, order, launches = b._partition(
+            dgs, np.ascontiguousarray(jobs[s]), C, 0,
+            b._global_tables(arena), merge_map=sp.merge_map)
+        assert set(used) <= set(used_all)
+        assert sum(L['count'] for L in launches) == len(s)
+    assert variant_key(b.variants[used_all[0]]).startswith('oc4_W1_')
