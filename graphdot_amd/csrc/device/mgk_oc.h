@@ -218,6 +218,22 @@ template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB,
 struct oc_solver {
     constexpr static bool STATIC = LAY::is_static;
     static_assert(!STATIC || W == 1, "static row-batch layouts are one-wave layouts");
+    // FLY (S = 0): no register slots.  The product-graph operator is NOT
+    // materialised; the owner of a row walks adj(i1) x adj(i2) in every CG
+    // iteration and evaluates the edge microkernel per term, as the reference
+    // does (marginalized_kernel.h:299-300,346) -- for graphs whose rows have
+    // hundreds of terms (from_ase-like molecular graphs: 88 % dense adjacency,
+    // degree up to n - 1; up to 2.5e5 terms per pair against the 6.5e4
+    // register slots of a 1024-lane workgroup).  Rows stay in natural order
+    // (dense graphs have near-equal degrees: nothing to sort), any degree.
+    constexpr static bool FLY = S == 0;
+    static_assert(!FLY || (C == 1 && !NGRAD && !MAXIMIN && !STATIC),
+                  "the on-the-fly solver is a value solver (graph-level or nodal outputs)");
+    constexpr static int SA = S > 0 ? S : 1;    // slot array extent
+#ifndef GD_FLY_U
+#define GD_FLY_U 4
+#endif
+    constexpr static int FLY_U = GD_FLY_U;      // terms per trip of the inner loop
     static_assert(!MAXIMIN || (NODAL && C == 1), "the maximin epilogue works on the nodal solution of a value solve");
     using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
     using PF = std::conditional_t<NGRAD, params_fd_t<real, Graph, NodeK, EdgeK, PStart>, P>;
@@ -231,7 +247,7 @@ struct oc_solver {
     constexpr static int NC = DMAX + 1;         // degree classes 0..DMAX
     constexpr static int NCP = NC * NC;         // degree-pair rectangles
     constexpr static int NTAB = ((NCP + 63) / 64) * 64;
-    constexpr static int NM = (S + 31) / 32;    // 32-bit flush-mask words
+    constexpr static int NM = S > 0 ? (S + 31) / 32 : 1;    // 32-bit flush-mask words
 #ifndef GD_OC_CHUNK
 #define GD_OC_CHUNK 4
 #endif
@@ -250,7 +266,7 @@ struct oc_solver {
 #define GD_OC_GCH 8
 #endif
     constexpr static int GCH = GD_OC_GCH;       // gathers in flight
-    constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4 && !STATIC;
+    constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4 && !STATIC && !FLY;
 #ifndef GD_OC_PACK
 #define GD_OC_PACK 1
 #endif
@@ -261,9 +277,9 @@ struct oc_solver {
     // profiles/r02_c2_pmc.csv).  Packed, a slot costs one extra VALU per
     // iteration (the unpack, kept inside the loop) and half an address
     // register.  The one-pass float value solvers only.
-    constexpr static bool PACK = GD_OC_PACK != 0 && sizeof(real) == 4 && C == 1 && !NODAL && !STATIC &&
+    constexpr static bool PACK = GD_OC_PACK != 0 && sizeof(real) == 4 && C == 1 && !NODAL && !STATIC && !FLY &&
                                  ((S >= 64 && W >= 8) || GD_OC_PACK == 2);
-    constexpr static int NADR = PACK ? (S + 1) / 2 : S;
+    constexpr static int NADR = PACK ? (S + 1) / 2 : SA;
     // LEAN (static layouts, value + gradient): the solution x lives in a
     // lane-private LDS region and p only in its published copy -- the update
     // block re-reads p (once for A p, once for the x / p update) and
@@ -272,7 +288,7 @@ struct oc_solver {
     // registers across the gather phase: the two-right-hand-side solver is
     // what the register file limits to two waves per SIMD in double.
     constexpr static bool LEAN = STATIC && C == 2 && !NODAL;
-    constexpr static bool HAS_Y = !STATIC || LEAN;   // the [Y] region exists
+    constexpr static bool HAS_Y = (!STATIC && !FLY) || LEAN;   // the [Y] region exists
     template<class L> constexpr static bool layout_matches() {
         if constexpr (L::is_static) return L::S == S && L::R == R;
         else return true;
@@ -399,7 +415,7 @@ struct oc_solver {
                     }
                 }
                 // lane-private row sums: rows of batches that own no slots read 0
-                if constexpr (!STATIC) {
+                if constexpr (!STATIC && !FLY) {
 #pragma unroll
                     for (int k = 0; k < R; ++k)
 #pragma unroll
@@ -428,7 +444,7 @@ struct oc_solver {
 
             // ---- degree histograms -> offsets of the degree-pair rectangles ---
             // (every wave computes the same wave-uniform numbers)
-            {
+            if constexpr (!FLY) {
                 // (the packer leaves the degree histogram of every graph in its
                 // header: scalar registers, no ballots over the row pointers)
                 int cnt1[NC], cnt2[NC];
@@ -461,12 +477,16 @@ struct oc_solver {
                     const bool ok = k * T + tid < N;
                     const int i1 = ok ? row.hi : 0, i2 = ok ? row.lo : 0;
                     row.next();
+                    if constexpr (FLY) {      // natural order
+                        if (ok) rowmap[k * T + tid] = ((unsigned)i1 << 16) | (unsigned)i2;
+                    } else {
                     const int d1 = (int)lrp1[i1 + 1] - (int)lrp1[i1];
                     const int d2 = (int)lrp2[i2 + 1] - (int)lrp2[i2];
                     const int pos = lds.tab_off[d1 * NC + d2] +
                                     (i1 - lds.tab_cls[d1]) * lds.tab_cls[16 + d2] +
                                     (i2 - lds.tab_cls[32 + d2]);
                     if (ok) rowmap[pos] = ((unsigned)i1 << 16) | (unsigned)i2;
+                    }
                 }
             }
             job_sync<W>();
@@ -516,7 +536,7 @@ struct oc_solver {
             };
 
             // ---- nonzero slots owned by this thread ---------------------------
-            real val[S];
+            real val[SA];
             unsigned adr[NADR];   // LDS byte address of the gathered element of p (two-pass setup: first (a << 16) | b, or ~0u; PACK: two per register)
             const unsigned lp_off = lds_offset(lp);
             constexpr unsigned ELEM = C * sizeof(real);
@@ -524,7 +544,7 @@ struct oc_solver {
 #pragma unroll
             for (int w = 0; w < NM; ++w) fm[w] = 0;
             int n_slots = 0;
-            {
+            if constexpr (!FLY) {
                 if constexpr (STATIC) {
                     // batch k is live if it has rows: its slots end at a
                     // compile-time position
@@ -657,12 +677,14 @@ struct oc_solver {
             real pp[KEEP_X ? 1 : R];   // p1(i1) p2(i2) of the rows
             real xs = 0;               // this lane's share of sum_i pp_i x_i
             int paddr[R];
+            [[maybe_unused]] unsigned rowid[FLY ? R : 1];   // FLY: (i1 << 16) | i2, ~0u for dead rows
             real rTz = 0;
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int pos = row_pos(k, wv, lane);
                 const bool ok = pos < N;
                 const unsigned rm = rowmap[ok ? pos : 0];
+                if constexpr (FLY) rowid[k] = ok ? rm : ~0u;
                 const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
                 const node_t v1 = at32(g1.node, (unsigned)i1), v2 = at32(g2.node, (unsigned)i2);
                 const real dx = real(at32(g1.degree, (unsigned)i1)) *
@@ -710,14 +732,69 @@ struct oc_solver {
                 job_sync<W>();   // p published
                 // row sums: sum over the slots of a batch, flushed to the
                 // lane-private cell Y[batch][lane] at wave-uniform positions
-                [[maybe_unused]] real ys[C][STATIC ? R : 1];   // static layouts: the row sums
-                if constexpr (STATIC) {
+                [[maybe_unused]] real ys[C][(STATIC || FLY) ? R : 1];   // static layouts / FLY: the row sums
+                if constexpr (STATIC || FLY) {
 #pragma unroll
                     for (int k = 0; k < R; ++k)
 #pragma unroll
                         for (int c = 0; c < C; ++c) ys[c][k] = 0;
                 }
-                {
+                if constexpr (FLY) {
+                    // the owner of row (i1, i2) walks adj(i1) x adj(i2) and
+                    // evaluates the edge microkernel per term (per-lane trip
+                    // counts: the EXEC mask narrows as lanes finish)
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const unsigned rm = rowid[k];
+                        const bool live = rm != ~0u;
+                        const unsigned i1 = live ? rm >> 16 : 0u, i2 = live ? rm & 0xFFFFu : 0u;
+                        const unsigned a0 = lrp1[i1], a1 = live ? (unsigned)lrp1[i1 + 1] : a0;
+                        const unsigned b0 = lrp2[i2], b1 = live ? (unsigned)lrp2[i2 + 1] : b0;
+                        real acc = 0;
+                        for (unsigned a = a0; a < a1; ++a) {
+                            const edge_t e1 = at32(g1.edge, a);
+                            const unsigned rowp = lp_off + __umul24((unsigned)at32(g1.nz, a).j, (unsigned)ldp) * (unsigned)sizeof(real);
+                            [[maybe_unused]] unsigned c1 = 0;
+                            [[maybe_unused]] real w1 = 1;
+                            if constexpr (TAB) {
+                                c1 = __umul24((unsigned)ecls1[a], nec);
+                                if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                                    w1 = real(edge_weight<edge_t>::get(e1));
+                            }
+                            // FLY_U terms per trip, indices clamped to the row's last
+                            // element and the surplus zeroed: the loads of a trip are
+                            // independent (one LDS latency per trip, not per term)
+                            real part[FLY_U];
+#pragma unroll
+                            for (int u = 0; u < FLY_U; ++u) part[u] = 0;
+                            const unsigned blast = b1 - 1u;     // (b1 > b0 inside the loop)
+                            for (unsigned b = b0; b < b1; b += FLY_U) {
+                                real e[FLY_U], pv[FLY_U];
+#pragma unroll
+                                for (int u = 0; u < FLY_U; ++u) {
+                                    const unsigned bb = b + u < b1 ? b + u : blast;
+                                    const unsigned col = (unsigned)at32(g2.nz, bb).j;
+                                    if constexpr (TAB) {
+                                        e[u] = at32(ketab, c1 + ecls2[bb]);
+                                        if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                                            e[u] *= real(edge_weight<edge_t>::get(at32(g2.edge, bb)));
+                                    } else {
+                                        e[u] = real(prm.edge_kernel(e1, at32(g2.edge, bb)));
+                                    }
+                                    pv[u] = load_real_at<real>(rowp + col * (unsigned)sizeof(real));
+                                }
+#pragma unroll
+                                for (int u = 0; u < FLY_U; ++u)
+                                    part[u] += (b + u < b1) ? e[u] * pv[u] : real(0);
+                            }
+                            real psum = 0;
+#pragma unroll
+                            for (int u = 0; u < FLY_U; ++u) psum += part[u];
+                            acc += TAB ? psum * w1 : psum;
+                        }
+                        ys[0][k] = acc;
+                    }
+                } else {
                     real acc[C];
 #pragma unroll
                     for (int c = 0; c < C; ++c) acc[c] = 0;
@@ -840,7 +917,7 @@ struct oc_solver {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
                     real y[C];
-                    if constexpr (STATIC) {
+                    if constexpr (STATIC || FLY) {
 #pragma unroll
                         for (int c = 0; c < C; ++c) y[c] = ys[c][k];
                     } else {

@@ -256,8 +256,10 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
         const int64_t N = n1 * n2, np_ = n1 * (n2 | 1);
         NP[t] = np_;
         choice[t] = -1;
-        const int pmd = std::max(maxdeg[a], maxdeg[b]);
-        if (pmd > 15) continue;
+        const int pmd_true = std::max(maxdeg[a], maxdeg[b]);
+        // (the histograms resolve degrees up to 14: graphs beyond that can
+        // only take the on-the-fly variants, S = 0)
+        const int pmd = std::min(pmd_true, 15);
         const int64_t gbytes = std::max(image_bytes[a], image_bytes[b]);
         // cumulative sizes of the degree-pair rectangles in sorted row order
         // (only the rectangles of classes <= pmd can be non-empty)
@@ -294,18 +296,21 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
             }
         }
         for (int32_t v = 0; v < n_var; ++v) {
-            if (pmd > D[v]) continue;
+            const bool fly = S[v] == 0;
+            if (!fly && (pmd_true > D[v] || pmd_true > 14)) continue;
             const int64_t T = 64 * (int64_t)W[v];
-            if (N > T * R[v] || np_ >= 0xFFFF) continue;
+            if (N > T * R[v] || np_ >= (fly ? 0x3FFF : 0xFFFF)) continue;
             const int64_t NR = T * R[v];
             const int64_t pcap = (np_ + 1 + 3) / 4 * 4;
-            const int64_t NRy = (n_L[v] > 0 && C != 2) ? 0 : NR;
+            const int64_t NRy = ((n_L[v] > 0 && C != 2) || fly) ? 0 : NR;
             const int64_t lds = (pcap + NRy) * C * real_size + 4 * NR + 2 * gbytes +
                                 4 * (int64_t)W[v] * real_size + 4 * (D[v] > 6 ? 128 : 64) + 256 + 16;
             if (lds > lds_limit) continue;
             const int64_t nb = (N + T - 1) / T;
             bool ok = true;
-            if (n_L[v] > 0) {      // static layout: every batch under its segment
+            if (fly) {             // on-the-fly: any degree, value solves only
+                ok = C == 1;
+            } else if (n_L[v] > 0) {      // static layout: every batch under its segment
                 for (int64_t k = 0; k < nb && ok; ++k) {
                     const int cap = k < n_L[v] && k < MAXL ? L[(size_t)v * MAXL + k] : 0;
                     ok = (W[v] == 1 && k <= MAXL ? trips1[k] : trip_at(k * T)) <= cap;

@@ -73,6 +73,14 @@ OC_STATIC_VARIANTS = [
     OCStatic(16, 4, 4, 3, 1, 1), OCStatic(16, 4, 4, 4, 1, 1, 1),
     OCStatic(16, 4, 4, 4, 3, 1, 1, 1), OCStatic(16, 4, 4, 4, 4, 1, 1, 1, 1),
 ]
+#: on-the-fly variants (mgk_oc.h FLY: S = 0, D = 0): no register slots, the
+#: edge microkernel is evaluated per term in every iteration; any degree.
+#: For the pairs no slot variant fits (dense from_ase-like graphs), value
+#: solves only.
+OC_FLY_VARIANTS = [
+    OCVariant(4, 0, 1, 0), OCVariant(4, 0, 2, 0), OCVariant(4, 0, 3, 0),
+    OCVariant(8, 0, 2, 0), OCVariant(16, 0, 2, 0), OCVariant(16, 0, 4, 0),
+]
 OC_VARIANTS = OC_STATIC_VARIANTS + [
     OCVariant(1, 12, 2, 4), OCVariant(1, 16, 3, 4), OCVariant(1, 20, 3, 4),
     OCVariant(1, 20, 4, 4), OCVariant(1, 24, 4, 4), OCVariant(1, 28, 5, 4),
@@ -83,7 +91,7 @@ OC_VARIANTS = OC_STATIC_VARIANTS + [
     OCVariant(8, 40, 2, 8), OCVariant(8, 48, 3, 8), OCVariant(8, 64, 4, 8),
     OCVariant(16, 32, 2, 8), OCVariant(16, 40, 2, 8), OCVariant(16, 48, 3, 8),
     OCVariant(16, 64, 3, 8),
-]
+] + OC_FLY_VARIANTS
 #: sentinel: the global-memory general solver (any pair size)
 GENERAL = Variant(0, 0, 0)
 #: sentinel: the kernel that fills the global microkernel tables
@@ -795,12 +803,18 @@ struct ${name}_t : ${name}_theta_t {
         f64 = np.dtype(self.real) == np.float64
         return v.L not in self._STATIC_OFF.get((f64, C), ())
 
+    _FLY_WAVES = int(os.environ.get('GD_FLY_WAVES', 3))
+
     def _oc_waves(self, v, C, ngrad=False):
         """Occupancy target of an owner-computes variant: per lane S values +
         S gather indices, 6 registers per row (x, r, p, diagonal, its inverse,
         the publish address), the gathers in flight and ~24 others; a double
         takes two registers."""
         f64 = np.dtype(self.real) == np.float64
+        if v.S == 0:
+            # on-the-fly kernels: no slot arrays, but the unrolled term loops
+            # keep ~140 registers busy (spill-free at three waves per SIMD)
+            return max(self._FLY_WAVES, -(-64 * v.W // 256))
         hit = self._OC_WAVES.get((f64, C), {}).get(
             v.L if v.L else tuple(v)[:4])
         if hit and not ngrad:
@@ -839,7 +853,7 @@ void ${name}(${params} prm) {
             maximin='true' if maximin else 'false',
             layout=('graphdot::mgk::seg_layout<%s>' % ', '.join(map(str, v.L))
                     if v.L else 'graphdot::mgk::dynamic_layout'),
-            S=v.S, R=v.R, W=v.W, C=C, D=v.D,
+            S=v.S, R=v.R, W=v.W, C=C, D=v.D if v.S else 1,
             waves=self._oc_waves(v, C, ngrad) if ngrad
             else self.waves_per_eu(v, C),
             nodal='true' if nodal else 'false',
@@ -917,7 +931,7 @@ void ${name}(params_t prm) {
             pcap = -(-(np.asarray(ntask) + 1) // 4) * 4
             # static layouts keep the row sums in registers: no Y region,
             # except the value + gradient solvers, which keep x there
-            NR_y = 0 if (v.L and C != 2) else NR
+            NR_y = 0 if ((v.L and C != 2) or v.S == 0) else NR
             return (pcap + NR_y) * C * rs + 4 * NR + 2 * np.asarray(gbytes) \
                 + 4 * v.W * rs + 4 * (128 if v.D > 6 else 64) + 256 + 16
         wpb = WPB1 if v.W == 1 else 1
@@ -1120,6 +1134,8 @@ void ${name}(params_t prm) {
         maxdeg = np.array([g.max_degree for g in dgraphs], dtype=np.int64)
         pair_maxdeg = np.maximum(maxdeg[ji], maxdeg[jj])
         oc_slots, hists, trips = {}, {}, {}
+        # (FLY kernels have no nodal-gradient / maximin flavour)
+        fly_off = oc_only or os.environ.get('GD_OC_FLY') == '0'
         # `rem`: the jobs without a variant yet -- every test below runs on
         # that shrinking subset only (most jobs leave in the first variants)
         rem = np.arange(len(ji))
@@ -1133,7 +1149,8 @@ void ${name}(params_t prm) {
         if native_oc:
             from ...hip import hostlib
             menu = [(k, v) for k, v in enumerate(self.variants[:n_oc])
-                    if not v.L or self._static_enabled(v, C)]
+                    if (not v.L or self._static_enabled(v, C))
+                    and (v.S > 0 or (C == 1 and not fly_off))]
             hist = degree_histograms(dgraphs)
             ch, _ = hostlib.classify_oc(
                 ji, jj, n_node, n_nz, image_oc, maxdeg, hist,
@@ -1152,6 +1169,16 @@ void ${name}(params_t prm) {
                 if tab_bytes or native_oc:  # (table kernels: two-stage only)
                     continue
                 if v.L and not self._static_enabled(v, C):
+                    continue
+                if v.S == 0:
+                    # on-the-fly: any degree, value solves only
+                    if C != 1 or fly_off:
+                        continue
+                    fits = (N[rem] <= 64 * v.W * v.R) & (NP[rem] < 0x3FFF)
+                    fits &= self.lds_bytes(v, C, NP[rem], gbytes_oc[rem]) \
+                        <= LDS_LIMIT
+                    choice[rem[fits]] = k
+                    rem = rem[~fits]
                     continue
                 fits = ((pair_maxdeg[rem] <= v.D) & (N[rem] <= 64 * v.W * v.R)
                         & (NP[rem] < 0xFFFF))
@@ -1375,8 +1402,8 @@ void ${name}(params_t prm) {
                 pcap = int(-(-(NP[idx].max() + 1) // 4) * 4)
                 gcap = int(-(-gbytes_oc[idx].max() // 16) * 16)
                 NR = 64 * v.W * v.R
-                dyn = (pcap + (0 if (v.L and C != 2) else NR)) * C * rsize \
-                    + 4 * NR + 2 * gcap
+                dyn = (pcap + (0 if ((v.L and C != 2) or v.S == 0)
+                               else NR)) * C * rsize + 4 * NR + 2 * gcap
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=pcap, gcap=gcap,
                     dynamic_lds=dyn, count=count,

@@ -146,6 +146,8 @@ def test_job_classification_respects_variant_capacity():
         assert n[a] * (n[b] | 1) <= 64 * v.W * v.R
         ldu = nz[a] + 1
         assert ntask[k] == max(ldu * n[b], n[a] + n[b] + 2)
+        if getattr(v, 'S', 1) == 0:
+            continue        # on-the-fly variant: no register slots to fit
         # brute-force the stage-1 walk of mgk_solver.h for this job
         T = 64 * v.W
         deg = dgs[b].adjacency_count
@@ -492,3 +494,34 @@ def test_measured_shard_plan_is_host_only_and_covers_every_job():
         assert set(used) <= set(used_all)
         assert sum(L['count'] for L in launches) == len(s)
     assert variant_key(b.variants[used_all[0]]).startswith('oc4_W1_')
+
+
+def test_dense_graphs_classify_into_the_on_the_fly_variants():
+    """Pairs whose rows have more terms than any register-slot variant holds
+    (degree above 8: dense from_ase-like graphs) are assigned the on-the-fly
+    variants (S = 0) for value solves -- natively and in numpy alike -- and
+    the two-stage / general solvers for gradients, which have no on-the-fly
+    flavour."""
+    from graphdot_amd.kernel.marginalized._backend_hip import OCVariant
+    G = cases.tang2019_graphs(30, seed=1)
+    kn, ke, q = cases.tang2019_kernels()
+    i, j = np.triu_indices(len(G))
+    got = {}
+    for native in (True, False):
+        b = HIPBackend(native=native)
+        dgs = [b._register_graph(g) for g in G]
+        assert max(d.max_degree for d in dgs) > 8
+        c1, *_ = b.classify(i, j, dgs, 1)
+        c2, *_ = b.classify(i, j, dgs, 2)
+        got[native] = (c1, c2)
+        v1 = [b.variants[c] for c in c1]
+        assert sum(isinstance(v, OCVariant) and v.S == 0 for v in v1) \
+            > 0.9 * len(v1)
+        for c, a, bb in zip(c1, i, j):
+            v = b.variants[c]
+            if isinstance(v, OCVariant) and v.S == 0:
+                assert dgs[a].n_node * dgs[bb].n_node <= 64 * v.W * v.R
+        assert not any(isinstance(b.variants[c], OCVariant)
+                       and b.variants[c].S == 0 for c in c2)
+    assert np.array_equal(got[True][0], got[False][0])
+    assert np.array_equal(got[True][1], got[False][1])

@@ -804,6 +804,50 @@ def test_maximin_distance(backend):
 
 
 @pytest.mark.parametrize('real', [np.float32, np.float64])
+def test_dense_graphs_take_the_on_the_fly_solver(real):
+    """Dense, from_ase-like molecular graphs (the reference's flagship preset,
+    kernel/molecular.py:47-66: tent-weighted adjacency within 3 sqrt(r_i r_j),
+    degree up to n - 1, continuous edge lengths) do not fit the register-slot
+    solvers (rows of several hundred terms); they take the on-the-fly
+    variants of mgk_oc.h (S = 0: the edge microkernel is evaluated per term in
+    every iteration, as the reference does).  Graph-level and nodal values,
+    X x Y blocks and lmin = 1 against the dense oracle."""
+    from graphdot_amd.kernel.marginalized._backend_hip import (
+        HIPBackend, OCVariant)
+    G = cases.tang2019_graphs(14, seed=5)
+    knode, kedge, q = cases.tang2019_kernels()
+    assert max(len(g.edges) * 2 / len(g.nodes) for g in G) > 9   # mean degree
+    f64 = real is np.float64
+    be = HIPBackend(real=real, record_iterations=True)
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=be,
+                                **({'ftol': 1e-13} if f64 else {}))
+    K = k(G)
+    used = {L['variant'] for L in be.last_plan.launches}
+    assert all(isinstance(v, OCVariant) for v in used)
+    assert any(v.S == 0 for v in used), used          # on the fly
+    ref = oracle.gram(G, knode, kedge, q=q)
+    rtol = 1e-9 if f64 else 1e-5
+    assert np.allclose(K, ref, rtol=rtol), np.abs(K / ref - 1).max()
+    assert np.array_equal(K, K.T)
+    # iteration counts are the restatement's (same stopping rule)
+    it = be.iterations(be.last_plan)
+    assert 2 <= it.min() and it.max() <= 64
+    Kn = k(G[:5], nodal=True)
+    refn = oracle.gram(G[:5], knode, kedge, q=q, nodal=True)
+    assert np.allclose(Kn, refn, rtol=rtol, atol=rtol * np.abs(refn).max())
+    Kxy = k(G[:4], G[4:9], lmin=1)
+    refxy = oracle.gram(G[:4], knode, kedge, Y=G[4:9], q=q, lmin=1)
+    assert np.allclose(Kxy, refxy, rtol=10 * rtol)
+    d = k.diag(G)
+    assert np.allclose(d, np.diag(ref), rtol=rtol)
+    # the gradient of such graphs stays with the two-stage solvers
+    K2, dK = k(G[:4], eval_gradient=True)
+    assert not any(getattr(L['variant'], 'S', 1) == 0
+                   for L in be.last_plan.launches)
+    assert np.allclose(K2, ref[:4, :4], rtol=rtol) and np.all(np.isfinite(dK))
+
+
+@pytest.mark.parametrize('real', [np.float32, np.float64])
 def test_maximin_pinned_to_the_reference(real):
     """The fused maximin epilogue (mgk_oc.h MAXIMIN / NGRAD) against
     tests/golden/maximin.json -- the REFERENCE's CPU solutions (M3._mlgk)
