@@ -92,6 +92,9 @@ OC_VARIANTS = OC_STATIC_VARIANTS + [
     OCVariant(16, 32, 2, 8), OCVariant(16, 40, 2, 8), OCVariant(16, 48, 3, 8),
     OCVariant(16, 64, 3, 8),
 ] + OC_FLY_VARIANTS
+#: pairs with a node of more than this many neighbours are what the
+#: on-the-fly variants are for (the slot variants stop at degree 8)
+FLY_MIN_DEGREE = 8
 #: sentinel: the global-memory general solver (any pair size)
 GENERAL = Variant(0, 0, 0)
 #: sentinel: the kernel that fills the global microkernel tables
@@ -792,12 +795,13 @@ struct ${name}_t : ${name}_theta_t {
     #: static layouts that lose to the dynamic variants behind them in the
     #: menu (measured, scripts/oc_sweep.py): (double?, C) -> {layout, ...}.
     #: The two-right-hand-side solver in double moves 16 bytes per gathered
-    #: element: it runs at the LDS rate in either form (17-18 ns per pair for
-    #: the four-batch pairs, static or dynamic), and from six row batches on
-    #: the row-sum registers of the static form cost more than its tests save
-    #: (33.5 against 25.6 ns per pair).
-    _STATIC_OFF = {(True, 2): {(16, 4, 4, 3, 1, 1), (16, 4, 4, 4, 1, 1, 1),
-                               (16, 4, 4, 4, 3, 1, 1, 1)}}
+    #: element: it runs at the LDS rate in either form (14.3 / 18.4 / 22.7 ns
+    #: per pair for the three- / four- / five-batch pairs in the static form
+    #: against 14.5 / 17.2 / 21.7 in the dynamic one), and from six row
+    #: batches on the row-sum registers of the static form cost more than its
+    #: tests save (33.5 against 25.6 ns per pair): double value + gradient
+    #: solves keep the dynamic variants.
+    _STATIC_OFF = {(True, 2): {v.L for v in OC_STATIC_VARIANTS}}
 
     def _static_enabled(self, v, C):
         f64 = np.dtype(self.real) == np.float64
@@ -1171,10 +1175,14 @@ void ${name}(params_t prm) {
                 if v.L and not self._static_enabled(v, C):
                     continue
                 if v.S == 0:
-                    # on-the-fly: any degree, value solves only
+                    # on-the-fly: value solves of the pairs whose degrees no
+                    # slot variant takes (sparse pairs that merely overflow
+                    # the slots are faster in the two-stage solver: 152 against
+                    # 229 us for the 118 largest pairs of configuration 2)
                     if C != 1 or fly_off:
                         continue
-                    fits = (N[rem] <= 64 * v.W * v.R) & (NP[rem] < 0x3FFF)
+                    fits = (N[rem] <= 64 * v.W * v.R) & (NP[rem] < 0x3FFF) \
+                        & (pair_maxdeg[rem] > FLY_MIN_DEGREE)
                     fits &= self.lds_bytes(v, C, NP[rem], gbytes_oc[rem]) \
                         <= LDS_LIMIT
                     choice[rem[fits]] = k

@@ -826,7 +826,11 @@ def test_dense_graphs_take_the_on_the_fly_solver(real):
     assert all(isinstance(v, OCVariant) for v in used)
     assert any(v.S == 0 for v in used), used          # on the fly
     ref = oracle.gram(G, knode, kedge, q=q)
-    rtol = 1e-9 if f64 else 1e-5
+    # (double: 2e-7, not 1e-9 -- the device format keeps the node degrees as
+    # float32 sums of the incident weights like the reference,
+    # _octilegraph.py:109-139, and these weights, 1 - d / cutoff, are not
+    # dyadic: the degrees carry 6e-8 of rounding the float64 oracle does not)
+    rtol = 2e-7 if f64 else 1e-5
     assert np.allclose(K, ref, rtol=rtol), np.abs(K / ref - 1).max()
     assert np.array_equal(K, K.T)
     # iteration counts are the restatement's (same stopping rule)
@@ -842,8 +846,8 @@ def test_dense_graphs_take_the_on_the_fly_solver(real):
     assert np.allclose(d, np.diag(ref), rtol=rtol)
     # the gradient of such graphs stays with the two-stage solvers
     K2, dK = k(G[:4], eval_gradient=True)
-    assert not any(getattr(L['variant'], 'S', 1) == 0
-                   for L in be.last_plan.launches)
+    assert not any(isinstance(L['variant'], OCVariant)
+                   and L['variant'].S == 0 for L in be.last_plan.launches)
     assert np.allclose(K2, ref[:4, :4], rtol=rtol) and np.all(np.isfinite(dK))
 
 
