@@ -7,18 +7,26 @@ request of a wide coalesced read -- MI355X_MICROARCH.md, HBM -- this solver's
 reads are narrow gathers, so no x2 is applied; both figures are kept)."""
 import glob
 import json
+import os
 import shutil
 import sys
 import pandas as pd
 
+
+def newest(pattern):
+    """gpurun merges gpurun_out/ instead of replacing it: a directory may
+    hold the files of several profiling runs -- take the latest."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
 src = 'gpurun_out/prof'
-shutil.copy(glob.glob(f'{src}/stats/*/*kernel_stats.csv')[0],
+shutil.copy(newest(f'{src}/stats/*/*kernel_stats.csv'),
             f'profiles/{tag}_kernel_stats.csv')
 shutil.copy(f'{src}/bench.json', f'profiles/{tag}_bench.json')
 rows, traffic = [], {}
 for d in ('pmc_a', 'pmc_b', 'pmc_fetch', 'pmc_write'):
-    f = glob.glob(f'{src}/{d}/*/*counter_collection.csv')[0]
+    f = newest(f'{src}/{d}/*/*counter_collection.csv')
     df = pd.read_csv(f)
     df = df[df.Kernel_Name.str.startswith('mgk')]
     df['dur_us'] = (df.End_Timestamp - df.Start_Timestamp) / 1e3
