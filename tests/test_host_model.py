@@ -449,3 +449,45 @@ def test_graphs_beyond_the_u16_device_format_are_refused():
             with pytest.raises(ValueError, match='65535'):
                 pack_many(Graph.unify_datatype([ok, bad]), native=native)
     assert len(pack_many([ok])) == 1
+
+
+def test_native_packer_on_random_multigraphs():
+    """The native packer against the per-graph packer on 200 seeded random
+    graphs with everything the format has to survive: self loops, repeated
+    edges in both orientations, isolated nodes, permuted node ids, weights
+    whose float32 sums depend on the summation order, integer / float / bool
+    attributes -- blobs, permutations, CSR arrays and degree histograms byte
+    for byte; and the job layout of their pairs natively and in numpy."""
+    from graphdot_amd.graph import Graph
+    from graphdot_amd.kernel.marginalized._devicegraph import (
+        DeviceGraph, GraphArena, pack_many)
+    rng = np.random.default_rng(20251003)
+    graphs = []
+    for _ in range(200):
+        n = int(rng.integers(1, 14))
+        m = int(rng.integers(1, 3 * n + 2))
+        ids = rng.permutation(n)
+        graphs.append(Graph(
+            nodes={'!i': ids, 'z': rng.integers(1, 9, n).astype(np.int8),
+                   'c': rng.normal(size=n).astype(np.float32),
+                   'a': rng.integers(0, 2, n).astype(bool)},
+            edges={'!i': rng.integers(0, n, m), '!j': rng.integers(0, n, m),
+                   '!w': rng.uniform(0.1, 3.0, m).astype(np.float32),
+                   'o': rng.choice([1.0, 1.5, 2.0], m).astype(np.float32),
+                   's': rng.integers(0, 3, m).astype(np.int8)}))
+    graphs = Graph.unify_datatype(graphs)
+    for real in (np.float32, np.float64):
+        a = pack_many(graphs, real, native=True)
+        b = [DeviceGraph(g, real) for g in graphs]
+        for x, y in zip(a, b):
+            assert np.array_equal(x.blob, y.blob)
+            assert np.array_equal(x.perm, y.perm)
+            assert np.array_equal(x.rowptr, y.rowptr)
+            assert np.array_equal(x.nz, y.nz)
+            assert np.array_equal(x.edge_index, y.edge_index)
+            assert np.array_equal(x.degree, y.degree)
+            assert np.array_equal(x.degree_hist, y.degree_hist)
+        A = GraphArena(a, native=True)
+        B = GraphArena(b, native=False)
+        assert np.array_equal(A.relocated(4096), B.relocated(4096))
+        assert A.classes == B.classes

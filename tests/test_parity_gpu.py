@@ -803,6 +803,62 @@ def test_maximin_distance(backend):
     assert np.all(np.abs(g[..., 0]) <= 2e-2 * np.abs(g).max())
 
 
+def test_mixed_degree_sets_cross_every_solver_family(backend):
+    """One Gram matrix whose pairs fall into every solver family at once --
+    static and dynamic register-slot layouts (degree <= 4 and <= 8), the
+    on-the-fly variants (a dense partner) -- against the dense oracle:
+    the classification boundaries hand no pair to a solver that mis-computes
+    it, and every entry of the matrix is written exactly once."""
+    from graphdot_amd.kernel.marginalized._backend_hip import OCVariant
+    import networkx as nx
+    rng = np.random.default_rng(77)
+    gs = []
+    for kind in ('tree', 'tree', 'nws', 'nws', 'dense', 'dense', 'star',
+                 'path', 'single-edge'):
+        if kind == 'tree':
+            g = nx.random_labeled_tree(int(rng.integers(5, 20)),
+                                       seed=int(rng.integers(1 << 30))) \
+                if hasattr(nx, 'random_labeled_tree') else nx.path_graph(9)
+        elif kind == 'nws':
+            g = nx.newman_watts_strogatz_graph(int(rng.integers(10, 30)), 5,
+                                               0.1, seed=int(rng.integers(1 << 30)))
+        elif kind == 'dense':
+            g = nx.gnp_random_graph(int(rng.integers(11, 18)), 0.9,
+                                    seed=int(rng.integers(1 << 30)))
+        elif kind == 'star':
+            g = nx.star_graph(12)
+        elif kind == 'path':
+            g = nx.path_graph(7)
+        else:
+            g = nx.path_graph(2)
+        for v in g.nodes:
+            g.nodes[v]['category'] = int(rng.integers(1, 4))
+        for e in g.edges:
+            g.edges[e]['w'] = float(rng.choice([0.5, 1.0, 2.0]))
+            g.edges[e]['length'] = float(rng.uniform(0.5, 2.5))
+        gs.append(Graph.from_networkx(g, weight='w'))
+    G = Graph.unify_datatype(gs)
+    knode, kedge, q = cases.config2b_kernels()
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    K = k(G)
+    fam = set()
+    for L in backend.last_plan.launches:
+        v = L['variant']
+        fam.add('fly' if isinstance(v, OCVariant) and v.S == 0 else
+                'slots' if isinstance(v, OCVariant) else 'two-stage')
+    assert {'fly', 'slots'} <= fam, fam
+    ref = oracle.gram(G, knode, kedge, q=q)
+    assert np.allclose(K, ref, rtol=1e-5), np.abs(K / ref - 1).max()
+    assert np.array_equal(K, K.T)
+    Kxy = k(G[:4], G[4:])
+    assert np.allclose(Kxy, ref[:4, 4:], rtol=1e-5)
+    K2, dK = k(G, eval_gradient=True)
+    ref2, dref = oracle.gram(G, knode, kedge, q=q, eval_gradient=True)
+    assert np.allclose(K2, ref, rtol=1e-5)
+    assert elementwise_gradient_error(dK, dref[:, :, k.active_theta_mask],
+                                      2e-3, 2e-5) <= 1.0
+
+
 @pytest.mark.parametrize('real', [np.float32, np.float64])
 def test_dense_graphs_take_the_on_the_fly_solver(real):
     """Dense, from_ase-like molecular graphs (the reference's flagship preset,
