@@ -423,21 +423,29 @@ def pack_many(graphs, real=np.float32, native=True):
     r['no_relocs'] = np.zeros(0, dtype=np.int64)
     r['blob_off'], r['nz_off'] = r['blob_off'].tolist(), r['nz_off'].tolist()
     r['node_off'] = node0.tolist()
-    offs = r['sec_off'].tolist()
+    r['sec_off_list'] = offs = r['sec_off'].tolist()
     maxdeg = r['maxdeg'].tolist()
     nnz = r['nnz'].tolist()
     nl = n.tolist()
-    for b_, k in enumerate(batch):
-        # (the per-graph array views are cut on first use: _BatchMember)
-        dg = _BatchMember.__new__(_BatchMember)
-        dg._b, dg._k = r, b_
-        dg.n_node, dg.n_nz, dg.weighted = nl[b_], nnz[b_], weighted
-        dg.node_t, dg.edge_t, dg.signature = node_t, edge_t, signature
-        o = offs[b_]
-        dg.offsets = dict(zip(SECTIONS, o))
-        dg.image_bytes = _pad(o[5] + 2 * nl[b_])
-        dg._max_degree = maxdeg[b_]
-        out[k] = dg
+    # (a thousand small objects in a row: keep the cyclic collector from
+    # walking the caller's heap in the middle of it -- nothing here can be
+    # part of a cycle)
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        for b_, k in enumerate(batch):
+            # (the per-graph array views are cut on first use: _BatchMember)
+            dg = _BatchMember.__new__(_BatchMember)
+            dg._b, dg._k = r, b_
+            dg.n_node, dg.n_nz, dg.weighted = nl[b_], nnz[b_], weighted
+            dg.node_t, dg.edge_t, dg.signature = node_t, edge_t, signature
+            dg.image_bytes = _pad(offs[b_][5] + 2 * nl[b_])
+            dg._max_degree = maxdeg[b_]
+            out[k] = dg
+    finally:
+        if gc_was_on:
+            gc.enable()
     return out
 
 
@@ -461,6 +469,15 @@ class _BatchMember(DeviceGraph):
     nz = property(lambda self: self._nonzeros('nz'))
     edge_index = property(lambda self: self._nonzeros('eid'))
     relocs = property(lambda self: self._b['no_relocs'])
+
+    @property
+    def offsets(self):
+        try:
+            return self._offsets
+        except AttributeError:
+            self._offsets = dict(zip(SECTIONS,
+                                     self._b['sec_off_list'][self._k]))
+            return self._offsets
 
     @property
     def rowptr(self):
@@ -828,9 +845,15 @@ class GraphArena:
                     word[0] += np.uint64(s)
         if self.n:
             hdr['n_node'], hdr['n_nz'] = n_node, n_nz
-            for name in SECTIONS:          # arena-relative for now
-                hdr[name] = starts + np.array(
-                    [g.offsets[name] for g in dgraphs], dtype=np.int64)
+            b0 = getattr(dgraphs[0], '_b', None)
+            whole_batch = (b0 is not None and len(b0['sec_off']) == self.n
+                           and all(getattr(g, '_b', None) is b0
+                                   and g._k == k
+                                   for k, g in enumerate(dgraphs)))
+            for s_, name in enumerate(SECTIONS):   # arena-relative for now
+                hdr[name] = starts + (
+                    b0['sec_off'][:, s_] if whole_batch else np.array(
+                        [g.offsets[name] for g in dgraphs], dtype=np.int64))
             hdr['hist'] = degree_histograms(dgraphs)
             if cls is not None:
                 # class ids in front of every blob: [node classes, padded to
