@@ -48,6 +48,14 @@
 #define GRAPHDOT_HIP_MGK_OC_H_
 #include "mgk_solver.h"
 
+// -DGD_MARKS: phase names as comments in the ISA (scripts/isa_phases.py counts
+// the instructions between them)
+#ifdef GD_MARKS
+#define GD_MARK(name) asm volatile("; GDMARK " #name)
+#else
+#define GD_MARK(name) ((void)0)
+#endif
+
 namespace graphdot {
 namespace mgk {
 
@@ -289,6 +297,24 @@ struct oc_solver {
     // what the register file limits to two waves per SIMD in double.
     constexpr static bool LEAN = STATIC && C == 2 && !NODAL;
     constexpr static bool HAS_Y = (!STATIC && !FLY) || LEAN;   // the [Y] region exists
+#ifndef GD_OC_GRID
+#define GD_OC_GRID 1
+#endif
+    // GRID (static layouts whose first batch has DMAX^2 slots): slot
+    // s = u DMAX + v of the first batch is the term (u-th nonzero of row i1,
+    // v-th nonzero of row i2) of the batch's row, valid if u < d1 and v < d2 --
+    // every row has degrees <= DMAX, so every row of the batch fits the grid.
+    // The labels, columns and table offsets are read once per u and per v
+    // (2 DMAX reads) instead of once per slot (DMAX^2), and a slot is an add
+    // for its gather address, an add for its table offset and a select: the
+    // running-index walk costs 20 VALU per slot, and the setup is a third of
+    // a pair's instructions.
+    template<class L> constexpr static int grid_slots() {
+        if constexpr (L::is_static && GD_OC_GRID != 0 && !NGRAD) return L::T.end[0] == DMAX * DMAX ? DMAX * DMAX : 0;
+        else return 0;
+    }
+    constexpr static int G0 = grid_slots<LAY>();
+    static_assert(G0 == 0 || ONE_PASS, "the grid walk belongs to the one-pass slot setup");
     template<class L> constexpr static bool layout_matches() {
         if constexpr (L::is_static) return L::S == S && L::R == R;
         else return true;
@@ -321,6 +347,31 @@ struct oc_solver {
 
     __device__ static __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+    // A load for the scalar unit: the address is wave-uniform and the memory
+    // (job list, graph headers) is not written while the kernel runs, which
+    // the constant address space states -- the compiler cannot prove it of a
+    // global pointer inside a loop that also stores results, and falls back to
+    // vector loads plus v_readfirstlane, with every number derived from the
+    // header computed per lane.
+#ifndef GD_OC_SLOAD
+#define GD_OC_SLOAD 1
+#endif
+    template<class V> __device__ static __forceinline__ V scalar_load(V const *ptr) {
+        if constexpr (GD_OC_SLOAD != 0) {
+            static_assert(sizeof(V) % 4 == 0, "whole dwords");
+            typedef const unsigned __attribute__((address_space(4))) *const_words;
+            const_words w = (const_words)(std::uintptr_t)ptr;
+            unsigned buf[sizeof(V) / 4];
+#pragma unroll
+            for (unsigned k = 0; k < sizeof(V) / 4; ++k) buf[k] = w[k];
+            V out;
+            __builtin_memcpy(&out, buf, sizeof(V));
+            return out;
+        } else {
+            return *ptr;
+        }
+    }
+
     // alpha and beta of the CG recurrence, a / b of two wave-uniform numbers.
     // Double: v_rcp_f64 and two Newton steps, then one product -- 6
     // instructions for a result within 1.5 ulp, against the 9 to 11 of the
@@ -352,6 +403,14 @@ struct oc_solver {
     struct row_t {        // the row a lane is filling slots for
         int i1, i2, rs1, rs2, d1, d2, prod;
     };
+    constexpr static int GD_ = G0 ? DMAX : 1;
+    struct grid_t {       // GRID: the first batch's row as 2 DMAX half-terms
+        unsigned a[GD_], b[GD_];      // element indices (clamped into the row)
+        unsigned j1[GD_], j2[GD_];    // lp byte address = j1[u] + j2[v]
+        unsigned t1[GD_], t2[GD_];    // edge table index = t1[u] + t2[v]
+        bool u[GD_], v[GD_];          // u < d1, v < d2
+        int row;                      // i1 * ldp + i2
+    };
 
     __device__ static __forceinline__ void run(PF const &full, lds_t &lds, real *dyn) {
         P const &prm = common(full);
@@ -373,8 +432,8 @@ struct oc_solver {
         const int dump = (int)prm.u_capacity - 1;   // cell that dead rows publish to
 
         for (unsigned t = blockIdx.x; t < prm.n_launch_jobs; t += gridDim.x) {
-            const job_t job = prm.jobs[t];
-            const graph_header_t h1 = headers[job.i], h2 = headers[job.j];
+            const job_t job = scalar_load(prm.jobs + t);
+            const graph_header_t h1 = scalar_load(headers + job.i), h2 = scalar_load(headers + job.j);
             const int n1 = h1.n_node, n2 = h2.n_node, N = n1 * n2;
             const int ldp = n2 | 1;            // odd row stride of p: banks spread
             const real q = prm.q, q0 = prm.q0;
@@ -386,6 +445,7 @@ struct oc_solver {
             const unsigned cb1 = TAB ? (nzpad1 + (((unsigned)h1.n_nz + 3u) & ~3u) + 15u) & ~15u : 0u;
             const unsigned cb2 = TAB ? (nzpad2 + (((unsigned)h2.n_nz + 3u) & ~3u) + 15u) & ~15u : 0u;
 
+            GD_MARK(stage);
             // ---- stage both graph images in LDS: one global round trip --------
             job_sync<W>();  // previous pair is done with the LDS regions
             {
@@ -442,6 +502,7 @@ struct oc_solver {
             std::uint16_t const *const lrp2 = g2.rowptr;
             job_sync<W>();
 
+            GD_MARK(rectangles);
             // ---- degree histograms -> offsets of the degree-pair rectangles ---
             // (every wave computes the same wave-uniform numbers)
             if constexpr (!FLY) {
@@ -469,6 +530,7 @@ struct oc_solver {
             }
             job_sync<W>();
 
+            GD_MARK(rowmap);
             // ---- sorted position of every row: rowmap[position] = (i1, i2) ----
             {
                 divmod_walk row(tid, T, n2);
@@ -535,6 +597,31 @@ struct oc_solver {
                 return w;
             };
 
+            // GRID: the first batch's row as 2 DMAX half-terms
+            auto open_grid = [&](unsigned base, unsigned elem) -> grid_t {
+                const row_t r = open_row(0);
+                const bool live = r.prod > 0;
+                grid_t g;
+                g.row = r.i1 * ldp + r.i2;
+#pragma unroll
+                for (int k = 0; k < GD_; ++k) {
+                    g.u[k] = k < r.d1;
+                    g.v[k] = k < r.d2;
+                    // (dead rows read element 0 and gather p[0]: finite)
+                    g.a[k] = live ? (unsigned)r.rs1 + (g.u[k] ? (unsigned)k : 0u) : 0u;
+                    g.b[k] = live ? (unsigned)r.rs2 + (g.v[k] ? (unsigned)k : 0u) : 0u;
+                    const nz_t z1 = at32(g1.nz, g.a[k]), z2 = at32(g2.nz, g.b[k]);
+                    g.j1[k] = base + (live ? __umul24((unsigned)z1.j, (unsigned)ldp) * elem : 0u);
+                    g.j2[k] = live ? (unsigned)z2.j * elem : 0u;
+                    if constexpr (TAB) {
+                        g.t1[k] = __umul24((unsigned)ecls1[g.a[k]], nec);
+                        g.t2[k] = (unsigned)ecls2[g.b[k]];
+                    }
+                }
+                return g;
+            };
+
+            GD_MARK(slots);
             // ---- nonzero slots owned by this thread ---------------------------
             real val[SA];
             unsigned adr[NADR];   // LDS byte address of the gathered element of p (two-pass setup: first (a << 16) | b, or ~0u; PACK: two per register)
@@ -576,16 +663,43 @@ struct oc_solver {
                 if constexpr (ONE_PASS) {
                     // one unrolled pass over the slots (walk_t above)
                     int kb = 0;
-                    walk_t cur = open_walk(0);
+                    walk_t cur = G0 ? walk_t{} : open_walk(0);
+                    [[maybe_unused]] grid_t grid;
+                    [[maybe_unused]] edge_t ge1[GD_], ge2[GD_];
+                    if constexpr (G0 > 0) {
+                        grid = open_grid(lp_off, ELEM);
+                        if constexpr (!TAB || (GD_WEIGHTED && edge_weight<edge_t>::value)) {
+#pragma unroll
+                            for (int k = 0; k < GD_; ++k) {
+                                ge1[k] = at32(g1.edge, grid.a[k]);
+                                ge2[k] = at32(g2.edge, grid.b[k]);
+                            }
+                        }
+                    }
     #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         // (limits the scheduler's hoisting of loads -- and with it the
                         // live registers -- to SETUP_CHUNK slots)
                         if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
-                        const bool ok = cur.valid();
+                        real e;
+                        bool ok;
+                        unsigned col;
+                        if (s < G0) {
+                            const int gu = s / GD_, gv = s % GD_;
+                            ok = grid.u[gu] && grid.v[gv];
+                            if constexpr (TAB) {
+                                e = at32(ketab, grid.t1[gu] + grid.t2[gv]);
+                                if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                                    e *= real(edge_weight<edge_t>::get(ge1[gu])) *
+                                         real(edge_weight<edge_t>::get(ge2[gv]));
+                            } else {
+                                e = prm.edge_kernel(ge1[gu], ge2[gv]);
+                            }
+                            col = grid.j1[gu] + grid.j2[gv];
+                        } else {
+                        ok = cur.valid();
                         const unsigned a = cur.a(), b = cur.e2;
                         const nz_t z1 = at32(g1.nz, a), z2 = at32(g2.nz, b);
-                        real e;
                         if constexpr (TAB) {
                             e = at32(ketab, __umul24((unsigned)ecls1[a], nec) + ecls2[b]);
                             if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
@@ -595,9 +709,10 @@ struct oc_solver {
                             const edge_t e1 = at32(g1.edge, a), e2 = at32(g2.edge, b);
                             e = prm.edge_kernel(e1, e2);
                         }
-                        val[s] = ok ? e : real(0);
-                        unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
+                        col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
                         col = lp_off + col * ELEM;
+                        }
+                        val[s] = ok ? e : real(0);
 #if GD_OC_PIN
                         asm volatile("" : "+v"(val[s]), "+v"(col));
 #endif
@@ -617,7 +732,7 @@ struct oc_solver {
                             }
                         }
 #endif
-                        cur.next();
+                        if (s >= G0) cur.next();
                         if (flush_at(s, fm) && s != S - 1) {   // wave-uniform: next row batch
                             ++kb;
                             cur = open_walk(kb);
@@ -672,6 +787,7 @@ struct oc_solver {
                 }
             }
 
+            GD_MARK(rows);
             // ---- rows owned by this thread (sorted order) ----------------------
             real dg[R], mi[R], x[C][KEEP_X ? R : 1], r[C][R], p[C][R];
             real pp[KEEP_X ? 1 : R];   // p1(i1) p2(i2) of the rows
@@ -730,6 +846,7 @@ struct oc_solver {
             const real tol = (C == 2) ? real(1e-10) * real(2 * N) : prm.ftol * real(N);
             const real tol2 = tol * tol;
             unsigned it = 0;
+            GD_MARK(cg_loop);
             for (; it < (unsigned)N && rTz != real(0); ++it) {
                 job_sync<W>();   // p published
                 // row sums: sum over the slots of a batch, flushed to the
@@ -973,6 +1090,7 @@ struct oc_solver {
                 publish(p);
                 rTz = rTz_next;
             }
+            GD_MARK(epilogue);
             if (prm.iters != nullptr && tid == 0) prm.iters[prm.order[t]] = it;
             if constexpr (LEAN) {
 #pragma unroll
@@ -1440,13 +1558,19 @@ struct oc_solver {
                 if constexpr (EdgeK::jac_dims > 0) {
                     // walk the slots again: row = the batch's row, col = adr
                     int kb = 0;
-                    walk_t cur = open_walk(0);
+                    walk_t cur = G0 ? walk_t{} : open_walk(0);
+                    [[maybe_unused]] grid_t grid;
+                    if constexpr (G0 > 0) {
+                        grid = open_grid(0u, 0u);
+                        cur.row = grid.row;
+                    }
                     real yrow = lp[cur.row * 2 + 1];
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         if (s < n_slots) {   // wave-uniform
-                            const bool ok = cur.valid();
-                            const unsigned a = cur.a(), b = cur.e2;
+                            const bool ok = s < G0 ? grid.u[s / GD_] && grid.v[s % GD_] : cur.valid();
+                            const unsigned a = s < G0 ? grid.a[s / GD_] : cur.a();
+                            const unsigned b = s < G0 ? grid.b[s % GD_] : cur.e2;
                             real w = ok ? yrow * load_real_at<real>(adr[s]) : real(0);
                             if constexpr (TAB) {
                                 const unsigned cidx = __umul24((unsigned)ecls1[a], nec) + ecls2[b];
@@ -1462,7 +1586,7 @@ struct oc_solver {
 #pragma unroll
                                 for (int jj = 0; jj < EdgeK::jac_dims; ++jj) jac[off_e + jj] += w * real(de[jj]);
                             }
-                            cur.next();
+                            if (s >= G0) cur.next();
                             if (flush_at(s, fm) && s != S - 1) {   // wave-uniform
                                 ++kb;
                                 cur = open_walk(kb);
