@@ -607,12 +607,13 @@ struct oc_solver {
                 for (int k = 0; k < GD_; ++k) {
                     g.u[k] = k < r.d1;
                     g.v[k] = k < r.d2;
-                    // (dead rows read element 0 and gather p[0]: finite)
+                    // (half-terms beyond the degree read element 0 of the row,
+                    // dead rows element 0 of the graph)
                     g.a[k] = live ? (unsigned)r.rs1 + (g.u[k] ? (unsigned)k : 0u) : 0u;
                     g.b[k] = live ? (unsigned)r.rs2 + (g.v[k] ? (unsigned)k : 0u) : 0u;
                     const nz_t z1 = at32(g1.nz, g.a[k]), z2 = at32(g2.nz, g.b[k]);
-                    g.j1[k] = base + (live ? __umul24((unsigned)z1.j, (unsigned)ldp) * elem : 0u);
-                    g.j2[k] = live ? (unsigned)z2.j * elem : 0u;
+                    g.j1[k] = base + __umul24((unsigned)z1.j, (unsigned)ldp) * elem;
+                    g.j2[k] = (unsigned)z2.j * elem;
                     if constexpr (TAB) {
                         g.t1[k] = __umul24((unsigned)ecls1[g.a[k]], nec);
                         g.t2[k] = (unsigned)ecls2[g.b[k]];
@@ -695,7 +696,11 @@ struct oc_solver {
                             } else {
                                 e = prm.edge_kernel(ge1[gu], ge2[gv]);
                             }
-                            col = grid.j1[gu] + grid.j2[gv];
+                            // (slots without a term gather p[0] like the running
+                            // walk's: lanes on one address share the LDS access,
+                            // clamped neighbours would add bank conflicts -- 3.43
+                            // against 3.24 LDS cycles per gather, scripts/lds_sim.py)
+                            col = ok ? grid.j1[gu] + grid.j2[gv] : lp_off;
                         } else {
                         ok = cur.valid();
                         const unsigned a = cur.a(), b = cur.e2;
