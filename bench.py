@@ -481,14 +481,37 @@ def effective_cpus():
     return n, quota
 
 
+_STDOUT = None
+
+
+def quiet_stdout():
+    """The contract is ONE JSON line on stdout: everything else a library
+    prints there (gloo's "[Gloo] Rank 0 is connected ..." banner, a
+    collective library's version line) goes to stderr.  File-descriptor
+    level, because those writes come from C++."""
+    global _STDOUT
+    if _STDOUT is None:
+        sys.stdout.flush()
+        _STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    text = (json.dumps(line) + '\n').encode()
+    sys.stdout.flush()
+    os.write(_STDOUT if _STDOUT is not None else 1, text)
+
+
 def main():
     args = parse()
+    if not (args.gpus > 1 and 'WORLD_SIZE' not in os.environ):
+        quiet_stdout()          # (the spawner's children each do their own)
     if args.config in ('2', '3'):
         args.config = int(args.config)
     if args.config == 'nws48':
         if args.dtype is None:
             args.dtype = 'f32'
-        print(json.dumps(nws48_line(args)), flush=True)
+        emit(nws48_line(args))
         return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
@@ -507,7 +530,7 @@ def main():
                 ctypes.CDLL(None).fflush(None)
             except Exception:
                 pass
-            print(json.dumps(line), flush=True)
+            emit(line)
         return
     if args.dtype is None:
         args.dtype = 'f64' if args.config == 3 else 'f32'
@@ -910,7 +933,7 @@ def main():
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    print(json.dumps(line), flush=True)
+    emit(line)
     if sharded:
         dist.destroy_process_group()
 

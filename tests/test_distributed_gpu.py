@@ -213,6 +213,9 @@ def test_bench_spawns_its_ranks():
          '--no-cpu-baseline'],
         capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
+    # ONE line on stdout: library banners (gloo's connection report) go to
+    # stderr
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[:2000]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 2
     assert line['config']['parallelism'] == 'pair-sharded x2'
