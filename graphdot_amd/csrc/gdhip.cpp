@@ -50,6 +50,26 @@ int gd_device_count(int *count) {
 int gd_init(int device) {
     GD_TRY(hipSetDevice(device));
     GD_TRY(hipFree(nullptr));  // force context creation
+    // The first DMA in either direction sets up the copy engine's queue:
+    // 8 ms for the first device-to-host copy of >= 64 KB of a process,
+    // whatever its size (scripts/download_bench2.py).  Paid here, with the
+    // context, not by the first result download.
+    {
+        const size_t n = 64 << 10;
+        void *d = nullptr, *h = nullptr;
+        GD_TRY(hipMalloc(&d, n));
+        if (hipHostMalloc(&h, n, hipHostMallocDefault) != hipSuccess) {
+            (void)hipFree(d);
+            return fail("gd_init: hipHostMalloc failed");
+        }
+        hipError_t e = hipMemsetAsync(d, 0, n, nullptr);
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, nullptr);
+        if (e == hipSuccess) e = hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        (void)hipHostFree(h);
+        (void)hipFree(d);
+        GD_TRY(e);
+    }
     return 0;
 }
 

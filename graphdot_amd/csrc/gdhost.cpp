@@ -9,6 +9,7 @@
 #include "gdhost.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -356,21 +357,82 @@ int gdh_order_jobs(const int32_t *pk, int64_t n_jobs, const int32_t *rank_of_key
                    int64_t n_keys, int64_t n_ranks, uint32_t *order,
                    const uint32_t *jobs, uint32_t *jobs_sorted) {
     if (n_jobs < 0 || n_keys < 0 || n_ranks < 0) return -1;
-    std::vector<int64_t> start((size_t)n_ranks + 1, 0);
+    if (n_ranks <= (1 << 16)) {
+        // counting sort: one counter per rank (at most 512 KB: cache resident)
+        std::vector<int64_t> start((size_t)n_ranks + 1, 0);
+        for (int64_t t = 0; t < n_jobs; ++t) {
+            if (pk[t] < 0 || pk[t] >= n_keys) return -1;
+            const int32_t r = rank_of_key[pk[t]];
+            if (r < 0 || r >= n_ranks) return -1;
+            ++start[(size_t)r + 1];
+        }
+        for (int64_t r = 0; r < n_ranks; ++r) start[(size_t)r + 1] += start[(size_t)r];
+        for (int64_t t = 0; t < n_jobs; ++t) {
+            const int64_t at = start[(size_t)rank_of_key[pk[t]]]++;
+            order[at] = (uint32_t)t;
+            if (jobs && jobs_sorted) {     // the job list in launch order, as uploaded
+                jobs_sorted[2 * at] = jobs[2 * t];
+                jobs_sorted[2 * at + 1] = jobs[2 * t + 1];
+            }
+        }
+        return 0;
+    }
+    // More ranks (1000 distinct graphs: one per class pair, 5e5): a counting
+    // sort is bound by its scattered counters (2.8 ms on the GPU box's host).
+    // Items (rank << 32) | job are sorted least significant digit first in
+    // passes of 11 bits -- 2048 counters and output streams, sequential
+    // reads, every pass stable (1.8 ms).
+    std::vector<uint64_t> item((size_t)n_jobs), other;
     for (int64_t t = 0; t < n_jobs; ++t) {
         if (pk[t] < 0 || pk[t] >= n_keys) return -1;
         const int32_t r = rank_of_key[pk[t]];
         if (r < 0 || r >= n_ranks) return -1;
-        ++start[(size_t)r + 1];
+        item[(size_t)t] = ((uint64_t)(uint32_t)r << 32) | (uint64_t)t;
     }
-    for (int64_t r = 0; r < n_ranks; ++r) start[(size_t)r + 1] += start[(size_t)r];
-    for (int64_t t = 0; t < n_jobs; ++t) {
-        const int64_t at = start[(size_t)rank_of_key[pk[t]]]++;
-        order[at] = (uint32_t)t;
-        if (jobs && jobs_sorted) {     // the job list in launch order, as uploaded
-            jobs_sorted[2 * at] = jobs[2 * t];
-            jobs_sorted[2 * at + 1] = jobs[2 * t + 1];
+    constexpr int BITS = 11;
+    constexpr uint64_t MASK = (1u << BITS) - 1u;
+    int n_pass = 1;
+    while (n_pass * BITS < 31 && (int64_t(1) << (n_pass * BITS)) < n_ranks) ++n_pass;
+    if (n_pass > 1) other.resize((size_t)n_jobs);
+    uint64_t *src = item.data(), *dst = other.data();
+    for (int p = 0; p < n_pass; ++p) {
+        const int shift = 32 + p * BITS;
+        int64_t count[MASK + 2] = {0};
+        for (int64_t k = 0; k < n_jobs; ++k) ++count[((src[k] >> shift) & MASK) + 1];
+        for (uint64_t d = 0; d <= MASK; ++d) count[d + 1] += count[d];
+        if (p == n_pass - 1) {              // the last pass writes the job ids
+            for (int64_t k = 0; k < n_jobs; ++k)
+                order[count[(src[k] >> shift) & MASK]++] = (uint32_t)src[k];
+        } else {
+            for (int64_t k = 0; k < n_jobs; ++k)
+                dst[count[(src[k] >> shift) & MASK]++] = src[k];
+            std::swap(src, dst);
         }
+    }
+    if (jobs && jobs_sorted)               // the job list in launch order, as uploaded
+        for (int64_t k = 0; k < n_jobs; ++k) {
+            const uint32_t t = order[k];
+            jobs_sorted[2 * k] = jobs[2 * (size_t)t];
+            jobs_sorted[2 * k + 1] = jobs[2 * (size_t)t + 1];
+        }
+    return 0;
+}
+
+int gdh_pairwise_jobs(int64_t nx, int64_t ny, uint32_t *jobs) {
+    if (nx < 0 || ny < -1 || nx + (ny > 0 ? ny : 0) > 0xFFFFFFFFll) return -1;
+    int64_t t = 0;
+    if (ny < 0) {          // symmetric: the upper triangle with the diagonal
+        for (int64_t i = 0; i < nx; ++i)
+            for (int64_t j = i; j < nx; ++j, ++t) {
+                jobs[2 * t] = (uint32_t)i;
+                jobs[2 * t + 1] = (uint32_t)j;
+            }
+    } else {               // X against Y: the graphs of Y follow those of X
+        for (int64_t i = 0; i < nx; ++i)
+            for (int64_t j = 0; j < ny; ++j, ++t) {
+                jobs[2 * t] = (uint32_t)i;
+                jobs[2 * t + 1] = (uint32_t)(nx + j);
+            }
     }
     return 0;
 }

@@ -29,6 +29,7 @@ SIGNATURES = {
     + [_i32, _i32, _i64, _vp, _vp],
     'gdh_pair_keys': [_vp, _i64, _vp, _i32, _i32, _vp, _vp],
     'gdh_order_jobs': [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp],
+    'gdh_pairwise_jobs': [_i64, _i64, _vp],
 }
 
 
@@ -185,7 +186,7 @@ def pair_keys(jobs, cid, nc):
     jobs = np.ascontiguousarray(jobs)
     raw = jobs.view(np.uint32)
     cid = _c(cid, np.int32)
-    pk = np.zeros(len(jobs), np.int32)
+    pk = np.empty(len(jobs), np.int32)
     count = np.zeros(nc * nc, np.int64)
     _check(lib().gdh_pair_keys(_p(raw), len(jobs), _p(cid), len(cid), int(nc),
                                _p(pk), _p(count)), 'gdh_pair_keys')
@@ -197,7 +198,7 @@ def order_jobs(pk, rank_of_key, n_ranks, jobs=None):
     With `jobs` also returns the job records in that order."""
     pk = _c(pk, np.int32)
     rank_of_key = _c(rank_of_key, np.int32)
-    order = np.zeros(len(pk), np.uint32)
+    order = np.empty(len(pk), np.uint32)
     raw = out = None
     if jobs is not None:
         jobs = np.ascontiguousarray(jobs)
@@ -208,3 +209,13 @@ def order_jobs(pk, rank_of_key, n_ranks, jobs=None):
         _p(order), _p(raw), None if out is None else _p(out.view(np.uint32))),
         'gdh_order_jobs')
     return order if jobs is None else (order, out)
+
+
+def pairwise_jobs(nx, ny=None, dtype=None):
+    """(i, j) records of a kernel-matrix evaluation: the upper triangle with
+    the diagonal (ny None), or all pairs (i, nx + j)."""
+    n = nx * (nx + 1) // 2 if ny is None else nx * ny
+    jobs = np.empty(2 * n, np.uint32)
+    _check(lib().gdh_pairwise_jobs(int(nx), -1 if ny is None else int(ny),
+                                   _p(jobs)), 'gdh_pairwise_jobs')
+    return jobs if dtype is None else jobs.view(dtype)

@@ -24,8 +24,8 @@ from ...hip import jit, runtime
 from ...microkernel import TensorProduct, Product
 from ...util.iterable import flatten, fold_like
 from ._backend import Backend
-from ._devicegraph import (DeviceGraph, GraphArena, class_bytes,
-                           degree_histograms, pack_many)
+from ._devicegraph import (DeviceGraph, GraphArena, HIST_BINS, class_bytes,
+                           degree_histograms, graph_features, pack_many)
 
 _TEMPLATE = os.path.join(os.path.dirname(__file__), 'template.hip')
 
@@ -455,6 +455,7 @@ class HIPBackend(Backend):
         self._dgraph_lists = IdentityCache()
         self._layouts = OrderedDict()      # job-list key -> Layout (LRU)
         self._source_cache = _SOURCES      # (code signature, variant) -> text
+        self._module_sets = {}             # (code signature, variants) -> (modules, argument dtype)
         self.layout_cache_size = 8
         self._props = None
         self.last_plan = None
@@ -1059,11 +1060,18 @@ void ${name}(params_t prm) {
             jj = np.asarray(jj, dtype=np.int64)
             return None, self._classify_pairs(ji, jj, dgraphs, C, tab_bytes,
                                               gtab, oc_only)
-        width = max(g.max_degree for g in dgraphs) + 1
-        key = np.zeros((len(dgraphs), width + 1), dtype=np.int64)
-        for k, g in enumerate(dgraphs):
-            key[k, :width] = np.bincount(g.adjacency_count, minlength=width)
-            key[k, width] = g.image_bytes
+        # graphs of one degree histogram and image size are classified alike
+        f = graph_features(dgraphs)
+        if int(f['max_degree'].max()) < HIST_BINS - 1:
+            # (the 16-bin histograms of the headers are exact)
+            key = np.column_stack((f['hist'], f['image_bytes']))
+        else:
+            width = int(f['max_degree'].max()) + 1
+            key = np.zeros((len(dgraphs), width + 1), dtype=np.int64)
+            for k, g in enumerate(dgraphs):
+                key[k, :width] = np.bincount(g.adjacency_count,
+                                             minlength=width)
+                key[k, width] = g.image_bytes
         _, rep, cid = np.unique(key, axis=0, return_index=True,
                                 return_inverse=True)
         cid, nc = cid.reshape(-1).astype(np.int32), len(rep)
@@ -1112,12 +1120,9 @@ void ${name}(params_t prm) {
 
     def _classify_pairs(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
                         oc_only=False):
-        n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
-        n_nz = np.array([g.n_nz for g in dgraphs], dtype=np.int64)
-        width = int(n_node.max())
-        deg_sorted = np.zeros((len(dgraphs), width), dtype=np.int64)
-        for k, g in enumerate(dgraphs):
-            deg_sorted[k, :g.n_node] = g.adjacency_count
+        f = graph_features(dgraphs)
+        n_node, n_nz = f['n_node'], f['n_nz']
+        deg_sorted = None      # (the two-stage variants' walk: made on demand)
         n1, n2 = n_node[ji], n_node[jj]
         nnz1 = n_nz[ji]
         N = n1 * n2
@@ -1128,14 +1133,14 @@ void ${name}(params_t prm) {
         # U entries per pair: one per stage-1 task; the region also stages the
         # CSR row pointers of both graphs during setup
         ntask = np.maximum((nnz1 + 1) * n2, n1 + n2 + 2)
-        image = np.array([g.image_bytes for g in dgraphs], dtype=np.int64)
+        image = f['image_bytes']
         if tab_bytes:      # the label-class section is staged with the image
             image = image + class_bytes(n_node, n_nz)
         gbytes = np.maximum(image[ji], image[jj])
         # the owner-computes solvers with global tables stage the class ids
         image_oc = image + class_bytes(n_node, n_nz) if gtab else image
         gbytes_oc = np.maximum(image_oc[ji], image_oc[jj])
-        maxdeg = np.array([g.max_degree for g in dgraphs], dtype=np.int64)
+        maxdeg = f['max_degree']
         pair_maxdeg = np.maximum(maxdeg[ji], maxdeg[jj])
         oc_slots, hists, trips = {}, {}, {}
         # (FLY kernels have no nodal-gradient / maximin flavour)
@@ -1155,7 +1160,7 @@ void ${name}(params_t prm) {
             menu = [(k, v) for k, v in enumerate(self.variants[:n_oc])
                     if (not v.L or self._static_enabled(v, C))
                     and (v.S > 0 or (C == 1 and not fly_off))]
-            hist = degree_histograms(dgraphs)
+            hist = f['hist']
             ch, _ = hostlib.classify_oc(
                 ji, jj, n_node, n_nz, image_oc, maxdeg, hist,
                 [(v.W, v.S, v.R, v.D, v.L) for _, v in menu], C,
@@ -1237,6 +1242,11 @@ void ${name}(params_t prm) {
             fits &= self.lds_bytes(v, C, ntask[rem], gbytes[rem], tab_bytes) \
                 <= LDS_LIMIT
             if v.W not in slots:
+                if deg_sorted is None:
+                    deg_sorted = np.zeros((len(dgraphs), int(n_node.max())),
+                                          dtype=np.int64)
+                    for k_, g in enumerate(dgraphs):
+                        deg_sorted[k_, :g.n_node] = g.adjacency_count
                 sl = np.full(len(ji), np.iinfo(np.int64).max, dtype=np.int64)
                 sl[rem] = self.slots_needed(nnz1[rem], n2[rem], jj[rem],
                                             deg_sorted, v.W)
@@ -1388,7 +1398,6 @@ void ${name}(params_t prm) {
             members = sel.members
         used = sorted(set(choice.tolist()))
         rsize = np.dtype(self.real).itemsize
-        n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
         launches, cursor = [], 0
         for k in used:
             v = self.variants[k]
@@ -1438,6 +1447,18 @@ void ${name}(params_t prm) {
             cursor += count
         return jobs, used, order_all, launches
 
+    @staticmethod
+    def _code_signature(node_kernel, edge_kernel, p, dgraphs, C, nodal,
+                        tab=False, gtab=False, ngrad=False, maximin=False):
+        """What the generated code depends on: the microkernel expressions
+        and record types (not the hyperparameter values), the graphs' record
+        types and the output mode.  (The dtypes themselves, not their
+        strings: numpy takes 15 us to print a structured dtype.)"""
+        return (node_kernel.gen_expr('x1', 'x2')[0], np.dtype(node_kernel.dtype),
+                edge_kernel.gen_expr('x1', 'x2')[0], np.dtype(edge_kernel.dtype),
+                p.gen_expr()[0], np.dtype(p.dtype), dgraphs[0].signature,
+                C, nodal, tab, gtab, ngrad, maximin)
+
     def _sources(self, used, node_kernel, edge_kernel, p, dgraphs, C, nodal,
                  tab=False, gtab=False, ngrad=False, maximin=False):
         """One translation unit per solver variant in use (+ the one of the
@@ -1446,10 +1467,8 @@ void ${name}(params_t prm) {
         text; only the entry point differs."""
         # rendering is pure text work on hyperparameter-independent inputs:
         # memoised on the generated expressions and the record types
-        sig = (node_kernel.gen_expr('x1', 'x2')[0], str(node_kernel.dtype),
-               edge_kernel.gen_expr('x1', 'x2')[0], str(edge_kernel.dtype),
-               p.gen_expr()[0], str(np.dtype(p.dtype)), dgraphs[0].signature,
-               C, nodal, tab, gtab, ngrad, maximin)
+        sig = self._code_signature(node_kernel, edge_kernel, p, dgraphs, C,
+                                   nodal, tab, gtab, ngrad, maximin)
         out = {}
         todo = [(k, self.variants[k]) for k in used]
         if gtab and any(isinstance(v, OCVariant) for _, v in todo):
@@ -1527,15 +1546,20 @@ void ${name}(params_t prm) {
         lay = Layout()
         lay.dgraphs = list(dgraphs)          # keeps the ids in `key` alive
         lay.jobs_host = jobs
+        tic('  arena and label classes')
         lay.arena, lay.arena_buf, _ = self._arena(dgraphs, fields)
+        toc('  arena and label classes')
         lay.tab_bytes = self._table_bytes(lay.arena)
         # (the nodal-gradient solvers evaluate the microkernels directly)
         lay.gtab = self._global_tables(lay.arena) and not ngrad
         if ngrad or maximin:
             lay.tab_bytes = 0
+        tic('  solver variants and launch order')
         jobs, lay.used, lay.order_host, lay.launches = self._partition(
             dgraphs, jobs, C, lay.tab_bytes, lay.gtab,
             oc_only=ngrad or maximin, merge_map=merge_map)
+        toc('  solver variants and launch order')
+        tic('  job list to the device')
         lay.n_jobs = len(jobs)
         lay.b_jobs = runtime.DeviceBuffer(max(jobs.nbytes, 8))
         lay.b_order = runtime.DeviceBuffer(max(lay.order_host.nbytes, 4))
@@ -1550,6 +1574,7 @@ void ${name}(params_t prm) {
         # uploads were issued on the null stream; solver launches may go to
         # non-blocking streams, which do not wait for it
         runtime.synchronize()
+        toc('  job list to the device')
         self._layouts[key] = lay
         while len(self._layouts) > self.layout_cache_size:
             self._layouts.popitem(last=False)    # freed with its last plan
@@ -1584,17 +1609,34 @@ void ${name}(params_t prm) {
 
         tic('code generation')
         nodal = traits.nodal is not False
-        sources = self._sources(lay.used, node_kernel, edge_kernel, p,
-                                dgraphs, C, nodal, tab, lay.gtab, ngrad,
-                                maximin is not None)
-        toc('code generation')
-        tic('JIT')
-        missing = [s for s in sources.values()
-                   if jit.cache_key(s, self.hipcc_extra) not in self._modules]
-        if len(missing) > 1:
-            jit.compile_many(missing, self.hipcc_extra)
-        modules = {k: self._module(s) for k, s in sources.items()}
-        toc('JIT')
+        # the loaded modules and the argument block of a (code signature, set
+        # of variants): a repeated call -- new hyperparameters, same code --
+        # renders, hashes and looks up nothing
+        mkey = (self._code_signature(node_kernel, edge_kernel, p, dgraphs, C,
+                                     nodal, tab, lay.gtab, ngrad,
+                                     maximin is not None), tuple(lay.used),
+                tuple(self.hipcc_extra), self.tables,
+                None if self.occupancy is None
+                else tuple(sorted(self.occupancy.items())))
+        hit = self._module_sets.get(mkey)
+        if hit is None:
+            sources = self._sources(lay.used, node_kernel, edge_kernel, p,
+                                    dgraphs, C, nodal, tab, lay.gtab, ngrad,
+                                    maximin is not None)
+            toc('code generation')
+            tic('JIT')
+            missing = [s for s in sources.values()
+                       if jit.cache_key(s, self.hipcc_extra)
+                       not in self._modules]
+            if len(missing) > 1:
+                jit.compile_many(missing, self.hipcc_extra)
+            modules = {k: self._module(s) for k, s in sources.items()}
+            toc('JIT')
+            hit = self._module_sets[mkey] = (
+                modules, self._params_dtype(node_kernel, edge_kernel, p))
+        else:
+            toc('code generation')
+        modules, pd = hit
 
         plan = Plan()
         plan.layout = lay
@@ -1671,7 +1713,6 @@ void ${name}(params_t prm) {
                             hotspot=b_hot)
 
         # kernel argument blocks
-        pd = self._params_dtype(node_kernel, edge_kernel, p)
         base = np.zeros((), dtype=pd)
         base['arena'] = lay.arena_buf.ptr
         base['jobs'] = lay.b_jobs.ptr

@@ -66,6 +66,54 @@ def degree_histograms(dgraphs):
     return hist
 
 
+def whole_batch(dgraphs):
+    """The packed batch (`pack_many`'s result dict) that `dgraphs` is, graph
+    for graph and in order -- or None."""
+    hit = getattr(dgraphs, 'batch', False)
+    if hit is not False:
+        return hit
+    n = len(dgraphs)
+    b0 = getattr(dgraphs[0], '_b', None) if n else None
+    if b0 is not None and not (
+            len(b0['sec_off']) == n and all(
+                getattr(g, '_b', None) is b0 and g._k == k
+                for k, g in enumerate(dgraphs))):
+        b0 = None
+    try:
+        dgraphs.batch = b0
+    except AttributeError:                 # a plain list
+        pass
+    return b0
+
+
+def graph_features(dgraphs):
+    """Per-graph quantities of a list of packed graphs as int64 arrays:
+    n_node, n_nz, image_bytes, max_degree and the 16-bin degree histogram
+    hist (n, 16).  A whole natively packed batch in its order hands out the
+    arrays made at pack time; any other list is walked graph by graph.  Kept
+    on the list when it can hold attributes (the backend's list of a call)."""
+    hit = getattr(dgraphs, 'features', None)
+    if hit is not None:
+        return hit
+    b0 = whole_batch(dgraphs)
+    if b0 is not None:
+        out = b0['features']
+    else:
+        out = dict(
+            n_node=np.array([g.n_node for g in dgraphs], dtype=np.int64),
+            n_nz=np.array([g.n_nz for g in dgraphs], dtype=np.int64),
+            image_bytes=np.array([g.image_bytes for g in dgraphs],
+                                 dtype=np.int64),
+            max_degree=np.array([g.max_degree for g in dgraphs],
+                                dtype=np.int64),
+            hist=degree_histograms(dgraphs))
+    try:
+        dgraphs.features = out
+    except AttributeError:                 # a plain list
+        pass
+    return out
+
+
 @cpptype(ptr=np.intp, size=np.int32)
 class FrozenArray(np.ndarray):
     """An ndarray slice that packs as {pointer, length}; the pointer is a
@@ -423,6 +471,15 @@ def pack_many(graphs, real=np.float32, native=True):
     r['no_relocs'] = np.zeros(0, dtype=np.int64)
     r['blob_off'], r['nz_off'] = r['blob_off'].tolist(), r['nz_off'].tolist()
     r['node_off'] = node0.tolist()
+    # per-graph quantities of the whole batch as arrays (graph_features)
+    gid = np.repeat(np.arange(len(batch)), n)
+    hist = np.zeros((len(batch), HIST_BINS), dtype=np.int64)
+    np.add.at(hist, (gid, np.minimum(r['count'], HIST_BINS - 1)), 1)
+    r['features'] = dict(
+        n_node=np.asarray(n, dtype=np.int64),
+        n_nz=np.asarray(r['nnz'], dtype=np.int64),
+        image_bytes=_pad(r['sec_off'][:, 5] + 2 * np.asarray(n, np.int64)),
+        max_degree=np.asarray(r['maxdeg'], dtype=np.int64), hist=hist)
     r['sec_off_list'] = offs = r['sec_off'].tolist()
     maxdeg = r['maxdeg'].tolist()
     nnz = r['nnz'].tolist()
@@ -752,13 +809,25 @@ def _label_classes(dgraphs, vfields=None, efields=None, max_classes=255,
         """all records of one section of every graph, as one array"""
         if dt.itemsize == 0:
             return np.zeros(int(sum(count)), dt)
-        raw = np.concatenate([
-            g.blob[g.offsets[section]:g.offsets[section] + c * dt.itemsize]
-            for g, c in zip(dgraphs, count)])
+        b0 = whole_batch(dgraphs)
+        if b0 is not None:
+            # (plain lists of offsets into the batch's blob: no per-graph
+            # views or offset dictionaries)
+            blob, isz = b0['blob'], dt.itemsize
+            col = SECTIONS.index(section)
+            at = (np.asarray(b0['blob_off'][:-1], dtype=np.int64)
+                  + b0['sec_off'][:, col]).tolist()
+            raw = np.concatenate([blob[a:a + c * isz]
+                                  for a, c in zip(at, count)])
+        else:
+            raw = np.concatenate([
+                g.blob[g.offsets[section]:g.offsets[section] + c * dt.itemsize]
+                for g, c in zip(dgraphs, count)])
         return raw.view(dt)
 
-    nodes = gather('node', [g.n_node for g in dgraphs], node_t)
-    edges = gather('edge', [g.n_nz for g in dgraphs], edge_t)
+    feat = graph_features(dgraphs)
+    nodes = gather('node', feat['n_node'].tolist(), node_t)
+    edges = gather('edge', feat['n_nz'].tolist(), edge_t)
     numbered = number(nodes, vfields)
     if numbered is None:
         return None
@@ -784,8 +853,6 @@ def _label_classes(dgraphs, vfields=None, efields=None, max_classes=255,
         vrep = np.zeros(1, dtype=node_t)
     if len(vrep) > max_classes or len(erep) > max_classes:
         return None
-    n_node = np.array([g.n_node for g in dgraphs])
-    n_nz = np.array([g.n_nz for g in dgraphs])
     # (flat: the node classes of all graphs back to back, likewise the edges)
     return ncls.astype(np.uint8), ecls.astype(np.uint8), vrep, erep
 
@@ -815,9 +882,12 @@ class GraphArena:
             self.classes = dict(nv=len(vrep), ne=len(erep), vrep=cursor,
                                 erep=cursor + _pad(vrep.nbytes))
             cursor = self.classes['erep'] + _pad(erep.nbytes)
-        sizes = np.array([len(g.blob) for g in dgraphs], dtype=np.int64)
-        cbytes = class_bytes(np.array([g.n_node for g in dgraphs], np.int64),
-                             np.array([g.n_nz for g in dgraphs], np.int64)) \
+        feat = graph_features(dgraphs) if self.n else None
+        b0 = whole_batch(dgraphs)
+        sizes = np.diff(np.asarray(b0['blob_off'], dtype=np.int64)) \
+            if b0 is not None else np.array([len(g.blob) for g in dgraphs],
+                                            dtype=np.int64)
+        cbytes = class_bytes(feat['n_node'], feat['n_nz']) \
             if self.n else np.zeros(0, np.int64)
         ends = cursor + np.cumsum(sizes + cbytes)
         starts = ends - sizes if self.n else np.zeros(0, np.int64)
@@ -833,28 +903,30 @@ class GraphArena:
                 erep.view(np.uint8).ravel() if erep.nbytes else []
         self._relocs = []
         hdr = np.zeros(self.n, dtype=HEADER_DTYPE)
-        n_node = np.array([g.n_node for g in dgraphs], dtype=np.int64)
-        n_nz = np.array([g.n_nz for g in dgraphs], dtype=np.int64)
-        for g, s in zip(dgraphs, starts.tolist()):
-            self.host[s:s + len(g.blob)] = g.blob
-            if len(g.relocs):
-                self._relocs.append(g.relocs + s)
-                words = self.host
-                for where in g.relocs + s:
-                    word = words[where:where + 8].view(np.uint64)
-                    word[0] += np.uint64(s)
+        if b0 is not None and not cbytes.any():
+            # the batch's blobs are back to back already: one copy
+            self.host[cursor:] = b0['blob']
+        elif b0 is not None:
+            host, blob, bo = self.host, b0['blob'], b0['blob_off']
+            for k, s in enumerate(starts.tolist()):
+                host[s:s + bo[k + 1] - bo[k]] = blob[bo[k]:bo[k + 1]]
+        else:
+            for g, s in zip(dgraphs, starts.tolist()):
+                self.host[s:s + len(g.blob)] = g.blob
+                if len(g.relocs):
+                    self._relocs.append(g.relocs + s)
+                    words = self.host
+                    for where in g.relocs + s:
+                        word = words[where:where + 8].view(np.uint64)
+                        word[0] += np.uint64(s)
         if self.n:
+            n_node, n_nz = feat['n_node'], feat['n_nz']
             hdr['n_node'], hdr['n_nz'] = n_node, n_nz
-            b0 = getattr(dgraphs[0], '_b', None)
-            whole_batch = (b0 is not None and len(b0['sec_off']) == self.n
-                           and all(getattr(g, '_b', None) is b0
-                                   and g._k == k
-                                   for k, g in enumerate(dgraphs)))
             for s_, name in enumerate(SECTIONS):   # arena-relative for now
                 hdr[name] = starts + (
-                    b0['sec_off'][:, s_] if whole_batch else np.array(
+                    b0['sec_off'][:, s_] if b0 is not None else np.array(
                         [g.offsets[name] for g in dgraphs], dtype=np.int64))
-            hdr['hist'] = degree_histograms(dgraphs)
+            hdr['hist'] = feat['hist']
             if cls is not None:
                 # class ids in front of every blob: [node classes, padded to
                 # 4][edge classes], one scatter per kind

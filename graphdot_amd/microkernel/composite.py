@@ -28,6 +28,22 @@ def Composite(oper, **kw_kernels):
     """
     if oper not in _OPS:
         raise ValueError(f'Invalid reduction operator {oper!r}.')
+    # the class depends on the operator and the (attribute, state type) list
+    # only: made once (building a class costs ~25 us, and the marginalized
+    # kernel wraps its edge kernel in a TensorProduct on every evaluation of
+    # weighted graphs)
+    ckey = (oper, tuple((key, np.dtype(ker.dtype))
+                        for key, ker in kw_kernels.items()))
+    cls = _CLASSES.get(ckey)
+    if cls is None:
+        cls = _CLASSES[ckey] = _composite_class(oper, kw_kernels)
+    return cls(oper, **kw_kernels)
+
+
+_CLASSES = {}
+
+
+def _composite_class(oper, kw_kernels):
     op = _OPS[oper]
 
     @cpptype([(key, ker.dtype) for key, ker in kw_kernels.items()])
@@ -91,7 +107,7 @@ def Composite(oper, **kw_kernels):
         setattr(CompositeKernel, key,
                 property(lambda self, key=key: self.kw_kernels[key]))
 
-    return CompositeKernel(oper, **kw_kernels)
+    return CompositeKernel
 
 
 def TensorProduct(**kw_kernels):

@@ -11,6 +11,7 @@
  *                        (graphdot/kernel/marginalized/_octilegraph.py:37-177)
  *   gdh_number_records   -- (new: label classes of the table kernels)
  *   gdh_classify_oc      the per-call launch configuration
+ *   gdh_pairwise_jobs    the job list of a matrix evaluation (_kernel.py:172-182)
  *   gdh_pair_keys        (graphdot/kernel/marginalized/_backend_cuda.py:292-316:
  *   gdh_order_jobs        block / shared-memory sizing; the reference has one
  *                         solver and a global atomic job counter, this build
@@ -119,6 +120,14 @@ int gdh_pair_keys(const uint32_t *jobs, int64_t n_jobs, const int32_t *cid,
 int gdh_order_jobs(const int32_t *pk, int64_t n_jobs, const int32_t *rank_of_key,
                    int64_t n_keys, int64_t n_ranks, uint32_t *order,
                    const uint32_t *jobs, uint32_t *jobs_sorted);
+
+/* The job list of a kernel-matrix evaluation, (u32 i, u32 j) per pair in
+ * row-major order: ny < 0: the upper triangle of an nx x nx symmetric matrix
+ * with its diagonal, nx (nx + 1) / 2 jobs (i <= j); ny >= 0: all nx * ny
+ * pairs (i, nx + j) of X against Y, whose graphs follow those of X in the
+ * graph list.  Replaces the reference's Python loops over pairs
+ * (graphdot/kernel/marginalized/_kernel.py:172-182). */
+int gdh_pairwise_jobs(int64_t nx, int64_t ny, uint32_t *jobs);
 
 #ifdef __cplusplus
 }

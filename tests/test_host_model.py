@@ -491,3 +491,42 @@ def test_native_packer_on_random_multigraphs():
         B = GraphArena(b, native=False)
         assert np.array_equal(A.relocated(4096), B.relocated(4096))
         assert A.classes == B.classes
+
+
+def test_native_pairwise_job_list_matches_numpy():
+    """gdh_pairwise_jobs against the numpy statement of the reference's job
+    list (_kernel.py:172-182): upper triangle with the diagonal, row-major;
+    X against Y with Y's graphs numbered after X's; empty lists."""
+    from graphdot_amd.hip import hostlib
+    for n in (0, 1, 2, 7, 300):
+        i, j = np.triu_indices(n)
+        got = hostlib.pairwise_jobs(n).reshape(-1, 2)
+        assert np.array_equal(got, np.column_stack((i, j)))
+    for nx, ny in ((0, 3), (3, 0), (1, 1), (5, 3), (40, 70)):
+        i, j = np.indices((nx, ny))
+        got = hostlib.pairwise_jobs(nx, ny).reshape(-1, 2)
+        assert np.array_equal(got, np.column_stack((i.ravel(),
+                                                    j.ravel() + nx)))
+    job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
+    jobs = hostlib.pairwise_jobs(3, None, job_t)
+    assert jobs.dtype == job_t and jobs['j'].tolist() == [0, 1, 2, 1, 2, 2]
+
+
+def test_native_job_order_is_a_stable_sort_in_both_regimes():
+    """gdh_order_jobs against numpy's stable argsort: the counting sort (up to
+    65 536 ranks) and the two- and three-pass radix sort behind it; jobs of one
+    rank keep their order, the job records travel with the ids."""
+    from graphdot_amd.hip import hostlib
+    rng = np.random.default_rng(0)
+    job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
+    for n, nk, nr in ((0, 3, 3), (5, 4, 2049), (3000, 50, 7), (20000, 9000, 65536),
+                      (20000, 9000, 65537), (30000, 100000, 100000),
+                      (30000, 5000000, 4500000)):
+        pk = rng.integers(0, nk, n).astype(np.int32)
+        rank_of_key = rng.integers(0, nr, nk).astype(np.int32)
+        jobs = rng.integers(0, 1000, (n, 2)).astype(np.uint32).ravel().view(job_t)
+        order, moved = hostlib.order_jobs(pk, rank_of_key, nr, jobs)
+        ref = np.argsort(rank_of_key[pk], kind='stable')
+        assert np.array_equal(order, ref.astype(np.uint32)), (n, nk, nr)
+        assert np.array_equal(moved, jobs[ref])
+        assert np.array_equal(hostlib.order_jobs(pk, rank_of_key, nr), order)
