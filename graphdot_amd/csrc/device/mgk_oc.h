@@ -235,8 +235,8 @@ struct oc_solver {
     // register slots of a 1024-lane workgroup).  Rows stay in natural order
     // (dense graphs have near-equal degrees: nothing to sort), any degree.
     constexpr static bool FLY = S == 0;
-    static_assert(!FLY || (C == 1 && !NGRAD && !MAXIMIN && !STATIC),
-                  "the on-the-fly solver is a value solver (graph-level or nodal outputs)");
+    static_assert(!FLY || (!NGRAD && !MAXIMIN && !STATIC && (C == 1 || !NODAL)),
+                  "the on-the-fly solver: values (graph-level or nodal) and graph-level value + gradient");
     constexpr static int SA = S > 0 ? S : 1;    // slot array extent
 #ifndef GD_FLY_U
 #define GD_FLY_U 4
@@ -874,10 +874,12 @@ struct oc_solver {
                         const unsigned i1 = live ? rm >> 16 : 0u, i2 = live ? rm & 0xFFFFu : 0u;
                         const unsigned a0 = lrp1[i1], a1 = live ? (unsigned)lrp1[i1 + 1] : a0;
                         const unsigned b0 = lrp2[i2], b1 = live ? (unsigned)lrp2[i2 + 1] : b0;
-                        real acc = 0;
+                        real acc[C];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) acc[c] = 0;
                         for (unsigned a = a0; a < a1; ++a) {
                             const edge_t e1 = at32(g1.edge, a);
-                            const unsigned rowp = lp_off + __umul24((unsigned)at32(g1.nz, a).j, (unsigned)ldp) * (unsigned)sizeof(real);
+                            const unsigned rowp = lp_off + __umul24((unsigned)at32(g1.nz, a).j, (unsigned)ldp) * ELEM;
                             [[maybe_unused]] unsigned c1 = 0;
                             [[maybe_unused]] real w1 = 1;
                             if constexpr (TAB) {
@@ -888,12 +890,14 @@ struct oc_solver {
                             // FLY_U terms per trip, indices clamped to the row's last
                             // element and the surplus zeroed: the loads of a trip are
                             // independent (one LDS latency per trip, not per term)
-                            real part[FLY_U];
+                            real part[C][FLY_U];
 #pragma unroll
-                            for (int u = 0; u < FLY_U; ++u) part[u] = 0;
+                            for (int c = 0; c < C; ++c)
+#pragma unroll
+                                for (int u = 0; u < FLY_U; ++u) part[c][u] = 0;
                             const unsigned blast = b1 - 1u;     // (b1 > b0 inside the loop)
                             for (unsigned b = b0; b < b1; b += FLY_U) {
-                                real e[FLY_U], pv[FLY_U];
+                                real e[FLY_U], pv[C][FLY_U];
 #pragma unroll
                                 for (int u = 0; u < FLY_U; ++u) {
                                     const unsigned bb = b + u < b1 ? b + u : blast;
@@ -905,18 +909,28 @@ struct oc_solver {
                                     } else {
                                         e[u] = real(prm.edge_kernel(e1, at32(g2.edge, bb)));
                                     }
-                                    pv[u] = load_real_at<real>(rowp + col * (unsigned)sizeof(real));
+                                    real pe[C];
+                                    load_elem_at<C>(rowp + col * ELEM, pe);
+#pragma unroll
+                                    for (int c = 0; c < C; ++c) pv[c][u] = pe[c];
                                 }
 #pragma unroll
-                                for (int u = 0; u < FLY_U; ++u)
-                                    part[u] += (b + u < b1) ? e[u] * pv[u] : real(0);
-                            }
-                            real psum = 0;
+                                for (int u = 0; u < FLY_U; ++u) {
+                                    const real eu = (b + u < b1) ? e[u] : real(0);
 #pragma unroll
-                            for (int u = 0; u < FLY_U; ++u) psum += part[u];
-                            acc += TAB ? psum * w1 : psum;
+                                    for (int c = 0; c < C; ++c) part[c][u] += eu * pv[c][u];
+                                }
+                            }
+#pragma unroll
+                            for (int c = 0; c < C; ++c) {
+                                real psum = 0;
+#pragma unroll
+                                for (int u = 0; u < FLY_U; ++u) psum += part[c][u];
+                                acc[c] += TAB ? psum * w1 : psum;
+                            }
                         }
-                        ys[0][k] = acc;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) ys[c][k] = acc[c];
                     }
                 } else {
                     real acc[C];
@@ -1560,7 +1574,46 @@ struct oc_solver {
                     }
                 }
                 job_sync<W>();
-                if constexpr (EdgeK::jac_dims > 0) {
+                if constexpr (EdgeK::jac_dims > 0 && FLY) {
+                    // no slots: the owner of a row walks its terms once more,
+                    // w = Yp(row) YDq(column) per term
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const unsigned rm = rowid[k];
+                        const bool live = rm != ~0u;
+                        const unsigned i1 = live ? rm >> 16 : 0u, i2 = live ? rm & 0xFFFFu : 0u;
+                        const unsigned a0 = lrp1[i1], a1 = live ? (unsigned)lrp1[i1 + 1] : a0;
+                        const unsigned b0 = lrp2[i2], b1 = live ? (unsigned)lrp2[i2 + 1] : b0;
+                        const real yrow = x[1][k];
+                        for (unsigned a = a0; a < a1; ++a) {
+                            const edge_t e1 = at32(g1.edge, a);
+                            const unsigned rowp = lp_off + __umul24((unsigned)at32(g1.nz, a).j, (unsigned)ldp) * ELEM;
+                            [[maybe_unused]] unsigned c1 = 0;
+                            real w1 = yrow;
+                            if constexpr (TAB) {
+                                c1 = __umul24((unsigned)ecls1[a], nec);
+                                if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                                    w1 *= real(edge_weight<edge_t>::get(e1));
+                            }
+                            for (unsigned b = b0; b < b1; ++b) {
+                                const unsigned col = (unsigned)at32(g2.nz, b).j;
+                                real w = w1 * load_real_at<real>(rowp + col * ELEM);
+                                if constexpr (TAB) {
+                                    const unsigned cidx = c1 + ecls2[b];
+                                    if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                                        w *= real(edge_weight<edge_t>::get(at32(g2.edge, b)));
+#pragma unroll
+                                    for (int jj = 0; jj < EdgeK::jac_dims; ++jj)
+                                        jac[off_e + jj] += w * at32(dketab, (unsigned)jj * nec * nec + cidx);
+                                } else {
+                                    auto de = prm.edge_kernel._j_a_c_o_b_i_a_n_(e1, at32(g2.edge, b));
+#pragma unroll
+                                    for (int jj = 0; jj < EdgeK::jac_dims; ++jj) jac[off_e + jj] += w * real(de[jj]);
+                                }
+                            }
+                        }
+                    }
+                } else if constexpr (EdgeK::jac_dims > 0) {
                     // walk the slots again: row = the batch's row, col = adr
                     int kb = 0;
                     walk_t cur = G0 ? walk_t{} : open_walk(0);

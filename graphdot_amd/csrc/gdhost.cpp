@@ -309,8 +309,8 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
             if (lds > lds_limit) continue;
             const int64_t nb = (N + T - 1) / T;
             bool ok = true;
-            if (fly) {             // on-the-fly: value solves of high-degree pairs
-                ok = C == 1 && pmd_true > 8;
+            if (fly) {             // on-the-fly: the high-degree pairs
+                ok = pmd_true > 8;
             } else if (n_L[v] > 0) {      // static layout: every batch under its segment
                 for (int64_t k = 0; k < nb && ok; ++k) {
                     const int cap = k < n_L[v] && k < MAXL ? L[(size_t)v * MAXL + k] : 0;

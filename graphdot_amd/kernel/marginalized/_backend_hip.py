@@ -75,8 +75,8 @@ OC_STATIC_VARIANTS = [
 ]
 #: on-the-fly variants (mgk_oc.h FLY: S = 0, D = 0): no register slots, the
 #: edge microkernel is evaluated per term in every iteration; any degree.
-#: For the pairs no slot variant fits (dense from_ase-like graphs), value
-#: solves only.
+#: For the pairs no slot variant fits (dense from_ase-like graphs): values
+#: (graph-level and nodal) and graph-level value + gradient.
 OC_FLY_VARIANTS = [
     OCVariant(4, 0, 1, 0), OCVariant(4, 0, 2, 0), OCVariant(4, 0, 3, 0),
     OCVariant(8, 0, 2, 0), OCVariant(16, 0, 2, 0), OCVariant(16, 0, 4, 0),
@@ -1159,7 +1159,7 @@ void ${name}(params_t prm) {
             from ...hip import hostlib
             menu = [(k, v) for k, v in enumerate(self.variants[:n_oc])
                     if (not v.L or self._static_enabled(v, C))
-                    and (v.S > 0 or (C == 1 and not fly_off))]
+                    and (v.S > 0 or not fly_off)]
             hist = f['hist']
             ch, _ = hostlib.classify_oc(
                 ji, jj, n_node, n_nz, image_oc, maxdeg, hist,
@@ -1180,11 +1180,11 @@ void ${name}(params_t prm) {
                 if v.L and not self._static_enabled(v, C):
                     continue
                 if v.S == 0:
-                    # on-the-fly: value solves of the pairs whose degrees no
-                    # slot variant takes (sparse pairs that merely overflow
+                    # on-the-fly: the pairs whose degrees no slot variant
+                    # takes (sparse pairs that merely overflow
                     # the slots are faster in the two-stage solver: 152 against
                     # 229 us for the 118 largest pairs of configuration 2)
-                    if C != 1 or fly_off:
+                    if fly_off:
                         continue
                     fits = (N[rem] <= 64 * v.W * v.R) & (NP[rem] < 0x3FFF) \
                         & (pair_maxdeg[rem] > FLY_MIN_DEGREE)

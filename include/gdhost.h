@@ -92,7 +92,7 @@ int gdh_number_records(const uint8_t *rec, int64_t n, int32_t itemsize,
  * [16 per class] (hist[15]: 15 and above).
  * Per variant v: waves W, slots S, rows R, degree bound D, static layout
  * L [12 per variant, zero padded] of n_L entries (0: dynamic layout).  S = 0
- * marks an on-the-fly variant: any degree above 8, value solves (C = 1) only.
+ * marks an on-the-fly variant: the pairs with a degree above 8.
  * C: right-hand sides (1 value, 2 value + gradient); real_size 4 or 8;
  * lds_limit bytes per workgroup.
  * Outputs per pair: choice (variant index or -1), NP (rows with the odd LDS

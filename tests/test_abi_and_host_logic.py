@@ -587,9 +587,8 @@ def test_measured_shard_plan_is_host_only_and_covers_every_job():
 def test_dense_graphs_classify_into_the_on_the_fly_variants():
     """Pairs whose rows have more terms than any register-slot variant holds
     (degree above 8: dense from_ase-like graphs) are assigned the on-the-fly
-    variants (S = 0) for value solves -- natively and in numpy alike -- and
-    the two-stage / general solvers for gradients, which have no on-the-fly
-    flavour."""
+    variants (S = 0), for value and for value + gradient solves (two
+    right-hand sides: twice the LDS for p) -- natively and in numpy alike."""
     from graphdot_amd.kernel.marginalized._backend_hip import OCVariant
     G = cases.tang2019_graphs(30, seed=1)
     kn, ke, q = cases.tang2019_kernels()
@@ -609,7 +608,12 @@ def test_dense_graphs_classify_into_the_on_the_fly_variants():
             v = b.variants[c]
             if isinstance(v, OCVariant) and v.S == 0:
                 assert dgs[a].n_node * dgs[bb].n_node <= 64 * v.W * v.R
-        assert not any(isinstance(b.variants[c], OCVariant)
-                       and b.variants[c].S == 0 for c in c2)
+        v2 = [b.variants[c] for c in c2]
+        assert sum(isinstance(v, OCVariant) and v.S == 0 for v in v2) \
+            > 0.9 * len(v2)
+        for c, a, bb in zip(c2, i, j):
+            v = b.variants[c]
+            if isinstance(v, OCVariant) and v.S == 0:
+                assert dgs[a].n_node * dgs[bb].n_node <= 64 * v.W * v.R
     assert np.array_equal(got[True][0], got[False][0])
     assert np.array_equal(got[True][1], got[False][1])

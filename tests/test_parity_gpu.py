@@ -900,11 +900,43 @@ def test_dense_graphs_take_the_on_the_fly_solver(real):
     assert np.allclose(Kxy, refxy, rtol=10 * rtol)
     d = k.diag(G)
     assert np.allclose(d, np.diag(ref), rtol=rtol)
-    # the gradient of such graphs stays with the two-stage solvers
-    K2, dK = k(G[:4], eval_gradient=True)
-    assert not any(isinstance(L['variant'], OCVariant)
-                   and L['variant'].S == 0 for L in be.last_plan.launches)
-    assert np.allclose(K2, ref[:4, :4], rtol=rtol) and np.all(np.isfinite(dK))
+    # value + gradient on the fly too (C = 2: two right-hand sides per term,
+    # the edge Jacobian from one more walk over the terms): against the dense
+    # oracle's analytic gradient, and against the two-stage solvers
+    K2, dK = k(G[:6], eval_gradient=True)
+    used = {L['variant'] for L in be.last_plan.launches}
+    assert all(isinstance(v, OCVariant) for v in used)
+    assert any(v.S == 0 for v in used), used
+    assert np.allclose(K2, ref[:6, :6], rtol=rtol)
+    Ro, dRo = oracle.gram(G[:6], knode, kedge, q=q, eval_gradient=True)
+    mask = np.asarray(k.active_theta_mask)
+    bound = (5e-6, 1e-8) if f64 else (2e-3, 2e-5)
+    dRo = dRo[:, :, mask]
+    # (the host-side product rule F / f * j of the composite microkernel,
+    # like the reference's composite.py, is 0 / 0 where the narrow length
+    # kernel underflows: that column is held to the two-stage solvers below)
+    fin = np.isfinite(dRo).all(axis=(0, 1))
+    assert fin[:-1].all()
+    assert elementwise_gradient_error(dK[:, :, fin], dRo[:, :, fin],
+                                      *bound) <= 1
+    assert np.all(np.isfinite(dK))
+    assert np.array_equal(dK, dK.transpose(1, 0, 2))
+    two_stage = HIPBackend(real=real, variants=[
+        v for v in be.variants if not isinstance(v, OCVariant)])
+    k2 = MarginalizedGraphKernel(knode, kedge, q=q, backend=two_stage,
+                                 **({'ftol': 1e-13} if f64 else {}))
+    K3, dK3 = k2(G[:6], eval_gradient=True)
+    assert elementwise_gradient_error(dK, dK3, *bound) <= 1
+    # X x Y with the gradient
+    Kxy2, dKxy = k(G[:3], G[3:7], eval_gradient=True)
+    _, dRxy = oracle.gram(G[:3], knode, kedge, Y=G[3:7], q=q,
+                          eval_gradient=True)
+    dRxy = dRxy[:, :, mask]
+    fin = np.isfinite(dRxy).all(axis=(0, 1))
+    assert elementwise_gradient_error(dKxy[:, :, fin], dRxy[:, :, fin],
+                                      *bound) <= 1
+    _, dKxy3 = k2(G[:3], G[3:7], eval_gradient=True)
+    assert elementwise_gradient_error(dKxy, dKxy3, *bound) <= 1
 
 
 @pytest.mark.parametrize('real', [np.float32, np.float64])
