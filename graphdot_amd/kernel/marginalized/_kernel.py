@@ -204,14 +204,17 @@ class MarginalizedGraphKernel:
         timer.toc('creating output buffer')
 
         timer.tic('calling GPU kernel (overall)')
-        backend(
-            np.concatenate((X, Y)) if Y is not None else X,
-            self.node_kernel, self.edge_kernel, self.p, self.q,
-            self.eps, self.ftol, self.gtol,
-            jobs, starts, gramian, gradient,
-            output_shape[0], output_shape[1], self.n_dims,
-            traits, timer,
-        )
+        # (an empty X or Y: nothing to solve, empty outputs of the right
+        # shape instead of a zero-size launch)
+        if n_out > 0:
+            backend(
+                np.concatenate((X, Y)) if Y is not None else X,
+                self.node_kernel, self.edge_kernel, self.p, self.q,
+                self.eps, self.ftol, self.gtol,
+                jobs, starts, gramian, gradient,
+                output_shape[0], output_shape[1], self.n_dims,
+                traits, timer,
+            )
         timer.toc('calling GPU kernel (overall)')
 
         timer.tic('collecting result')

@@ -1338,6 +1338,60 @@ def test_graphs_with_many_isolated_nodes(real):
                        rtol=1e-5 if real is np.float32 else 1e-6)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('real', [np.float32, np.float64])
+def test_degenerate_graphs_and_empty_blocks(real):
+    """The smallest inputs the graph container accepts (a graph needs an
+    edge: `from_networkx` raises without, like the reference's
+    graph/_from_networkx.py): a two-node graph, a path of three, a star whose
+    centre has the largest degree of the set, a ring, a clique -- alone, in
+    pairs and against each other; one-graph lists; an empty Y.  Values, nodal
+    values, diagonal and the analytic gradient against the dense oracle."""
+    import networkx as nx
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    with pytest.raises(RuntimeError):
+        Graph.from_networkx(nx.empty_graph(3))
+    shapes = [nx.path_graph(2), nx.path_graph(3), nx.star_graph(9),
+              nx.cycle_graph(5), nx.complete_graph(6), nx.path_graph(2)]
+    graphs = []
+    for seed, g in enumerate(shapes):
+        rng = np.random.default_rng(seed)
+        for v in g.nodes:
+            g.nodes[v]['category'] = int(rng.integers(1, 3))
+        for e in g.edges:
+            g.edges[e]['order'] = float(rng.integers(1, 3))
+        graphs.append(g)
+    G = [Graph.from_networkx(g) for g in graphs]
+    G = Graph.unify_datatype(G)
+    knode = TensorProduct(category=KroneckerDelta(0.5))
+    kedge = TensorProduct(order=SquareExponential(1.0))
+    f64 = real is np.float64
+    k = MarginalizedGraphKernel(knode, kedge, q=0.1,
+                                backend=HIPBackend(real=real),
+                                **({'ftol': 1e-13} if f64 else {}))
+    rtol = 1e-7 if f64 else 1e-5
+    ref = oracle.gram(G, knode, kedge, q=0.1)
+    K = k(G)
+    assert np.allclose(K, ref, rtol=rtol) and np.array_equal(K, K.T)
+    assert np.allclose(k.diag(G), np.diag(ref), rtol=rtol)
+    for a in range(len(G)):                      # one-graph lists
+        assert np.allclose(k([G[a]]), ref[a:a + 1, a:a + 1], rtol=rtol)
+    Kxy = k(G[:2], G[2:])
+    assert np.allclose(Kxy, ref[:2, 2:], rtol=rtol)
+    Kn = k(G, nodal=True)
+    refn = oracle.gram(G, knode, kedge, q=0.1, nodal=True)
+    assert Kn.shape == refn.shape
+    assert np.allclose(Kn, refn, rtol=10 * rtol, atol=rtol * np.abs(refn).max())
+    Kg, dK = k(G, eval_gradient=True)
+    Ro, dRo = oracle.gram(G, knode, kedge, q=0.1, eval_gradient=True)
+    mask = np.asarray(k.active_theta_mask)
+    assert np.allclose(Kg, Ro, rtol=rtol)
+    assert elementwise_gradient_error(
+        dK, dRo[:, :, mask], *((1e-6, 1e-9) if f64 else (2e-3, 2e-5))) <= 1
+    empty = k(G[:3], [])
+    assert empty.shape == (3, 0)
+
+
 def test_config2_full_size_properties(backend):
     """BASELINE.json configuration 2 at full size (256 weighted random graphs
     of 8..48 nodes, 32 896 pairs; the BASELINE-faithful kernels): symmetry,
