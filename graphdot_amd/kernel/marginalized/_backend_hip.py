@@ -94,7 +94,7 @@ OC_VARIANTS = OC_STATIC_VARIANTS + [
 ] + OC_FLY_VARIANTS
 #: pairs with a node of more than this many neighbours are what the
 #: on-the-fly variants are for (the slot variants stop at degree 8)
-FLY_MIN_DEGREE = 8
+FLY_MIN_DEGREE = int(os.environ.get('GD_FLY_MIN_DEGREE', 8))   # (the override: numpy classification only)
 #: sentinel: the global-memory general solver (any pair size)
 GENERAL = Variant(0, 0, 0)
 #: sentinel: the kernel that fills the global microkernel tables
