@@ -125,7 +125,9 @@ class MarginalizedGraphKernel:
             return cache[key]
         # (natively: np.triu_indices builds an nx x nx mask, 3.5 ms for 1000
         # graphs on the first call)
-        jobs = self.backend.array(hostlib.pairwise_jobs(nx, ny, _job_t))
+        jobs = hostlib.pairwise_jobs(nx, ny, _job_t)
+        if type(self.backend.array(jobs[:0])) is not np.ndarray:
+            jobs = self.backend.array(jobs)     # (a backend with its own arrays)
         if isinstance(jobs, np.ndarray):
             jobs.flags.writeable = False
             cache[key] = jobs

@@ -5,12 +5,14 @@ need; behaviour follows ``graphdot/minipandas/dataframe.py:9-118`` -- in
 particular ``rowtype()`` (packed, aligned struct dtype with the widest fields
 first) which *defines* the node_t / edge_t layout on the device.
 """
+import operator
 from collections import namedtuple
 import numpy as np
 from .series import Series
 
 
 _ROWTYPES = {}
+_CONCRETE = operator.attrgetter('_concrete_type')
 
 
 class DataFrame:
@@ -64,8 +66,8 @@ class DataFrame:
         # (memoised on the columns' names and types: the graphs of a data set
         # share one row type, and building a struct dtype takes ~30 us)
         try:
-            key = (pack, tuple((k, c.concrete_type)
-                               for k, c in self._data.items()))
+            key = (pack, tuple(self._data),
+                   tuple(map(_CONCRETE, self._data.values())))
             hit = _ROWTYPES.get(key)
         except TypeError:                  # an unhashable concrete type
             key = hit = None

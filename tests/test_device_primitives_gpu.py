@@ -59,3 +59,39 @@ def test_wave_sums(real):
         assert abs(out[w, 0, 2] - ref_b[w]) <= tol * scale[w]
     assert out[1, 0, 0] == 64 and out[1, 0, 2] == 64
     assert out[2, 0, 1] == 2016 and out[2, 0, 2] == -4032
+
+
+def test_transfers_through_the_staging_buffer_round_trip():
+    """DeviceBuffer.upload / download: arrays below the staging threshold go
+    to the runtime directly, larger ones through the process's pinned staging
+    buffer (runtime.STAGED_UPLOAD_BYTES), which grows on demand and is reused;
+    offsets, structured dtypes and non-contiguous sources included."""
+    from graphdot_amd.hip import runtime
+    runtime.ensure_device(0)
+    rng = np.random.default_rng(0)
+    thr = runtime.STAGED_UPLOAD_BYTES
+    for nbytes in (8, thr - 8, thr, thr + 8, 3 * thr + 40, (9 << 20) + 16,
+                   1 << 20):
+        a = rng.integers(0, 255, nbytes, dtype=np.uint8)
+        buf = runtime.DeviceBuffer(nbytes + 64)
+        buf.upload(a, offset=64)
+        runtime.synchronize()
+        back = np.empty(nbytes, np.uint8)
+        buf.download(back, offset=64)
+        assert np.array_equal(a, back), nbytes
+    job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
+    jobs = rng.integers(0, 1000, (100000, 2)).astype(np.uint32).ravel() \
+        .view(job_t)
+    buf = runtime.DeviceBuffer(jobs.nbytes)
+    buf.upload(jobs)
+    runtime.synchronize()
+    back = np.empty_like(jobs)
+    buf.download(back)
+    assert np.array_equal(jobs, back)
+    m = rng.standard_normal((700, 900))
+    buf = runtime.DeviceBuffer(m[:, ::2].size * 8)
+    buf.upload(m[:, ::2])                       # (made contiguous first)
+    runtime.synchronize()
+    back = np.empty((700, 450))
+    buf.download(back)
+    assert np.array_equal(back, m[:, ::2])

@@ -1338,7 +1338,6 @@ def test_graphs_with_many_isolated_nodes(real):
                        rtol=1e-5 if real is np.float32 else 1e-6)
 
 
-@pytest.mark.gpu
 @pytest.mark.parametrize('real', [np.float32, np.float64])
 def test_degenerate_graphs_and_empty_blocks(real):
     """The smallest inputs the graph container accepts (a graph needs an
