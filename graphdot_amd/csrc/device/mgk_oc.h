@@ -270,10 +270,15 @@ struct oc_solver {
     // instead of 29 in two passes); the two-pass form keeps fewer registers
     // live and stays where the register file is the limit
     constexpr static bool ONE_PASS = sizeof(real) == 4 || W == 1;
-#ifndef GD_OC_GCH
-#define GD_OC_GCH 8
+    // gathers in flight: 8, and 16 in the static one-wave kernels that have
+    // the registers for it -- double values (130.6 -> 136.9 M pairs/s) and
+    // float value + gradient (89.8 -> 93.3 M); 16 costs the dynamic double
+    // gradient kernels and configuration 2's multi-wave ones 10-25 % (spills)
+#ifdef GD_OC_GCH
+    constexpr static int GCH = GD_OC_GCH;
+#else
+    constexpr static int GCH = (STATIC && W == 1 && !NODAL && (sizeof(real) == 8 ? C == 1 : C == 2)) ? 16 : 8;
 #endif
-    constexpr static int GCH = GD_OC_GCH;       // gathers in flight
     constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4 && !STATIC && !FLY;
 #ifndef GD_OC_PACK
 #define GD_OC_PACK 1
