@@ -235,8 +235,8 @@ struct oc_solver {
     // register slots of a 1024-lane workgroup).  Rows stay in natural order
     // (dense graphs have near-equal degrees: nothing to sort), any degree.
     constexpr static bool FLY = S == 0;
-    static_assert(!FLY || (!NGRAD && !MAXIMIN && !STATIC && (C == 1 || !NODAL)),
-                  "the on-the-fly solver: values (graph-level or nodal) and graph-level value + gradient");
+    static_assert(!FLY || (!NGRAD && !STATIC && (C == 1 || !NODAL)),
+                  "the on-the-fly solver: values (graph-level, nodal, maximin distance) and graph-level value + gradient");
     constexpr static int SA = S > 0 ? S : 1;    // slot array extent
 #ifndef GD_FLY_U
 #define GD_FLY_U 4

@@ -1065,6 +1065,39 @@ def test_maximin_fused_vs_host_composition():
     assert np.allclose(a(G, lmin=1)[iu], b(G, lmin=1)[iu], atol=3e-4)
 
 
+def test_maximin_distance_of_dense_graphs_on_the_fly():
+    """The molecular preset's dense graphs (degree above 8): the maximin
+    distance is fused into the on-the-fly solver's launch (no register slots:
+    the epilogue needs the nodal solution only); its gradient -- finite
+    differences inside a slot solver's launch -- falls back to the host
+    composition.  Distances and hotspots against the host composition on full
+    nodal matrices from the two-stage solvers."""
+    from graphdot_amd.metric.maximin import MaxiMin
+    from graphdot_amd.kernel.marginalized._backend_hip import (
+        HIPBackend, OCVariant, VARIANTS, GENERAL)
+    G = cases.tang2019_graphs(8, seed=3)
+    knode, kedge, q = cases.tang2019_kernels()
+    fused = HIPBackend()
+    host = HIPBackend(variants=VARIANTS + [GENERAL])
+    a = MaxiMin(knode, kedge, q=q, backend=fused)
+    b = MaxiMin(knode, kedge, q=q, backend=host)
+    Da, (a1, a2) = a(G, return_hotspot=True)
+    assert fused.last_plan.maximin and not fused.last_plan.ngrad
+    used = {L['variant'] for L in fused.last_plan.launches}
+    assert any(isinstance(v, OCVariant) and v.S == 0 for v in used), used
+    Db, (b1, b2) = b(G, return_hotspot=True)
+    assert not getattr(host.last_plan, 'maximin', False)
+    iu = np.triu_indices(len(G), 1)
+    assert np.allclose(Da[iu], Db[iu], atol=2e-4) and np.array_equal(Da, Da.T)
+    same = (a1 == b1) & (a2 == b2)
+    assert same[iu].mean() > 0.9          # (near-ties may pick another pair)
+    assert np.allclose(a(G[:3], G[3:]), Da[:3, 3:], atol=1e-4)
+    # with the gradient: host composition, same distances
+    Dg, g = a(G[:4], eval_gradient=True)
+    assert np.allclose(Dg[np.triu_indices(4, 1)], Da[:4, :4][np.triu_indices(4, 1)],
+                       atol=3e-4) and np.all(np.isfinite(g))
+
+
 @pytest.mark.parametrize('name', ['unlabeled', 'labeled', 'weighted'])
 def test_label_class_tables_match_direct_evaluation(name):
     """Microkernel value tables over label classes (GraphArena.classes,
