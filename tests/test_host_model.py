@@ -530,3 +530,36 @@ def test_native_job_order_is_a_stable_sort_in_both_regimes():
         assert np.array_equal(order, ref.astype(np.uint32)), (n, nk, nr)
         assert np.array_equal(moved, jobs[ref])
         assert np.array_equal(hostlib.order_jobs(pk, rank_of_key, nr), order)
+
+
+def test_composite_kernels_of_one_shape_share_a_class_not_their_state():
+    """Composite microkernels are instances of one class per (operator,
+    attribute, state type) shape -- made once, the marginalized kernel wraps
+    its edge kernel on every evaluation of weighted graphs -- and stay
+    independent objects: hyperparameters, repr, evaluation, generated code and
+    packed state follow the instance."""
+    import copy
+    a = TensorProduct(radius=SquareExponential(0.5), category=KroneckerDelta(0.5))
+    b = TensorProduct(radius=SquareExponential(2.0), category=KroneckerDelta(0.25))
+    assert type(a) is type(b)
+    c = Additive(radius=SquareExponential(0.5), category=KroneckerDelta(0.5))
+    d = TensorProduct(category=KroneckerDelta(0.5), radius=SquareExponential(0.5))
+    assert type(c) is not type(a) and type(d) is not type(a)
+    assert d.dtype.names != a.dtype.names or type(d) is type(a)
+    ta = np.array(list(flatten(a.theta)))
+    b.theta = fold_like(np.array([3.0, 0.125]), b.theta)
+    assert np.allclose(list(flatten(a.theta)), ta)           # untouched
+    assert np.allclose(list(flatten(b.theta)), [3.0, 0.125])
+    assert a.radius is not b.radius
+    assert np.allclose(list(flatten(a.radius.theta)), [0.5])
+    x = {'radius': 1.0, 'category': 1}
+    y = {'radius': 1.5, 'category': 1}
+    assert np.isclose(a(x, y), np.exp(-0.5 * 0.25 / 0.25))
+    assert np.isclose(b(x, y), np.exp(-0.5 * 0.25 / 9.0))
+    assert np.isclose(c(x, y), np.exp(-0.5) + 1.0)
+    assert eval(repr(b)).state == b.state and eval(repr(a)).state == a.state
+    assert a.gen_expr('x', 'y')[0] == b.gen_expr('x', 'y')[0]
+    assert a.state != b.state
+    e = copy.deepcopy(a)
+    e.theta = fold_like(np.array([9.0, 0.9]), e.theta)
+    assert np.allclose(list(flatten(a.theta)), ta)
