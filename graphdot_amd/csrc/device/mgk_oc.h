@@ -235,8 +235,8 @@ struct oc_solver {
     // register slots of a 1024-lane workgroup).  Rows stay in natural order
     // (dense graphs have near-equal degrees: nothing to sort), any degree.
     constexpr static bool FLY = S == 0;
-    static_assert(!FLY || (!NGRAD && !STATIC && (C == 1 || !NODAL)),
-                  "the on-the-fly solver: values (graph-level, nodal, maximin distance) and graph-level value + gradient");
+    static_assert(!FLY || (!STATIC && (C == 1 || !NODAL)),
+                  "the on-the-fly solver: values (graph-level, nodal with their finite-difference Jacobian, maximin) and graph-level value + gradient");
     constexpr static int SA = S > 0 ? S : 1;    // slot array extent
 #ifndef GD_FLY_U
 #define GD_FLY_U 4
@@ -840,6 +840,81 @@ struct oc_solver {
                 }
             }
 
+            // FLY: the owner of row (i1, i2) walks adj(i1) x adj(i2) and
+            // evaluates the edge microkernel `ek` per term (per-lane trip
+            // counts: the EXEC mask narrows as lanes finish); ysum[c][k] = the
+            // off-diagonal sum of row batch k for right-hand side c over the
+            // vector published in lp
+            [[maybe_unused]] auto fly_matvec = [&](auto const &ek, real (&ysum)[C][(STATIC || FLY) ? R : 1]) {
+                if constexpr (FLY) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const unsigned rm = rowid[k];
+                    const bool live = rm != ~0u;
+                    const unsigned i1 = live ? rm >> 16 : 0u, i2 = live ? rm & 0xFFFFu : 0u;
+                    const unsigned a0 = lrp1[i1], a1 = live ? (unsigned)lrp1[i1 + 1] : a0;
+                    const unsigned b0 = lrp2[i2], b1 = live ? (unsigned)lrp2[i2 + 1] : b0;
+                    real acc[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] = 0;
+                    for (unsigned a = a0; a < a1; ++a) {
+                        const edge_t e1 = at32(g1.edge, a);
+                        const unsigned rowp = lp_off + __umul24((unsigned)at32(g1.nz, a).j, (unsigned)ldp) * ELEM;
+                        [[maybe_unused]] unsigned c1 = 0;
+                        [[maybe_unused]] real w1 = 1;
+                        if constexpr (TAB) {
+                            c1 = __umul24((unsigned)ecls1[a], nec);
+                            if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                                w1 = real(edge_weight<edge_t>::get(e1));
+                        }
+                        // FLY_U terms per trip, indices clamped to the row's last
+                        // element and the surplus zeroed: the loads of a trip are
+                        // independent (one LDS latency per trip, not per term)
+                        real part[C][FLY_U];
+#pragma unroll
+                        for (int c = 0; c < C; ++c)
+#pragma unroll
+                            for (int u = 0; u < FLY_U; ++u) part[c][u] = 0;
+                        const unsigned blast = b1 - 1u;     // (b1 > b0 inside the loop)
+                        for (unsigned b = b0; b < b1; b += FLY_U) {
+                            real e[FLY_U], pv[C][FLY_U];
+#pragma unroll
+                            for (int u = 0; u < FLY_U; ++u) {
+                                const unsigned bb = b + u < b1 ? b + u : blast;
+                                const unsigned col = (unsigned)at32(g2.nz, bb).j;
+                                if constexpr (TAB) {
+                                    e[u] = at32(ketab, c1 + ecls2[bb]);
+                                    if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
+                                        e[u] *= real(edge_weight<edge_t>::get(at32(g2.edge, bb)));
+                                } else {
+                                    e[u] = real(ek(e1, at32(g2.edge, bb)));
+                                }
+                                real pe[C];
+                                load_elem_at<C>(rowp + col * ELEM, pe);
+#pragma unroll
+                                for (int c = 0; c < C; ++c) pv[c][u] = pe[c];
+                            }
+#pragma unroll
+                            for (int u = 0; u < FLY_U; ++u) {
+                                const real eu = (b + u < b1) ? e[u] : real(0);
+#pragma unroll
+                                for (int c = 0; c < C; ++c) part[c][u] += eu * pv[c][u];
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            real psum = 0;
+#pragma unroll
+                            for (int u = 0; u < FLY_U; ++u) psum += part[c][u];
+                            acc[c] += TAB ? psum * w1 : psum;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) ysum[c][k] = acc[c];
+                }
+                }
+            };
+
             auto publish = [&](real const (&v)[C][R]) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
@@ -869,74 +944,7 @@ struct oc_solver {
                         for (int c = 0; c < C; ++c) ys[c][k] = 0;
                 }
                 if constexpr (FLY) {
-                    // the owner of row (i1, i2) walks adj(i1) x adj(i2) and
-                    // evaluates the edge microkernel per term (per-lane trip
-                    // counts: the EXEC mask narrows as lanes finish)
-#pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        const unsigned rm = rowid[k];
-                        const bool live = rm != ~0u;
-                        const unsigned i1 = live ? rm >> 16 : 0u, i2 = live ? rm & 0xFFFFu : 0u;
-                        const unsigned a0 = lrp1[i1], a1 = live ? (unsigned)lrp1[i1 + 1] : a0;
-                        const unsigned b0 = lrp2[i2], b1 = live ? (unsigned)lrp2[i2 + 1] : b0;
-                        real acc[C];
-#pragma unroll
-                        for (int c = 0; c < C; ++c) acc[c] = 0;
-                        for (unsigned a = a0; a < a1; ++a) {
-                            const edge_t e1 = at32(g1.edge, a);
-                            const unsigned rowp = lp_off + __umul24((unsigned)at32(g1.nz, a).j, (unsigned)ldp) * ELEM;
-                            [[maybe_unused]] unsigned c1 = 0;
-                            [[maybe_unused]] real w1 = 1;
-                            if constexpr (TAB) {
-                                c1 = __umul24((unsigned)ecls1[a], nec);
-                                if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
-                                    w1 = real(edge_weight<edge_t>::get(e1));
-                            }
-                            // FLY_U terms per trip, indices clamped to the row's last
-                            // element and the surplus zeroed: the loads of a trip are
-                            // independent (one LDS latency per trip, not per term)
-                            real part[C][FLY_U];
-#pragma unroll
-                            for (int c = 0; c < C; ++c)
-#pragma unroll
-                                for (int u = 0; u < FLY_U; ++u) part[c][u] = 0;
-                            const unsigned blast = b1 - 1u;     // (b1 > b0 inside the loop)
-                            for (unsigned b = b0; b < b1; b += FLY_U) {
-                                real e[FLY_U], pv[C][FLY_U];
-#pragma unroll
-                                for (int u = 0; u < FLY_U; ++u) {
-                                    const unsigned bb = b + u < b1 ? b + u : blast;
-                                    const unsigned col = (unsigned)at32(g2.nz, bb).j;
-                                    if constexpr (TAB) {
-                                        e[u] = at32(ketab, c1 + ecls2[bb]);
-                                        if constexpr (GD_WEIGHTED && edge_weight<edge_t>::value)
-                                            e[u] *= real(edge_weight<edge_t>::get(at32(g2.edge, bb)));
-                                    } else {
-                                        e[u] = real(prm.edge_kernel(e1, at32(g2.edge, bb)));
-                                    }
-                                    real pe[C];
-                                    load_elem_at<C>(rowp + col * ELEM, pe);
-#pragma unroll
-                                    for (int c = 0; c < C; ++c) pv[c][u] = pe[c];
-                                }
-#pragma unroll
-                                for (int u = 0; u < FLY_U; ++u) {
-                                    const real eu = (b + u < b1) ? e[u] : real(0);
-#pragma unroll
-                                    for (int c = 0; c < C; ++c) part[c][u] += eu * pv[c][u];
-                                }
-                            }
-#pragma unroll
-                            for (int c = 0; c < C; ++c) {
-                                real psum = 0;
-#pragma unroll
-                                for (int u = 0; u < FLY_U; ++u) psum += part[c][u];
-                                acc[c] += TAB ? psum * w1 : psum;
-                            }
-                        }
-#pragma unroll
-                        for (int c = 0; c < C; ++c) ys[c][k] = acc[c];
-                    }
+                    fly_matvec(prm.edge_kernel, ys);
                 } else {
                     real acc[C];
 #pragma unroll
@@ -1341,8 +1349,17 @@ struct oc_solver {
 #pragma unroll
                 for (int k = 0; k < R; ++k) x0[k] = x[0][k];
 
+                // FLY: the edge microkernel of the system being solved
+                [[maybe_unused]] EdgeK const *ek_cur = &prm.edge_kernel;
                 // y[k] = sum over the slots of row batch k of val * (vector in lp)
                 auto matvec = [&](real (&y)[R]) {
+                    if constexpr (FLY) {
+                        real ysum[C][R];
+                        fly_matvec(*ek_cur, ysum);
+#pragma unroll
+                        for (int k = 0; k < R; ++k) y[k] = ysum[0][k];
+                        return;
+                    }
                     real acc = 0;
                     int kb = 0;
                     if constexpr (STATIC) {
@@ -1398,7 +1415,11 @@ struct oc_solver {
                     }
                 };
                 // slot values for edge microkernel `ek`
-                auto set_vals = [&](auto const &ek) {
+                auto set_vals = [&](EdgeK const &ek) {
+                    if constexpr (FLY) {      // evaluated per term: just name it
+                        ek_cur = &ek;
+                        return;
+                    }
                     int kb = 0, j = 0, ja = 0, jb = 0;
                     row_t cur = open_row(0);
 #pragma unroll

@@ -1143,10 +1143,9 @@ void ${name}(params_t prm) {
         maxdeg = f['max_degree']
         pair_maxdeg = np.maximum(maxdeg[ji], maxdeg[jj])
         oc_slots, hists, trips = {}, {}, {}
-        # (the on-the-fly kernels have no nodal-gradient flavour: oc_only is
-        # True for plans that need one, 'fly' for owner-computes-only plans
-        # that may use them -- the maximin distance without its gradient)
-        fly_off = oc_only is True or os.environ.get('GD_OC_FLY') == '0'
+        # (the on-the-fly kernels have every flavour of the slot kernels but
+        # the static layouts)
+        fly_off = os.environ.get('GD_OC_FLY') == '0'
         # `rem`: the jobs without a variant yet -- every test below runs on
         # that shrinking subset only (most jobs leave in the first variants)
         rem = np.arange(len(ji))
@@ -1559,8 +1558,7 @@ void ${name}(params_t prm) {
         tic('  solver variants and launch order')
         jobs, lay.used, lay.order_host, lay.launches = self._partition(
             dgraphs, jobs, C, lay.tab_bytes, lay.gtab,
-            oc_only=True if ngrad else ('fly' if maximin else False),
-            merge_map=merge_map)
+            oc_only=ngrad or maximin, merge_map=merge_map)
         toc('  solver variants and launch order')
         tic('  job list to the device')
         lay.n_jobs = len(jobs)
