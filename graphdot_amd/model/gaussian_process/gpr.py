@@ -35,6 +35,25 @@ def _torch():
     return torch
 
 
+def _contract_planes(W, dK):
+    """``sum_ij W[i, j] dK[i, j, k]`` for a *symmetric* W.  The kernel hands
+    its gradient over plane by plane (element (i, j, k) at i + n j + n^2 k,
+    reference _kernel.py:249-256): then the contraction is one matrix-vector
+    product over contiguous rows, 0.03 ms for n = 1000 and six planes on an
+    MI355X against 0.34 ms for multiply + reduce over the broadcast product
+    (scripts/time_gpr_dense.py).  Any other layout: multiply + reduce (the
+    einsum / GEMV form on a hyperparameter-fastest layout took 107 ms on
+    rocBLAS)."""
+    n0, n1, nt = dK.shape
+    planes = dK.permute(2, 1, 0)                # [k][j][i]: W_ji = W_ij
+    if planes.is_contiguous():
+        return planes.reshape(nt, n0 * n1) @ W.reshape(n0 * n1)
+    if dK.permute(2, 0, 1).is_contiguous():     # [k][i][j]
+        return dK.permute(2, 0, 1).reshape(nt, n0 * n1) @ \
+            W.contiguous().reshape(n0 * n1)
+    return (W.unsqueeze(-1) * dK).sum((0, 1))
+
+
 class _Dense:
     """float64 dense algebra on one device."""
 
@@ -373,11 +392,9 @@ class GaussianProcessRegressor:
         value = yKy + logdet
         grad = None
         if eval_gradient is True:
-            # tr(K^-1 dK_k) as multiply + reduce: the einsum / GEMV form of
-            # this (10^6 x n_theta) contraction takes 107 ms on rocBLAS
-            # against 0.7 ms (measured, n = 1000, MI355X)
-            d = ((Kinv.unsqueeze(-1) * dK).sum((0, 1))
-                 - Ky @ torch.tensordot(Ky, dK, dims=([0], [0])))
+            # tr(K^-1 dK_k) - (K^-1 y)^T dK_k (K^-1 y) = sum_ij W_ij dK_ijk
+            # with the symmetric W = K^-1 - (K^-1 y)(K^-1 y)^T: one pass over dK
+            d = _contract_planes(Kinv - torch.outer(Ky, Ky), dK)
             grad = d.cpu().numpy() * np.exp(theta)
         t_linalg = time.perf_counter() - t
         if verbose:
