@@ -97,13 +97,17 @@ class _Dense:
             # K^-1 = X^T X with X = L^-1 from one triangular solve
             from ._potrf import cholesky_
             L = torch.tril(cholesky_(K.clone()))
-            d = torch.diagonal(L)
-            ok = bool((torch.isfinite(d) & (d > 0)).all())
-            if ok:
-                X = torch.linalg.solve_triangular(
-                    L, torch.eye(len(L), dtype=L.dtype, device=L.device),
-                    upper=False)
-                return X.T @ X, float(2.0 * torch.log(d).sum())
+            # (one host synchronisation: a diagonal entry that is not finite
+            # and positive -- the matrix was not positive definite -- makes
+            # the sum of logarithms non-finite)
+            logdet = 2.0 * torch.log(torch.diagonal(L)).sum()
+            X = torch.linalg.solve_triangular(
+                L, torch.eye(len(L), dtype=L.dtype, device=L.device),
+                upper=False)
+            Kinv = X.T @ X
+            logdet = float(logdet)
+            if np.isfinite(logdet):
+                return Kinv, logdet
         else:
             L, info = torch.linalg.cholesky_ex(K)
             if int(info) == 0:

@@ -156,6 +156,40 @@ def test_singular_matrix_falls_back_to_pseudoinverse():
 
 
 @pytest.mark.gpu
+def test_singular_matrix_on_the_gpu_falls_back_to_pseudoinverse():
+    """The native factorisation (potrf.hip) leaves a non-finite or
+    non-positive pivot for a matrix that is not positive definite; `factor`
+    sees it in the log-determinant (its one host synchronisation) and takes
+    the clamped pseudo-inverse like the CPU path."""
+    import torch
+    from graphdot_amd.model.gaussian_process.gpr import _Dense
+    la = _Dense('cuda')
+    assert la.native_cholesky
+    n = 200
+    K = torch.ones(n, n, dtype=torch.float64, device='cuda')    # rank one
+    with pytest.warns(UserWarning, match='singular'):
+        Kinv, logdet = la.factor(K, 1e-8)
+    assert bool(torch.isfinite(Kinv).all()) and np.isfinite(logdet)
+    # an indefinite matrix too
+    g = torch.Generator().manual_seed(1)
+    A = torch.randn(n, n, generator=g, dtype=torch.float64)
+    S = (A + A.T).to('cuda')
+    with pytest.warns(UserWarning, match='singular'):
+        Sinv, _ = la.factor(S, 1e-8)
+    assert bool(torch.isfinite(Sinv).all())
+    # and a well-conditioned one takes the Cholesky route silently
+    P = (A @ A.T / n + torch.eye(n, dtype=torch.float64)).to('cuda')
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        Pinv, ld = la.factor(P, 1e-8)
+    assert torch.allclose(Pinv @ P, torch.eye(n, dtype=torch.float64,
+                                              device='cuda'), atol=1e-9)
+    assert ld == pytest.approx(float(torch.linalg.slogdet(P.cpu())[1]),
+                               rel=1e-10)
+
+
+@pytest.mark.gpu
 def test_gpr_on_the_marginalized_graph_kernel():
     """Configuration 5 in miniature: likelihood + gradient of a GPR whose
     kernel is the HIP marginalized graph kernel, dense algebra on the same
