@@ -165,6 +165,7 @@ def device_props(device=None):
 
 
 STAGED_UPLOAD_BYTES = 256 << 10
+STAGING_CHUNK_BYTES = 64 << 20      # larger transfers go in pieces of this size
 _staging_lock = threading.Lock()
 _staging_ptr, _staging_view = None, None
 
@@ -208,13 +209,16 @@ class DeviceBuffer:
             # for 4 MB).  Handed over directly, the runtime pins the pages of
             # a large source in place, which took 2-20 ms per array on the
             # first call of a new layout (scripts/upload_bench.py).
+            src = a.reshape(-1).view(np.uint8)
             with _staging_lock:
-                view = _staging(a.nbytes)
-                np.copyto(view[:a.nbytes], a.reshape(-1).view(np.uint8))
-                check(lib().gd_memcpy_h2d(self.ptr + offset,
-                                          view.ctypes.data, a.nbytes, stream))
-                # (the staging buffer is reused by the next upload)
-                check(lib().gd_stream_sync(stream))
+                view = _staging(min(a.nbytes, STAGING_CHUNK_BYTES))
+                for at in range(0, a.nbytes, STAGING_CHUNK_BYTES):
+                    n = min(STAGING_CHUNK_BYTES, a.nbytes - at)
+                    np.copyto(view[:n], src[at:at + n])
+                    check(lib().gd_memcpy_h2d(self.ptr + offset + at,
+                                              view.ctypes.data, n, stream))
+                    # (the staging buffer is reused by the next piece)
+                    check(lib().gd_stream_sync(stream))
             return self
         # pageable source: hipMemcpyAsync returns once `a` may be reused
         check(lib().gd_memcpy_h2d(self.ptr + offset, a.ctypes.data, a.nbytes,
@@ -229,13 +233,16 @@ class DeviceBuffer:
             # large pageable destinations: through the pinned staging buffer
             # (the 8 MB matrix of 1000 graphs into a fresh numpy array took
             # 10 ms directly: the runtime pins the untouched pages)
+            dst = array.reshape(-1).view(np.uint8)
             with _staging_lock:
-                view = _staging(array.nbytes)
-                check(lib().gd_memcpy_d2h(view.ctypes.data, self.ptr + offset,
-                                          array.nbytes, stream))
-                check(lib().gd_stream_sync(stream))
-                np.copyto(array.reshape(-1).view(np.uint8),
-                          view[:array.nbytes])
+                view = _staging(min(array.nbytes, STAGING_CHUNK_BYTES))
+                for at in range(0, array.nbytes, STAGING_CHUNK_BYTES):
+                    n = min(STAGING_CHUNK_BYTES, array.nbytes - at)
+                    check(lib().gd_memcpy_d2h(view.ctypes.data,
+                                              self.ptr + offset + at, n,
+                                              stream))
+                    check(lib().gd_stream_sync(stream))
+                    np.copyto(dst[at:at + n], view[:n])
             return array
         check(lib().gd_memcpy_d2h(array.ctypes.data, self.ptr + offset,
                                   array.nbytes, stream))

@@ -79,6 +79,18 @@ def test_transfers_through_the_staging_buffer_round_trip():
         back = np.empty(nbytes, np.uint8)
         buf.download(back, offset=64)
         assert np.array_equal(a, back), nbytes
+    # beyond one staging piece: the transfer goes in chunks
+    old_chunk = runtime.STAGING_CHUNK_BYTES
+    runtime.STAGING_CHUNK_BYTES = 1 << 20
+    try:
+        a = rng.integers(0, 255, (5 << 20) + 12345, dtype=np.uint8)
+        buf = runtime.DeviceBuffer(a.nbytes)
+        buf.upload(a)
+        back = np.empty_like(a)
+        buf.download(back)
+        assert np.array_equal(a, back)
+    finally:
+        runtime.STAGING_CHUNK_BYTES = old_chunk
     job_t = np.dtype([('i', np.uint32), ('j', np.uint32)])
     jobs = rng.integers(0, 1000, (100000, 2)).astype(np.uint32).ravel() \
         .view(job_t)
