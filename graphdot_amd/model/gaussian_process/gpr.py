@@ -92,7 +92,7 @@ class _Dense:
         base.py:126-127, linalg/spectral.py)."""
         torch = _torch()
         if K.is_cuda and K.dtype == torch.float64 and self.native_cholesky:
-            # blocked factorisation of potrf.hip (0.9 ms against the 2.7 ms
+            # blocked factorisation of potrf.hip (0.87 ms against the 2.7 ms
             # of the library's column-by-column one at n = 1000), then
             # K^-1 = X^T X with X = L^-1 from one triangular solve
             from ._potrf import cholesky_
