@@ -4,7 +4,7 @@
 # container, by  scripts/summarize_all.sh r03  into profiles/.
 set -u
 cd "$GRAFT_REPO_ROOT"
-for tag in ${PROFILE_TAGS:-"f64:" "f32:--dtype f32" "grad64:--gradient" "grad32:--gradient --dtype f32" "c2:--config 2" "c2f64:--config 2 --dtype f64" "tang:--config tang2019"}; do
+for tag in ${PROFILE_TAGS:-"f64:" "f32:--dtype f32" "grad64:--gradient" "grad32:--gradient --dtype f32" "c2:--config 2" "c2f64:--config 2 --dtype f64" "tang:--config tang2019" "tanggrad:--config tang2019 --gradient"}; do
   name=${tag%%:*}; args=${tag#*:}
   BENCH_ARGS="$args" bash scripts/profile.sh > /dev/null 2>&1
   rm -rf gpurun_out/prof_$name && mv gpurun_out/prof gpurun_out/prof_$name
