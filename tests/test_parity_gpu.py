@@ -1499,6 +1499,51 @@ def test_config2_full_size_properties(backend):
     assert np.allclose(K[ii, jj], ref, rtol=2e-5)
 
 
+def test_dense_molecular_set_full_size_properties(backend):
+    """The dense molecular workload of `bench.py --config tang2019` at full
+    size (256 from_ase-like graphs, 32 896 pairs, the molecular preset's
+    kernels) through the on-the-fly solver, values and gradient: symmetry, the
+    diagonal against `diag()`, Cauchy-Schwarz, positive semi-definiteness, the
+    gradient planes symmetric and consistent with a central difference of the
+    matrix in the stopping probability, and a sample of pairs against the
+    dense oracle."""
+    from graphdot_amd.kernel.marginalized._backend_hip import OCVariant
+    G = cases.tang2019_graphs(256)
+    knode, kedge, q = cases.tang2019_kernels()
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    K, dK = k(G, eval_gradient=True)
+    assert any(isinstance(L['variant'], OCVariant) and L['variant'].S == 0
+               for L in backend.last_plan.launches)
+    assert K.shape == (256, 256) and np.all(np.isfinite(K))
+    assert np.all(np.isfinite(dK))
+    assert np.array_equal(K, K.T)
+    assert np.array_equal(dK, dK.transpose(1, 0, 2))
+    d = k.diag(G)
+    assert np.allclose(np.diag(K), d, rtol=1e-5)
+    Kn = K / np.sqrt(np.outer(d, d))
+    assert Kn.max() <= 1 + 1e-5
+    w = np.linalg.eigvalsh(Kn.astype(np.float64))
+    assert w.min() > -1e-4 * w.max()
+    # d/d(log q) by central differences of the matrix itself: theta is
+    # [log p, log q, log h, log length_scale], the gradient is with respect to
+    # the hyperparameters themselves
+    assert list(k.active_theta_mask) == [True] * 4 and dK.shape[2] == 4
+    theta = np.array(k.theta)
+    h = 2e-2          # (float matrices: a smaller step drowns in rounding)
+    tp, tm = theta.copy(), theta.copy()
+    tp[1] += h
+    tm[1] -= h
+    fd = (k.clone_with_theta(tp)(G[:40]) - k.clone_with_theta(tm)(G[:40])) \
+        / (2 * h)
+    g = dK[:40, :40, 1] * np.exp(theta[1])
+    assert np.allclose(g, fd, rtol=3e-2, atol=5e-3 * np.abs(fd).max())
+    rng = np.random.default_rng(7)
+    ii, jj = rng.integers(0, 256, 12), rng.integers(0, 256, 12)
+    for a, b in zip(ii, jj):
+        ref = oracle.gram([G[a]], knode, kedge, Y=[G[b]], q=q)[0, 0]
+        assert np.isclose(K[a, b], ref, rtol=2e-5)
+
+
 @pytest.mark.parametrize('real', [np.float32, np.float64])
 def test_mixed_degree_structures_all_pairs(real):
     """Stars, paths, cycles, cliques, regular and random graphs of 2..30 nodes
