@@ -775,8 +775,8 @@ struct ${name}_t : ${name}_theta_t {
                     (4, 64, 5, 8): 2, (8, 40, 2, 8): 2, (8, 64, 4, 8): 2},
         (False, 2): {(16,): 4, (16, 4): 4, (16, 4, 1): 4, (16, 4, 4): 2,
                      (16, 4, 4, 1): 2, (16, 4, 4, 1, 1): 3,
-                     (16, 4, 4, 3, 1): 2, (16, 4, 4, 3, 1, 1): 3,
-                     (16, 4, 4, 4, 1, 1, 1): 3,
+                     (16, 4, 4, 3, 1): 3, (16, 4, 4, 3, 1, 1): 3,
+                     (16, 4, 4, 4, 1, 1, 1): 2,
                      (16, 4, 4, 4, 3, 1, 1, 1): 2,
                      (16, 4, 4, 4, 4, 1, 1, 1, 1): 2,
                      (1, 12, 2, 4): 4, (1, 16, 3, 4): 4, (1, 20, 3, 4): 3,
