@@ -64,8 +64,13 @@ __device__ __forceinline__ double sum(double v) {
     v += dpp_mov<0x4E, 0xF, true>(v);    // quad_perm [2,3,0,1]
     v += dpp_mov<0x141, 0xF, true>(v);   // row_half_mirror
     v += dpp_mov<0x140, 0xF, true>(v);   // row_mirror: 16-lane sums in every lane
-    v += dpp_mov<0x142, 0xA, false>(v);  // row_bcast:15 into rows 1 and 3 (others add 0)
-    v += dpp_mov<0x143, 0xC, false>(v);  // row_bcast:31 into rows 2 and 3
+    // row_bcast:15: every row adds the total of the previous one (row 0: no
+    // source lane, bound_ctrl reads 0); row_bcast:31: rows 2 and 3 add lane 31
+    // (= rows 0 + 1).  All rows enabled: lane 63, the only one read, is right
+    // -- r3 + r2 + (r1 + r0) -- and the destination needs no "old" value: with
+    // rows masked off the moves cost two v_mov 0 each.
+    v += dpp_mov<0x142, 0xF, true>(v);
+    v += dpp_mov<0x143, 0xF, true>(v);
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
     return __hiloint2double(hi, lo);
@@ -97,7 +102,7 @@ __device__ __forceinline__ void sum2(double &a, double &b) {
     v += dpp_mov<0x4E, 0xF, true>(v);
     v += dpp_mov<0x141, 0xF, true>(v);
     v += dpp_mov<0x140, 0xF, true>(v);
-    v += dpp_mov<0x142, 0xA, false>(v);
+    v += dpp_mov<0x142, 0xF, true>(v);     // (lanes 31 and 63: rows 1 and 3)
     const int l = __double2loint(v), h = __double2hiint(v);
     a = __hiloint2double(__builtin_amdgcn_readlane(h, 31), __builtin_amdgcn_readlane(l, 31));
     b = __hiloint2double(__builtin_amdgcn_readlane(h, 63), __builtin_amdgcn_readlane(l, 63));
