@@ -80,12 +80,25 @@ def parse():
                          'the solver, dense algebra through torch on the same '
                          'GPU); value = pairs of the Gram matrix per second of '
                          'that step')
+    ap.add_argument('--fit', action='store_true',
+                    help='with --gpr: configuration 5 as BASELINE.json words '
+                         'it, a hyperparameter FIT -- L-BFGS-B on the log '
+                         'marginal likelihood from the default '
+                         'hyperparameters (reference gpr.py:62-136) with '
+                         'synthetic energies as targets; reports '
+                         'iterations, objective evaluations, ms per '
+                         'evaluation and the total')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-api', action='store_true',
                     help='skip the numpy-in / numpy-out measurement')
     ap.add_argument('--sharded', action='store_true',
                     help='one rank through the multi-GPU code path (process '
                          'group of size 1, RCCL all-gather, device reassembly)')
+    ap.add_argument('--share-devices', action='store_true',
+                    help='allow more ranks than GPUs: ranks share devices and '
+                         'the all-gather goes through gloo on host memory '
+                         '(tests on a one-GPU box; without it a node with '
+                         'fewer GPUs than --gpus is an error on every rank)')
     ap.add_argument('--pipeline', action='store_true',
                     help='sharded steps overlap: the solvers of a step run '
                          'during the all-gather and the reassembly of the '
@@ -255,10 +268,14 @@ def measure_api(graphs, knode, kedge, q, real, device, gradient, n_pairs):
             'note': 'host-, PCIe- and conversion-inclusive; never `value`'}
 
 
-def init_ranks(world, local_rank):
-    """Process group of a multi-rank run: RCCL ("nccl") with one GPU per rank,
-    gloo on host memory when the ranks have to share devices (development
-    box).  Returns (torch, dist, host_collective, device ordinal)."""
+def init_ranks(world, local_rank, share_devices=False):
+    """Process group of a multi-rank run: RCCL ("nccl") with one GPU per rank.
+    A node that shows fewer GPUs than ranks is an ERROR (every rank leaves
+    with a non-zero code before any group is formed: a number measured with
+    ranks sharing a device over gloo must never pass for an N-GPU number)
+    unless `--share-devices` asks for exactly that (tests on a one-GPU box:
+    ranks share devices, the all-gather goes through gloo on host memory).
+    Returns (torch, dist, host_collective, device ordinal)."""
     import torch
     import torch.distributed as dist
     if world == 1:
@@ -272,8 +289,15 @@ def init_ranks(world, local_rank):
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device(
             'cuda', local_rank))
+    elif not share_devices:
+        sys.stderr.write(
+            f'bench.py: --gpus {world} needs {world} distinct GPUs, this '
+            f'node shows {n_dev} (rank {os.environ.get("RANK", 0)}); '
+            'pass --share-devices to let ranks share a device over gloo '
+            '(tests only)\n')
+        sys.exit(3)
     else:
-        # fewer GPUs than ranks (development box): ranks share devices
+        # fewer GPUs than ranks, asked for explicitly: ranks share devices
         # and the all-gather goes through gloo on host memory
         host_collective = True
         local_rank = local_rank % max(n_dev, 1)
@@ -302,12 +326,18 @@ def gpr_step_line(args, world, rank, local_rank):
     knode, kedge, q = cases.config3_kernels()
     dist, host_collective = None, False
     if world > 1 or args.sharded:
-        torch, dist, host_collective, local_rank = init_ranks(world,
-                                                              local_rank)
+        torch, dist, host_collective, local_rank = init_ranks(
+            world, local_rank, args.share_devices)
         backend = distributed_backend(real=real, device=local_rank,
                                       shard_single_rank=True)
     else:
         backend = HIPBackend(real=real, device=local_rank)
+    if args.fit:
+        line = gpr_fit_line(args, world, rank, backend, graphs, real, dist,
+                            host_collective)
+        if dist is not None:
+            dist.destroy_process_group()
+        return line
     kernel = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
     y = np.random.default_rng(0).normal(size=n)
     d = kernel.diag(graphs)
@@ -375,6 +405,105 @@ def gpr_step_line(args, world, rank, local_rank):
         'kernel_ms': 1e3 * parts['kernel'] / args.steps,
         'dense_algebra_ms': 1e3 * parts['linalg'] / args.steps,
         'device_resident_kernel_matrix': bool(on_device),
+        'collective': None if dist is None else
+        ('gloo/host' if host_collective else 'nccl(RCCL)'),
+        'roofline': None, 'cpu_baseline': None}
+
+
+def gpr_fit_line(args, world, rank, backend, graphs, real, dist,
+                 host_collective):
+    """`--gpr --fit`: BASELINE.json's configuration 5 as it is worded, a
+    hyperparameter fit.  `GaussianProcessRegressor.fit` with
+    `optimizer=True` (reference model/gaussian_process/gpr.py:62-136:
+    scipy L-BFGS-B on the log marginal likelihood within the kernel's
+    bounds, gradient from dK/dtheta), from the default hyperparameters, on
+    the QM7-like set with synthetic energies.  Every objective evaluation is
+    one value + gradient Gram matrix on the solver plus the dense algebra on
+    the same GPU; on N ranks the pairs are sharded and every rank runs the
+    same optimiser on the same (bit-equal) numbers."""
+    import torch
+    import cases
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.model.gaussian_process import GaussianProcessRegressor
+    n = len(graphs)
+    knode, kedge, q = cases.config3_fit_kernels()
+    kernel = MarginalizedGraphKernel(knode, kedge, q=q, q_bounds=(1e-3, 0.5),
+                                     backend=backend)
+    y = cases.synthetic_energies(graphs)
+    gpr = GaussianProcessRegressor(kernel, alpha=1e-2, optimizer=True,
+                                   normalize_y=True)
+    # warm-up: code objects, graph images, job layout, torch's handles
+    gpr.X, gpr.y = graphs, y
+    theta0 = np.array(kernel.theta)
+    start = None
+    for _ in range(max(args.warmup, 1)):
+        start = gpr.log_marginal_likelihood(theta0, eval_gradient=True)[0]
+    evals, parts = [0], {'kernel': 0.0, 'linalg': 0.0}
+    objective = gpr.log_marginal_likelihood
+
+    def counted(*a, **kw):
+        out = objective(*a, **kw)
+        evals[0] += 1
+        for k in parts:
+            parts[k] += gpr.last_timing[k]
+        return out
+    gpr.log_marginal_likelihood = counted
+    torch.cuda.synchronize()
+    if dist is not None and world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    gpr.fit(graphs, y, tol=1e-6)
+    torch.cuda.synchronize()
+    if dist is not None and world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    n_fit_evals = evals[0]
+    res = gpr.optimization_result
+    if dist is not None and world > 1:
+        dev = 'cpu' if host_collective else 'cuda'
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        v = torch.tensor([float(res.fun)], dtype=torch.float64, device=dev)
+        lo, hi = v.clone(), v.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert float(lo) == float(hi), 'ranks disagree on the optimum'
+    if rank != 0:
+        return None
+    n_pairs = n * (n + 1) // 2
+    return {
+        'metric': 'graph-pairs/sec (GPR hyperparameter fit)',
+        'value': n_fit_evals * n_pairs / elapsed, 'unit': 'graph-pairs/s',
+        'n_gpus': world, 'steps': n_fit_evals, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / max(n_fit_evals, 1),
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': f'GPR hyperparameter fit on the QM7-like set '
+                               f'({n} molecules, {n_pairs} pairs per kernel '
+                               'matrix, 7 hyperparameters, synthetic '
+                               'energies): scipy L-BFGS-B on the log '
+                               'marginal likelihood from the default '
+                               'hyperparameters, tol 1e-6; a step is one '
+                               'objective evaluation (value + dK/dtheta on '
+                               'the solver, Cholesky and gradient '
+                               'contractions in float64 on the same GPU)',
+                   'graphs': n, 'pairs': n_pairs,
+                   'parallelism': (f'pair-sharded x{world}, device-resident '
+                                   'reassembly, replicated dense algebra')
+                   if dist is not None else 'single'},
+        'fit': {'iterations': int(res.nit), 'objective_evaluations':
+                n_fit_evals, 'total_s': elapsed,
+                'ms_per_evaluation': 1e3 * elapsed / max(n_fit_evals, 1),
+                'kernel_ms_per_evaluation':
+                1e3 * parts['kernel'] / max(n_fit_evals, 1),
+                'dense_algebra_ms_per_evaluation':
+                1e3 * parts['linalg'] / max(n_fit_evals, 1),
+                'objective_start': float(start),
+                'objective_final': float(res.fun),
+                'theta_start': [float(v) for v in np.exp(theta0)],
+                'theta_final': [float(v) for v in np.exp(res.x)],
+                'message': str(res.message)},
         'collective': None if dist is None else
         ('gloo/host' if host_collective else 'nccl(RCCL)'),
         'roofline': None, 'cpu_baseline': None}
@@ -541,8 +670,8 @@ def main():
     dist = torch = None
     host_collective = False
     if sharded:
-        torch, dist, host_collective, local_rank = init_ranks(world,
-                                                              local_rank)
+        torch, dist, host_collective, local_rank = init_ranks(
+            world, local_rank, args.share_devices)
 
     from graphdot_amd.hip import runtime
     from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel

@@ -659,6 +659,9 @@ def distributed_backend(**kwargs):
             #: the cuts are taken again: ShardPlan.rebalanced)
             self.rebalance = int(os.environ.get('GD_SHARD_REBALANCE',
                                                 rebalance))
+            #: job lists shorter than this per rank are not re-balanced
+            self.rebalance_min_jobs = int(os.environ.get(
+                'GD_SHARD_REBALANCE_MIN_JOBS', 4096))
             self._shard_plans = {}
             self._steps = {}      # (shard plan, nJ, traits) -> ShardedStep
 
@@ -684,7 +687,7 @@ def distributed_backend(**kwargs):
                                          edge_kernel, jobs, nX, nY, traits,
                                          rank, world)
                 hit = self._shard_plans[key] = (sp, jobs, list(dgraphs))
-            return hit
+            return key, hit
 
         def sharded_step(self, graphs, node_kernel, edge_kernel, p, q, eps,
                          ftol, gtol, jobs, starts, nX, nY, nJ, traits,
@@ -702,7 +705,7 @@ def distributed_backend(**kwargs):
             if not isinstance(graphs, (list, tuple)):
                 graphs = list(graphs)
             dgraphs = [self._register_graph(g) for g in graphs]
-            sp, _, _ = self._shard_plan(
+            plan_key, (sp, _, kept) = self._shard_plan(
                 graphs, dgraphs, node_kernel, edge_kernel, jobs, int(nX),
                 int(nY), traits, rank, world)
             key = (id(sp), int(nJ), traits)
@@ -718,13 +721,15 @@ def distributed_backend(**kwargs):
                         timer=timer, shard_plan=plan,
                         collective=self.collective, pipeline=self.pipeline)
                 step = build(sp)
-                if world > 1 and len(jobs) >= 4096 * world:
+                if (world > 1 and self.rebalance > 0
+                        and len(jobs) >= self.rebalance_min_jobs * world):
                     step, sp = balance_by_measurement(step, sp, build,
                                                       self.rebalance)
-                    # (later calls find the tuned plan)
-                    for k_, v_ in list(self._shard_plans.items()):
-                        if v_[1] is jobs and k_[-1] == world:
-                            self._shard_plans[k_] = (sp, v_[1], v_[2])
+                    # later calls find the tuned plan -- under the key of
+                    # THIS evaluation only: the job list of an n x n matrix
+                    # is one cached object shared by every set of n graphs
+                    # and by value and value + gradient evaluations
+                    self._shard_plans[plan_key] = (sp, jobs, kept)
                     key = (id(sp), int(nJ), traits)
                 self._steps[key] = step
             else:

@@ -272,6 +272,8 @@ class GaussianProcessRegressor:
                     f'Training using the {loss} loss did not converge, got:\n'
                     f'{best}')
             self.kernel.theta = best.x
+            #: the optimiser's report (scipy OptimizeResult: nit, nfev, fun)
+            self.optimization_result = best
         la = self._dense()
         K = self._gramian(self.alpha, self._X)
         self.K = K = K[self._y_mask, :][:, self._y_mask]

@@ -38,10 +38,25 @@ def build(quiet=True):
     return out
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the
+    container's CPU quota (the GPU box shows 256 CPUs and grants 16)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def lib(omp=False):
     key = 'omp' if omp else 'seq'
     if key not in _libs:
         build()
+        if omp:                        # (libgomp reads it when it is loaded)
+            os.environ.setdefault('OMP_NUM_THREADS', str(usable_cpus()))
         name = 'libmgk_oracle_omp.so' if omp else 'libmgk_oracle.so'
         _libs[key] = ctypes.CDLL(os.path.join(_here, '_build', name))
     return _libs[key]

@@ -207,7 +207,7 @@ def test_bench_spawns_its_ranks():
            if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT',
                         'MASTER_ADDR')}
     common = ['--gpus', '2', '--graphs', '120', '--steps', '2', '--warmup',
-              '1', '--dtype', 'f32']
+              '1', '--dtype', 'f32', '--share-devices']
     r = subprocess.run(
         [sys.executable, os.path.join(ROOT, 'bench.py'), *common,
          '--no-cpu-baseline'],
@@ -233,3 +233,155 @@ def test_bench_spawns_its_ranks():
         capture_output=True, text=True, env=dict(env, WORLD_SIZE='2'),
         timeout=120)
     assert r.returncode != 0
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_bench_refuses_to_share_devices_silently():
+    """`bench.py --gpus N` on a node that shows fewer than N GPUs leaves with
+    a non-zero code on every rank and prints no JSON line: ranks sharing a
+    device over gloo never pass for an N-GPU measurement (that mode has to be
+    asked for with --share-devices)."""
+    import subprocess
+    n = _device_count() + 1
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT',
+                        'MASTER_ADDR')}
+    r = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n),
+         '--graphs', '60', '--steps', '1', '--warmup', '1', '--dtype', 'f32',
+         '--no-cpu-baseline'],
+        capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ''
+    assert 'distinct GPUs' in r.stderr
+
+
+def _alternating_worker(rank, world, port, tmp, backend_name, n_dev):
+    import torch
+    import torch.distributed as dist
+    sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    device = rank % n_dev
+    torch.cuda.set_device(device)
+    if backend_name == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', device))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    import cases
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._sharded import (
+        distributed_backend, cuda_collective)
+    assert cuda_collective() == (backend_name == 'nccl')
+    A = cases.config3_graphs(48, seed=31)
+    B = cases.config3_graphs(48, seed=32)           # same size, other graphs
+    knode, kedge, q = cases.config3_kernels()
+    out = {}
+    for name, kw in (('torch', {}), ('rccl', {'collective': 'rccl'})):
+        if name == 'rccl' and backend_name != 'nccl':
+            continue
+        backend = distributed_backend(device=device, **kw)
+        # (measured re-balancing on these small job lists too: it replaces
+        # the cached plan of the evaluation it tuned -- and only that one)
+        backend.rebalance_min_jobs = 1
+        k = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+        out[f'{name}_KA'] = k(A)
+        assert backend.last_step.world == world
+        assert backend.last_step.on_device == (backend_name == 'nccl')
+        out[f'{name}_KB'] = k(B)
+        out[f'{name}_KA2'], out[f'{name}_dKA'] = k(A, eval_gradient=True)
+        out[f'{name}_KB2'], out[f'{name}_dKB'] = k(B, eval_gradient=True)
+        out[f'{name}_KA3'] = k(A)                   # cached plans, third round
+        out[f'{name}_KB3'] = k(B)
+        out[f'{name}_KA4'], out[f'{name}_dKA4'] = k(A, eval_gradient=True)
+    np.savez(os.path.join(tmp, f'alt{rank}.npz'), **out)
+    dist.destroy_process_group()
+
+
+def _check_alternating(tmp_path, names):
+    import cases
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    A = cases.config3_graphs(48, seed=31)
+    B = cases.config3_graphs(48, seed=32)
+    knode, kedge, q = cases.config3_kernels()
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=HIPBackend())
+    KA, KB = k(A), k(B)
+    KA2, dKA = k(A, eval_gradient=True)
+    KB2, dKB = k(B, eval_gradient=True)
+    assert not np.allclose(KA, KB)
+    for rank in range(2):
+        r = np.load(tmp_path / f'alt{rank}.npz')
+        for n in names:
+            assert np.array_equal(r[f'{n}_KA'], KA)
+            assert np.array_equal(r[f'{n}_KB'], KB)
+            assert np.array_equal(r[f'{n}_KA2'], KA2)
+            assert np.array_equal(r[f'{n}_dKA'], dKA)
+            assert np.array_equal(r[f'{n}_KB2'], KB2)
+            assert np.array_equal(r[f'{n}_dKB'], dKB)
+            assert np.array_equal(r[f'{n}_KA3'], KA)
+            assert np.array_equal(r[f'{n}_KB3'], KB)
+            assert np.array_equal(r[f'{n}_KA4'], KA2)
+            assert np.array_equal(r[f'{n}_dKA4'], dKA)
+
+
+def test_two_ranks_alternating_graph_sets_and_gradient_calls(tmp_path):
+    """Two graph sets of EQUAL size evaluated in turn, values and value +
+    gradient in turn, on two ranks with measured re-balancing on: the job
+    list of an n x n matrix is one cached object shared by every set of n
+    graphs, so the tuned shard plan of one evaluation must not replace the
+    plan (and with it the cached step, bound to other graphs) of another.
+    Every result bit-equal to the single-GPU one."""
+    import torch.multiprocessing as mp
+    port = 29300 + os.getpid() % 200
+    mp.spawn(_alternating_worker, args=(2, port, str(tmp_path), 'gloo', 1),
+             nprocs=2, join=True)
+    _check_alternating(tmp_path, ['torch'])
+
+
+@pytest.mark.skipif(_device_count() < 2, reason='needs two GPUs')
+def test_two_ranks_on_two_devices_over_rccl(tmp_path):
+    """The multi-device branch proper (runs wherever two GPUs are visible):
+    two ranks on two devices, "nccl" process group (RCCL over xGMI), through
+    `distributed_backend()` with torch's all-gather and with
+    `collective='rccl'` (gd_comm_unique_id / gd_comm_init_rank /
+    gd_all_gather of the C ABI, per-rank gd_init(local_rank)); alternating
+    graph sets, values and gradients; bit-equal to one rank."""
+    import torch.multiprocessing as mp
+    port = 29100 + os.getpid() % 200
+    mp.spawn(_alternating_worker, args=(2, port, str(tmp_path), 'nccl', 2),
+             nprocs=2, join=True)
+    _check_alternating(tmp_path, ['torch', 'rccl'])
+
+
+@pytest.mark.skipif(_device_count() < 2, reason='needs two GPUs')
+def test_bench_two_gpus_sharded():
+    """`bench.py --gpus 2` on two real devices: RCCL, two ranks, the
+    reassembled matrix against the oracle; and the GPR step on two ranks."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT',
+                        'MASTER_ADDR')}
+    for extra in (['--no-cpu-baseline'], ['--gradient', '--no-cpu-baseline'],
+                  ['--gpr']):
+        r = subprocess.run(
+            [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+             '--graphs', '200', '--steps', '3', '--warmup', '1', *extra],
+            capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line['n_gpus'] == 2
+        if '--gpr' in extra:
+            assert line['collective'] == 'nccl(RCCL)'
+            assert line['device_resident_kernel_matrix']
+        else:
+            chk = line['sharded_check']
+            assert chk['collective'] == 'nccl(RCCL)' and chk['ranks'] == 2
+            # (double arithmetic at the reference's stopping rule, 1e-8 N)
+            assert chk['max_rel_diff_vs_oracle'] < 1e-6

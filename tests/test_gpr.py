@@ -219,9 +219,12 @@ def test_gpr_on_the_marginalized_graph_kernel():
             + 0.02 * np.abs(grad).max() + 1e-3
     # the zero-copy device path (kernel.device_gram) and the numpy path of
     # the kernel protocol give the same objective and gradient
+    # (the host arm does its dense algebra on the CPU: the comparison covers
+    # the transport of the kernel matrix AND the algebra)
     host = GaussianProcessRegressor(kernel, alpha=gpr.alpha, normalize_y=True,
-                                    kernel_options={'lmin': 0})
+                                    kernel_options={'lmin': 0}, device='cpu')
     host.X, host.y = G, y
+    assert host._dense().device.type == 'cpu'
     assert host._device_gramian(host._dense(), kernel, G, True) is None
     assert gpr._device_gramian(gpr._dense(), kernel, G, True) is not None
     val_h, grad_h = host.log_marginal_likelihood(theta, eval_gradient=True)
@@ -235,6 +238,46 @@ def test_gpr_on_the_marginalized_graph_kernel():
     gpr.fit(G, y)
     mean, std = gpr.predict(G[:5], return_std=True)
     assert mean.shape == (5,) and np.all(std >= 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('real,tol', [(np.float64, 1e-3), (np.float32, 3e-2)])
+def test_fit_lands_on_the_optimum_of_the_oracle_driven_fit(real, tol):
+    """Configuration 5 as BASELINE.json words it -- a hyperparameter FIT
+    (reference model/gaussian_process/gpr.py:62-136: L-BFGS-B on the log
+    marginal likelihood, gradient from the kernel's dK/dtheta): 150 QM7-like
+    molecules with synthetic energies, the optimiser driven once by the HIP
+    solver (kernel matrix and gradient planes stay on the GPU, dense algebra
+    there) and once by the CPU oracle (oracle/mgk_oracle.c compute_duo +
+    derivative through the same MarginalizedGraphKernel / regressor code,
+    dense algebra on the CPU).  Both must land on the same theta*: within
+    1e-3 in log theta with the double solver, 3e-2 with the float one (its
+    gradient is good to ~1e-3 relative), and on the same objective."""
+    import cases
+    from oracle_backend import OracleBackend
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    G = cases.config3_graphs(150, seed=5)
+    y = cases.synthetic_energies(G)
+    out = []
+    for backend, device in ((HIPBackend(real=real), 'cuda'),
+                            (OracleBackend(), 'cpu')):
+        knode, kedge, q = cases.config3_fit_kernels()
+        kernel = MarginalizedGraphKernel(knode, kedge, q=q,
+                                         q_bounds=(1e-3, 0.5), backend=backend)
+        gpr = GaussianProcessRegressor(kernel, alpha=1e-2, optimizer=True,
+                                       normalize_y=True, device=device)
+        start = gpr.log_marginal_likelihood(X=G, y=(y - y.mean()) / y.std())
+        gpr.fit(G, y, tol=1e-9)
+        out.append((np.array(gpr.kernel.theta),
+                    gpr.log_marginal_likelihood(), start))
+    (t_hip, f_hip, s_hip), (t_ref, f_ref, s_ref) = out
+    assert f_ref < s_ref - 10            # the optimiser went somewhere
+    assert np.abs(t_hip - t_ref).max() <= tol, (t_hip, t_ref)
+    assert f_hip == pytest.approx(f_ref, rel=1e-6 if real is np.float64
+                                  else 1e-3)
+    assert s_hip == pytest.approx(s_ref, rel=1e-7 if real is np.float64
+                                  else 1e-4)
 
 
 def test_normalization_and_exponentiation_follow_the_protocol(data):
@@ -336,14 +379,29 @@ def test_molecular_kernel_normalised_in_a_gpr():
     assert np.abs(gpr.predict(G) - y).max() < 1.0
 
 
-def test_against_the_reference_regressor():
+@pytest.mark.parametrize('device,native', [
+    ('cpu', None),
+    pytest.param('cuda', True, marks=pytest.mark.gpu),
+    pytest.param('cuda', False, marks=pytest.mark.gpu)])
+def test_against_the_reference_regressor(device, native):
     """Objectives, their gradients and the predictions of the reference's own
     GaussianProcessRegressor (recorded by tests/golden/make_golden_gpr.py from
     graphdot/model/gaussian_process/gpr.py:62-315 on the same kernel and
     data): additive / multiplicative regularisation, normalised targets,
     masked targets.  Tolerance 1e-8 relative (both sides are float64 dense
-    algebra; the reference inverts by Cholesky like this class)."""
+    algebra; the reference inverts by Cholesky like this class).  Three arms:
+    torch on the CPU; on the GPU with the hand-written factorisation
+    (potrf.hip: `_Dense.factor`, `_contract_planes`) and with the library's
+    (GD_NATIVE_CHOLESKY=0)."""
     from _fixtures import load
+
+    def regressor(*args, **kw):
+        g = GaussianProcessRegressor(*args, **kw)
+        if native is not None:
+            la = g._dense()
+            assert la.device.type == 'cuda'
+            la.native_cholesky = native
+        return g
     ref = load('gpr_reference.json')
     X, y = np.array(ref['X']), ref['y']
     Z, z = np.array(ref['Z']), np.array(ref['z'])
@@ -354,8 +412,8 @@ def test_against_the_reference_regressor():
             yy[3] = None
             yy[17] = None
         kw = dict(alpha=c['alpha'], normalize_y=c['normalize_y'],
-                  regularization=c['regularization'], device='cpu')
-        g = GaussianProcessRegressor(RBF(1.3, 0.8), **kw)
+                  regularization=c['regularization'], device=device)
+        g = regressor(RBF(1.3, 0.8), **kw)
         g.X, g.y = X, yy
         lml, dlml = g.log_marginal_likelihood(theta, eval_gradient=True)
         loo, dloo = g.squared_loocv_error(theta, eval_gradient=True)
@@ -363,14 +421,14 @@ def test_against_the_reference_regressor():
         assert np.allclose(dlml, c['dlml'], rtol=1e-7, atol=1e-9)
         assert loo == pytest.approx(c['loo'], rel=1e-8)
         assert np.allclose(dloo, c['dloo'], rtol=1e-7, atol=1e-9)
-        g2 = GaussianProcessRegressor(RBF(1.3, 0.8), **kw)
+        g2 = regressor(RBF(1.3, 0.8), **kw)
         g2.fit(X, yy)
         mean, std = g2.predict(Z, return_std=True)
         _, cov = g2.predict(Z, return_cov=True)
         assert np.allclose(mean, c['mean'], rtol=1e-8, atol=1e-10)
         assert np.allclose(std, c['std'], rtol=1e-6, atol=1e-9)
         assert np.allclose(cov, c['cov'], rtol=1e-6, atol=1e-9)
-        g3 = GaussianProcessRegressor(RBF(1.3, 0.8), **kw)
+        g3 = regressor(RBF(1.3, 0.8), **kw)
         g3.fit_loocv(X, yy)
         lmean, lstd = g3.predict_loocv(Z, z, return_std=True)
         assert np.allclose(lmean, c['loocv_mean'], rtol=1e-8, atol=1e-10)

@@ -1209,16 +1209,27 @@ def test_label_class_tables_with_multi_wave_variants():
         assert np.allclose(Ka, Kb, rtol=tol)
 
 
-@pytest.mark.parametrize('real', [np.float32, np.float64])
-def test_full_size_gram_matrix_properties(real):
+@pytest.mark.parametrize('real,ftol', [(np.float32, 1e-8), (np.float64, 1e-8),
+                                       (np.float64, 1e-13)])
+def test_full_size_gram_matrix_properties(real, ftol):
     """BASELINE.json's full configuration (1000 QM7-like graphs, 500 500
-    pairs), checked through size-independent properties: exact symmetry, the
+    pairs), checked through size-independent properties -- exact symmetry, the
     diagonal equals `diag()`, Cauchy-Schwarz on the normalised matrix,
-    positive semi-definiteness, and a random sample against the oracle."""
+    positive semi-definiteness -- and EVERY one of the 500 500 values against
+    the C restatement of the solver converged to 1e-13 N in double
+    (oracle/mgk_oracle.c, OpenMP over the pairs: seconds).
+
+    Tolerances, stated: the float build at the reference's stopping rule
+    sqrt(rTr) < ftol N, ftol = 1e-8 (marginalized_kernel.h:449) is held to
+    the reference's own bar, rel 1e-5 (test_kernel.py:214).  The double build
+    AT THE SAME RULE -- what `bench.py`'s headline times: double arithmetic,
+    the reference's default tolerance -- stops where the float solver stops
+    and is good to rel 1e-7 only; converged (ftol = 1e-13) it meets the
+    fp64 parity statement of SURVEY.md Appendix D, rel 1e-9."""
     from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
     G = cases.config3_graphs(1000)
     knode, kedge, q = cases.config3_kernels()
-    k = MarginalizedGraphKernel(knode, kedge, q=q,
+    k = MarginalizedGraphKernel(knode, kedge, q=q, ftol=ftol,
                                 backend=HIPBackend(real=real))
     K = k(G)
     assert K.shape == (1000, 1000) and np.all(np.isfinite(K))
@@ -1229,12 +1240,12 @@ def test_full_size_gram_matrix_properties(real):
     assert Kn.max() <= 1 + (2e-6 if real is np.float32 else 1e-9)
     w = np.linalg.eigvalsh(Kn.astype(np.float64))
     assert w.min() > -(1e-4 if real is np.float32 else 1e-7) * w.max()
-    rng = np.random.default_rng(9)
-    ii, jj = rng.integers(0, 1000, 300), rng.integers(0, 1000, 300)
+    ii, jj = np.triu_indices(1000)
     batch = oracle.TensorProductBatch(G, knode, kedge)
-    ref, _ = batch.run(ii, jj, q=q, real='f64', tol=1e-13)
-    assert np.allclose(K[ii, jj], ref,
-                       rtol=1e-5 if real is np.float32 else 1e-7)
+    ref, _ = batch.run(ii, jj, q=q, real='f64', tol=1e-13, omp=True)
+    rtol = 1e-5 if real is np.float32 else (1e-7 if ftol > 1e-12 else 1e-9)
+    err = np.abs(K[ii, jj] / ref - 1)
+    assert err.max() <= rtol, (err.max(), int(err.argmax()))
 
 
 def _feature_graphs(seed=12, n_graphs=5, real=np.float32):
@@ -1340,12 +1351,13 @@ def test_ring_list_attribute_on_the_molecular_set(backend):
 @pytest.mark.parametrize('real', [np.float32, np.float64])
 def test_full_size_gradient_vs_oracle(real):
     """Config 5's kernel part at BASELINE size: value + dK/dtheta of all
-    500 500 pairs of the 1000 QM7-like graphs in one evaluation, 320 sampled
+    500 500 pairs of the 1000 QM7-like graphs in one evaluation; 320 sampled
     pairs (+ 16 diagonal ones) of every gradient plane against the fp64 dense
     restatement of marginalized_kernel.h:806-997 / template.cu:422-469
     (`oracle.pair_value(..., eval_gradient=True)`), with an ELEMENT-WISE bound:
     fp32 |d| <= 2e-3 |ref| + 2e-5 colscale, fp64 |d| <= 1e-7 |ref| + 1e-10
-    colscale."""
+    colscale; then ALL 500 500 pairs, every plane, against the C restatement
+    of compute_duo + derivative."""
     from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
     G = cases.config3_graphs(1000)
     knode, kedge, q = cases.config3_kernels()
@@ -1375,12 +1387,12 @@ def test_full_size_gradient_vs_oracle(real):
                        rtol=1e-5 if real is np.float32 else 1e-9)
     worst = elementwise_gradient_error(dK[ii, jj, :], ref_g, rtol, atol)
     assert worst <= 1, worst
-    # and 20 000 more pairs against the C restatement of compute_duo +
-    # derivative in fp64 (itself checked against the dense one in
-    # tests/test_oracle.py); its CG stops at 1e-10 * 2N like the device's
-    ii, jj = rng.integers(0, 1000, 20000), rng.integers(0, 1000, 20000)
+    # and EVERY pair against the C restatement of compute_duo + derivative in
+    # fp64 (itself checked against the dense one in tests/test_oracle.py);
+    # its CG stops at 1e-10 * 2N like the device's (OpenMP over the pairs)
+    ii, jj = np.triu_indices(1000)
     batch = oracle.TensorProductBatch(G, knode, kedge)
-    ref_v, ref_g, _ = batch.run_gradient(ii, jj, q=q, real='f64')
+    ref_v, ref_g, _ = batch.run_gradient(ii, jj, q=q, real='f64', omp=True)
     assert np.allclose(K[ii, jj], ref_v,
                        rtol=1e-5 if real is np.float32 else 1e-8)
     rtol2 = rtol if real is np.float32 else 1e-6
