@@ -124,8 +124,19 @@ class MarginalizedGraphKernel:
             cache.move_to_end(key)
             return cache[key]
         # (natively: np.triu_indices builds an nx x nx mask, 3.5 ms for 1000
-        # graphs on the first call)
-        jobs = hostlib.pairwise_jobs(nx, ny, _job_t)
+        # graphs on the first call.  Only a backend on the native host path
+        # needs libgdhost: any other backend of the plugin seam, and
+        # HIPBackend(native=False), take the numpy form)
+        if getattr(self.backend, 'native', False):
+            jobs = hostlib.pairwise_jobs(nx, ny, _job_t)
+        else:
+            if ny is None:
+                i, j = np.triu_indices(nx)
+            else:
+                i, j = np.indices((nx, ny), dtype=np.uint32)
+                j = j + nx
+            jobs = np.column_stack((i.ravel(), j.ravel())).astype(
+                np.uint32).ravel().view(_job_t)
         if type(self.backend.array(jobs[:0])) is not np.ndarray:
             jobs = self.backend.array(jobs)     # (a backend with its own arrays)
         if isinstance(jobs, np.ndarray):

@@ -1,5 +1,6 @@
 """Host-side object model against fixtures recorded from the reference
 (codegen grammar, theta structs, states, hyperparameter plumbing, degrees)."""
+import os
 import re
 import numpy as np
 import pytest
@@ -563,3 +564,25 @@ def test_composite_kernels_of_one_shape_share_a_class_not_their_state():
     e = copy.deepcopy(a)
     e.theta = fold_like(np.array([9.0, 0.9]), e.theta)
     assert np.allclose(list(flatten(a.theta)), ta)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/graphdot'),
+                    reason='needs the reference checkout (build container)')
+def test_reference_kernel_object_drives_the_hip_backend():
+    """The seam regression test: the REFERENCE's MarginalizedGraphKernel
+    (`graphdot/kernel/marginalized/_kernel.py:224-242,363-381`) constructs the
+    arguments of `HIPBackend.__call__` from its own Graph / microkernel
+    objects, for value, gradient, nodal, X x Y, lmin and the three `diag`
+    modes; everything of `prepare` that needs no device runs on them
+    (tests/golden/check_dropin.py, in a process of its own: the numpy /
+    pycuda shims the reference's import needs must not leak into this one).
+    Skipped where /root/reference does not exist (the GPU box)."""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                          'golden', 'check_dropin.py')
+    r = subprocess.run([sys.executable, script], capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'drop-in seam ok' in r.stdout
+    assert r.stdout.count('10 backend calls') == 4
