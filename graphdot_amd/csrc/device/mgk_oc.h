@@ -274,10 +274,13 @@ struct oc_solver {
     // the registers for it -- double values (130.6 -> 136.9 M pairs/s) and
     // float value + gradient (89.8 -> 93.3 M); 16 costs the dynamic double
     // gradient kernels and configuration 2's multi-wave ones 10-25 % (spills)
+#ifndef GD_OC_SEQ
+#define GD_OC_SEQ 1   // sequential value + gradient solves (below): 0 off, 1 double, 2 double and float
+#endif
 #ifdef GD_OC_GCH
     constexpr static int GCH = GD_OC_GCH;
 #else
-    constexpr static int GCH = (STATIC && W == 1 && !NODAL && (sizeof(real) == 8 ? C == 1 : C == 2)) ? 16 : 8;
+    constexpr static int GCH = (STATIC && W == 1 && !NODAL && (sizeof(real) == 8 ? (C == 1 || GD_OC_SEQ != 0) : C == 2)) ? 16 : 8;
 #endif
     constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4 && !STATIC && !FLY;
 #ifndef GD_OC_PACK
@@ -300,8 +303,40 @@ struct oc_solver {
     // the static layout saved on the row sums) for 4 R reals fewer in
     // registers across the gather phase: the two-right-hand-side solver is
     // what the register file limits to two waves per SIMD in double.
-    constexpr static bool LEAN = STATIC && C == 2 && !NODAL;
-    constexpr static bool HAS_Y = (!STATIC && !FLY) || LEAN;   // the [Y] region exists
+    // SEQ (static layouts, value + gradient): the two right-hand sides of the
+    // gradient solve -- D q^2/q0^2 and p1 (x) p2 -- are solved ONE AFTER THE
+    // OTHER by the one-right-hand-side iteration of the value solver, over the
+    // same register slots, instead of stacked with shared alpha / beta
+    // (compute_duo, marginalized_kernel.h:492-804).  Same solutions to the
+    // stopping tolerance; the stacked form keeps r, p, A p, z, x of both
+    // systems in registers (108-128 VGPRs in double on top of the slots: 1.9
+    // waves per SIMD, VALU 55 % / LDS 55 % busy -- a latency-bound kernel),
+    // the sequential form keeps those of one system and the finished solution
+    // of the other.  Each system stops at sqrt(rTr) < 1e-10 * 2N / sqrt(2), so
+    // that the stacked residual is under the reference's 1e-10 * 2N.
+    constexpr static bool SEQ = C == 2 && STATIC && !NODAL && W == 1 &&
+                                (GD_OC_SEQ == 2 || (GD_OC_SEQ == 1 && sizeof(real) == 8));
+    constexpr static int CW = SEQ ? 1 : C;      // right-hand sides per CG iteration
+    constexpr static int NSYS = C / CW;         // solves per pair
+    constexpr static bool LEAN = STATIC && C == 2 && !NODAL && !SEQ;
+#ifndef GD_OC_FSCAL
+#define GD_OC_FSCAL 1
+#endif
+    // FSCAL (double builds): the SCALARS of the iteration -- pAp, rTr, rTz and
+    // with them alpha and beta -- are reduced and divided in float; vectors,
+    // per-lane partial sums and every update stay double.  x and r move by the
+    // same alpha (converted back to double once), so r remains the residual of
+    // x to double rounding whatever alpha is: a step length that is off by
+    // 6e-8 relative is a marginally sub-optimal step, not an error (measured
+    // on 300 pairs of the QM7-like set: the same 16.6 iterations to 1e-8 N,
+    // 24.7 against 24.0 to 1e-13 N, K within 2e-13 of the direct solve).  A
+    // wave sum costs 7 instructions in float (v_add_f32_dpp) against 20 in
+    // double (v_add_f64 takes no DPP operand: two v_mov_dpp per step), a
+    // quotient 2 against 6: the three sums and two quotients of an iteration
+    // were 52 of its 134 vector instructions.
+    constexpr static bool FSCAL = GD_OC_FSCAL != 0 && sizeof(real) == 8 && !NGRAD;
+    using sreal = std::conditional_t<FSCAL, float, real>;
+    constexpr static bool HAS_Y = (!STATIC && !FLY) || LEAN || SEQ;   // the [Y] region exists (SEQ: the first system's solution waits there)
 #ifndef GD_OC_GRID
 #define GD_OC_GRID 1
 #endif
@@ -432,6 +467,8 @@ struct oc_solver {
         char *const lG2 = lG1 + prm.g_capacity;
         real *const red0 = lds.red[0], *const red1 = lds.red[1];
         using reduce = alternating_reduce<real, W>;
+        using sreduce = alternating_reduce<sreal, W>;
+        sreal *const sred0 = reinterpret_cast<sreal *>(red0), *const sred1 = reinterpret_cast<sreal *>(red1);
         const unsigned lY_off = uni((int)lds_offset(lY));
         graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
         const int dump = (int)prm.u_capacity - 1;   // cell that dead rows publish to
@@ -632,7 +669,7 @@ struct oc_solver {
             real val[SA];
             unsigned adr[NADR];   // LDS byte address of the gathered element of p (two-pass setup: first (a << 16) | b, or ~0u; PACK: two per register)
             const unsigned lp_off = lds_offset(lp);
-            constexpr unsigned ELEM = C * sizeof(real);
+            constexpr unsigned ELEM = CW * sizeof(real);
             unsigned fm[NM];
 #pragma unroll
             for (int w = 0; w < NM; ++w) fm[w] = 0;
@@ -799,53 +836,21 @@ struct oc_solver {
 
             GD_MARK(rows);
             // ---- rows owned by this thread (sorted order) ----------------------
-            real dg[R], mi[R], x[C][KEEP_X ? R : 1], r[C][R], p[C][R];
+            real dg[R], mi[R], x[C][KEEP_X ? R : 1], r[CW][R], p[CW][R];
+            [[maybe_unused]] real xq[SEQ ? R : 1];   // SEQ: the solution of the system being solved
             real pp[KEEP_X ? 1 : R];   // p1(i1) p2(i2) of the rows
             real xs = 0;               // this lane's share of sum_i pp_i x_i
             int paddr[R];
             [[maybe_unused]] unsigned rowid[FLY ? R : 1];   // FLY: (i1 << 16) | i2, ~0u for dead rows
             real rTz = 0;
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const int pos = row_pos(k, wv, lane);
-                const bool ok = pos < N;
-                const unsigned rm = rowmap[ok ? pos : 0];
-                if constexpr (FLY) rowid[k] = ok ? rm : ~0u;
-                const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
-                const node_t v1 = at32(g1.node, (unsigned)i1), v2 = at32(g2.node, (unsigned)i2);
-                const real dx = real(at32(g1.degree, (unsigned)i1)) *
-                                real(at32(g2.degree, (unsigned)i2)) * inv1q2;
-                const real vx = kappa_v(i1, i2, v1, v2);
-                // (double: two reciprocals of 6 instructions instead of the two
-                // divisions of 11 the compiler expands -- cg_ratio above)
-                dg[k] = ok ? cg_ratio(dx, vx) : real(0);
-                mi[k] = ok ? cg_ratio(vx, dx) : real(0);
-                paddr[k] = ok ? (int)__umul24((unsigned)i1, (unsigned)ldp) + i2 : dump;
-                const real b = ok ? dx * bscale : real(0);
-                if constexpr (KEEP_X) x[0][k] = 0;
-                else pp[k] = real(prm.p_start(v1)) * real(prm.p_start(v2));
-                if constexpr (LEAN) {
-                    const real zero[C] = {};
-                    store_elem<C>(lY, k * T + tid, zero);
-                }
-                r[0][k] = b;
-                p[0][k] = b * mi[k];
-                rTz += r[0][k] * p[0][k];
-                if constexpr (C == 2) {
-                    const real bx = ok ? real(prm.p_start(v1)) * real(prm.p_start(v2)) : real(0);
-                    x[1][k] = 0;
-                    r[1][k] = bx;
-                    p[1][k] = bx * mi[k];
-                    rTz += r[1][k] * p[1][k];
-                }
-            }
+            unsigned it = 0;
 
             // FLY: the owner of row (i1, i2) walks adj(i1) x adj(i2) and
             // evaluates the edge microkernel `ek` per term (per-lane trip
             // counts: the EXEC mask narrows as lanes finish); ysum[c][k] = the
             // off-diagonal sum of row batch k for right-hand side c over the
             // vector published in lp
-            [[maybe_unused]] auto fly_matvec = [&](auto const &ek, real (&ysum)[C][(STATIC || FLY) ? R : 1]) {
+            [[maybe_unused]] auto fly_matvec = [&](auto const &ek, real (&ysum)[CW][(STATIC || FLY) ? R : 1]) {
                 if constexpr (FLY) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
@@ -915,213 +920,301 @@ struct oc_solver {
                 }
             };
 
-            auto publish = [&](real const (&v)[C][R]) {
+            auto publish = [&](real const (&v)[CW][R]) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    real e[C];
+                    real e[CW];
 #pragma unroll
-                    for (int c = 0; c < C; ++c) e[c] = v[c][k];
-                    store_elem<C>(lp, (unsigned)paddr[k], e);
+                    for (int c = 0; c < CW; ++c) e[c] = v[c][k];
+                    store_elem<CW>(lp, (unsigned)paddr[k], e);
                 }
             };
-            publish(p);
-            job_sync<W>();   // the previous pair's last reduction is read
-            rTz = reduce::sum(rTz, red1);
-
-            const real tol = (C == 2) ? real(1e-10) * real(2 * N) : prm.ftol * real(N);
-            const real tol2 = tol * tol;
-            unsigned it = 0;
-            GD_MARK(cg_loop);
-            for (; it < (unsigned)N && rTz != real(0); ++it) {
-                job_sync<W>();   // p published
-                // row sums: sum over the slots of a batch, flushed to the
-                // lane-private cell Y[batch][lane] at wave-uniform positions
-                [[maybe_unused]] real ys[C][(STATIC || FLY) ? R : 1];   // static layouts / FLY: the row sums
-                if constexpr (STATIC || FLY) {
+            rTz = 0;
 #pragma unroll
-                    for (int k = 0; k < R; ++k)
-#pragma unroll
-                        for (int c = 0; c < C; ++c) ys[c][k] = 0;
-                }
-                if constexpr (FLY) {
-                    fly_matvec(prm.edge_kernel, ys);
-                } else {
-                    real acc[C];
-#pragma unroll
-                    for (int c = 0; c < C; ++c) acc[c] = 0;
-                    int kb = 0;
-                    unsigned fmv[NM];
-#pragma unroll
-                    for (int w = 0; w < NM; ++w) {
-                        fmv[w] = fm[w];
-                        asm volatile("" : "+s"(fmv[w]));
-                    }
-#pragma unroll
-                    for (int s0 = 0; s0 < S; s0 += GCH) {
-                        if (s0 >= n_slots) break;   // wave-uniform: no slots left
-                        // (static layouts have no branch between the chunks:
-                        // without the fence the scheduler merges their gathers
-                        // -- 16 instead of 8 vectors in flight, and spills)
-                        if constexpr (STATIC) __builtin_amdgcn_sched_barrier(0);
-                        real g[C][GCH];
-#pragma unroll
-                        for (int jj = 0; jj < GCH; ++jj) {
-                            real e[C];
-#pragma unroll
-                            for (int c = 0; c < C; ++c) e[c] = 0;
-                            if (s0 + jj < S) {
-                                if constexpr (PACK) {
-                                    // (the pin keeps the unpack -- one VALU --
-                                    // in the loop instead of S hoisted registers)
-                                    unsigned pk = adr[(s0 + jj) / 2];
-                                    asm volatile("" : "+v"(pk));
-                                    load_elem_at<C>(((s0 + jj) & 1) ? pk >> 16 : pk & 0xFFFFu, e);
-                                } else {
-                                    load_elem_at<C>(adr[s0 + jj], e);
-                                }
-                            }
-#pragma unroll
-                            for (int c = 0; c < C; ++c) g[c][jj] = e[c];
-                        }
-#pragma unroll
-                        for (int jj = 0; jj < GCH; ++jj) {
-                            const int s = s0 + jj;
-                            if (s < S) {
-#pragma unroll
-                                for (int c = 0; c < C; ++c) acc[c] += val[s] * g[c][jj];
-                                if (flush_at(s, fmv)) {   // wave-uniform
-                                    if constexpr (STATIC) {
-#pragma unroll
-                                        for (int c = 0; c < C; ++c) {
-                                            ys[c][kb] = acc[c];
-                                            acc[c] = 0;
-                                        }
-                                    } else if constexpr (ADDTID) {
-                                        store_lane_contiguous<0>(lY_off + kb * (T * 4), (float)acc[0]);
-                                        acc[0] = 0;
-                                    } else {
-                                        store_elem<C>(lY, kb * T + tid, acc);
-#pragma unroll
-                                        for (int c = 0; c < C; ++c) acc[c] = 0;
-                                    }
-                                    ++kb;
-                                }
-                            }
-                        }
-                    }
-                }
+            for (int k = 0; k < R; ++k) {
+                const int pos = row_pos(k, wv, lane);
+                const bool ok = pos < N;
+                const unsigned rm = rowmap[ok ? pos : 0];
+                if constexpr (FLY) rowid[k] = ok ? rm : ~0u;
+                const int i1 = (int)(rm >> 16), i2 = (int)(rm & 0xFFFFu);
+                const node_t v1 = at32(g1.node, (unsigned)i1), v2 = at32(g2.node, (unsigned)i2);
+                const real dx = real(at32(g1.degree, (unsigned)i1)) *
+                                real(at32(g2.degree, (unsigned)i2)) * inv1q2;
+                const real vx = kappa_v(i1, i2, v1, v2);
+                // (double: two reciprocals of 6 instructions instead of the two
+                // divisions of 11 the compiler expands -- cg_ratio above)
+                dg[k] = ok ? cg_ratio(dx, vx) : real(0);
+                mi[k] = ok ? cg_ratio(vx, dx) : real(0);
+                paddr[k] = ok ? (int)__umul24((unsigned)i1, (unsigned)ldp) + i2 : dump;
+                const real b = ok ? dx * bscale : real(0);
+                if constexpr (SEQ) xq[k] = 0;
+                else if constexpr (KEEP_X) x[0][k] = 0;
+                else pp[k] = real(prm.p_start(v1)) * real(prm.p_start(v2));
                 if constexpr (LEAN) {
-                    // update block from LDS-resident p and x (one wave: its LDS
-                    // operations execute in order, no barriers)
+                    const real zero[C] = {};
+                    store_elem<C>(lY, k * T + tid, zero);
+                }
+                r[0][k] = b;
+                p[0][k] = b * mi[k];
+                rTz += r[0][k] * p[0][k];
+                if constexpr (C == 2 && !SEQ) {
+                    const real bx = ok ? real(prm.p_start(v1)) * real(prm.p_start(v2)) : real(0);
+                    x[1][k] = 0;
+                    r[1][k] = bx;
+                    p[1][k] = bx * mi[k];
+                    rTz += r[1][k] * p[1][k];
+                }
+            }
+
+            // SEQ: the two systems one after the other (NSYS = 2); else one pass
+#pragma nounroll
+            for (int sys = 0; sys < NSYS; ++sys) {
+                if constexpr (SEQ) {
+                    if (sys == 1) {
+                        // second system: right-hand side p1 (x) p2; the
+                        // diagonal and the preconditioner stay
+                        rTz = 0;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            const int pos = row_pos(k, wv, lane);
+                            const bool ok = pos < N;
+                            const unsigned rm = rowmap[ok ? pos : 0];
+                            const node_t v1 = at32(g1.node, rm >> 16), v2 = at32(g2.node, rm & 0xFFFFu);
+                            const real b = ok ? real(prm.p_start(v1)) * real(prm.p_start(v2)) : real(0);
+                            xq[k] = 0;
+                            r[0][k] = b;
+                            p[0][k] = b * mi[k];
+                            rTz += r[0][k] * p[0][k];
+                        }
+                    }
+                }
+                publish(p);
+                job_sync<W>();   // the previous pair's last reduction is read
+                sreal rTz_s = sreduce::sum((sreal)rTz, sred1);
+
+                const real tol = (C == 2) ? real(1e-10) * real(2 * N) * real(SEQ ? 0.70710678118654752 : 1.0) : prm.ftol * real(N);
+                const sreal tol2 = (sreal)(tol * tol);
+                unsigned its = 0;
+                if constexpr (SEQ) {
+                    // (a definition of every slot register in front of the
+                    // loop: what the allocator spills of them around the
+                    // derivative pass is reloaded HERE, not use by use inside
+                    // the iteration -- it had put eight serialised
+                    // scratch_load + s_waitcnt vmcnt(0) pairs into the loop)
+#pragma unroll
+                    for (int s_ = 0; s_ < S; ++s_) asm volatile("" : "+v"(val[s_]), "+v"(adr[s_]));
+                }
+                GD_MARK(cg_loop);
+                for (; its < (unsigned)N && rTz_s != sreal(0); ++its) {
+                    job_sync<W>();   // p published
+                    // row sums: sum over the slots of a batch, flushed to the
+                    // lane-private cell Y[batch][lane] at wave-uniform positions
+                    [[maybe_unused]] real ys[CW][(STATIC || FLY) ? R : 1];   // static layouts / FLY: the row sums
+                    if constexpr (STATIC || FLY) {
+#pragma unroll
+                        for (int k = 0; k < R; ++k)
+#pragma unroll
+                            for (int c = 0; c < CW; ++c) ys[c][k] = 0;
+                    }
+                    if constexpr (FLY) {
+                        fly_matvec(prm.edge_kernel, ys);
+                    } else {
+                        real acc[CW];
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) acc[c] = 0;
+                        int kb = 0;
+                        unsigned fmv[NM];
+#pragma unroll
+                        for (int w = 0; w < NM; ++w) {
+                            fmv[w] = fm[w];
+                            asm volatile("" : "+s"(fmv[w]));
+                        }
+#pragma unroll
+                        for (int s0 = 0; s0 < S; s0 += GCH) {
+                            if (s0 >= n_slots) break;   // wave-uniform: no slots left
+                            // (static layouts have no branch between the chunks:
+                            // without the fence the scheduler merges their gathers
+                            // -- 16 instead of 8 vectors in flight, and spills)
+                            if constexpr (STATIC) __builtin_amdgcn_sched_barrier(0);
+                            real g[CW][GCH];
+#pragma unroll
+                            for (int jj = 0; jj < GCH; ++jj) {
+                                real e[CW];
+#pragma unroll
+                                for (int c = 0; c < CW; ++c) e[c] = 0;
+                                if (s0 + jj < S) {
+                                    if constexpr (PACK) {
+                                        // (the pin keeps the unpack -- one VALU --
+                                        // in the loop instead of S hoisted registers)
+                                        unsigned pk = adr[(s0 + jj) / 2];
+                                        asm volatile("" : "+v"(pk));
+                                        load_elem_at<CW>(((s0 + jj) & 1) ? pk >> 16 : pk & 0xFFFFu, e);
+                                    } else {
+                                        load_elem_at<CW>(adr[s0 + jj], e);
+                                    }
+                                }
+#pragma unroll
+                                for (int c = 0; c < CW; ++c) g[c][jj] = e[c];
+                            }
+#pragma unroll
+                            for (int jj = 0; jj < GCH; ++jj) {
+                                const int s = s0 + jj;
+                                if (s < S) {
+#pragma unroll
+                                    for (int c = 0; c < CW; ++c) acc[c] += val[s] * g[c][jj];
+                                    if (flush_at(s, fmv)) {   // wave-uniform
+                                        if constexpr (STATIC) {
+#pragma unroll
+                                            for (int c = 0; c < CW; ++c) {
+                                                ys[c][kb] = acc[c];
+                                                acc[c] = 0;
+                                            }
+                                        } else if constexpr (ADDTID) {
+                                            store_lane_contiguous<0>(lY_off + kb * (T * 4), (float)acc[0]);
+                                            acc[0] = 0;
+                                        } else {
+                                            store_elem<C>(lY, kb * T + tid, acc);
+#pragma unroll
+                                            for (int c = 0; c < C; ++c) acc[c] = 0;
+                                        }
+                                        ++kb;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if constexpr (LEAN) {
+                        // update block from LDS-resident p and x (one wave: its LDS
+                        // operations execute in order, no barriers)
+                        real pAp = 0;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            real pk[C];
+                            load_elem<C>(lp, (unsigned)paddr[k], pk);
+#pragma unroll
+                            for (int c = 0; c < C; ++c) {
+                                ys[c][k] = dg[k] * pk[c] - ys[c][k];   // (A p)
+                                pAp += pk[c] * ys[c][k];
+                            }
+                        }
+                        pAp = reduce::sum(pAp, red0);
+                        if (pAp == real(0)) break;
+                        const real alpha = cg_ratio((real)rTz_s, pAp);
+                        real rTr = 0, rTz_next = 0;
+#pragma unroll
+                        for (int k = 0; k < R; ++k)
+#pragma unroll
+                            for (int c = 0; c < C; ++c) {
+                                r[c][k] -= alpha * ys[c][k];
+                                rTr += r[c][k] * r[c][k];
+                                rTz_next += r[c][k] * (mi[k] * r[c][k]);
+                            }
+                        reduce::sum2(rTr, rTz_next, red1);
+                        real beta = cg_ratio(rTz_next, (real)rTz_s);
+                        asm volatile("" : "+v"(beta));
+                        // x += alpha p (also in the iteration that ends the loop,
+                        // like the register form) and p = z + beta p, in place
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            real pk[C], xv[C];
+                            load_elem<C>(lp, (unsigned)paddr[k], pk);
+                            load_elem<C>(lY, k * T + tid, xv);
+#pragma unroll
+                            for (int c = 0; c < C; ++c) {
+                                xv[c] += alpha * pk[c];
+                                pk[c] = mi[k] * r[c][k] + beta * pk[c];
+                            }
+                            store_elem<C>(lY, k * T + tid, xv);
+                            store_elem<C>(lp, (unsigned)paddr[k], pk);
+                        }
+                        if (rTr < (real)tol2) {   // sqrt(rTr) < tol
+                            ++its;
+                            break;
+                        }
+                        rTz_s = (sreal)rTz_next;
+                        continue;
+                    }
+                    // (no barrier: a lane reads back what it wrote itself, and the
+                    // LDS operations of one wave execute in order)
+                    real Ap[CW][R];
                     real pAp = 0;
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        real pk[C];
-                        load_elem<C>(lp, (unsigned)paddr[k], pk);
+                        real y[CW];
+                        if constexpr (STATIC || FLY) {
 #pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            ys[c][k] = dg[k] * pk[c] - ys[c][k];   // (A p)
-                            pAp += pk[c] * ys[c][k];
+                            for (int c = 0; c < CW; ++c) y[c] = ys[c][k];
+                        } else {
+                            load_elem<C>(lY, k * T + tid, y);
+                        }
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) {
+                            Ap[c][k] = dg[k] * p[c][k] - y[c];
+                            pAp += p[c][k] * Ap[c][k];
                         }
                     }
-                    pAp = reduce::sum(pAp, red0);
-                    if (pAp == real(0)) break;
-                    const real alpha = cg_ratio(rTz, pAp);
+                    const sreal pAp_s = sreduce::sum((sreal)pAp, sred0);
+                    if (pAp_s == sreal(0)) break;
+                    const real alpha = (real)cg_ratio(rTz_s, pAp_s);
                     real rTr = 0, rTz_next = 0;
+                    real z[CW][R];
+                    if constexpr (!KEEP_X) {
+                        real pdot = 0;   // (dead rows carry p = 0)
+#pragma unroll
+                        for (int k = 0; k < R; ++k) pdot += pp[k] * p[0][k];
+                        xs += alpha * pdot;
+                        // (here, not after the update of p: the old p can then be
+                        // overwritten in place instead of being copied)
+                        asm volatile("" : "+v"(xs));
+                    }
 #pragma unroll
                     for (int k = 0; k < R; ++k)
 #pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            r[c][k] -= alpha * ys[c][k];
+                        for (int c = 0; c < CW; ++c) {
+                            if constexpr (SEQ) xq[k] += alpha * p[c][k];
+                            else if constexpr (KEEP_X) x[c][k] += alpha * p[c][k];
+                            r[c][k] -= alpha * Ap[c][k];
+                            z[c][k] = mi[k] * r[c][k];
                             rTr += r[c][k] * r[c][k];
-                            rTz_next += r[c][k] * (mi[k] * r[c][k]);
+                            rTz_next += r[c][k] * z[c][k];
                         }
-                    reduce::sum2(rTr, rTz_next, red1);
-                    real beta = cg_ratio(rTz_next, rTz);
-                    asm volatile("" : "+v"(beta));
-                    // x += alpha p (also in the iteration that ends the loop,
-                    // like the register form) and p = z + beta p, in place
-#pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        real pk[C], xv[C];
-                        load_elem<C>(lp, (unsigned)paddr[k], pk);
-                        load_elem<C>(lY, k * T + tid, xv);
-#pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            xv[c] += alpha * pk[c];
-                            pk[c] = mi[k] * r[c][k] + beta * pk[c];
-                        }
-                        store_elem<C>(lY, k * T + tid, xv);
-                        store_elem<C>(lp, (unsigned)paddr[k], pk);
-                    }
-                    if (rTr < tol2) {   // sqrt(rTr) < tol
-                        ++it;
+                    sreal rTr_s = (sreal)rTr, rTz_next_s = (sreal)rTz_next;
+                    sreduce::sum2(rTr_s, rTz_next_s, sred1);
+                    if (rTr_s < tol2) {   // sqrt(rTr) < tol
+                        ++its;
                         break;
                     }
-                    rTz = rTz_next;
-                    continue;
+                    real beta = (real)cg_ratio(rTz_next_s, rTz_s);
+                    // (one scalar: without the pin fast-math turns z + beta p into
+                    // (p rTz') (1 / rTz) + z, a multiplication more per element)
+                    asm volatile("" : "+v"(beta));
+#pragma unroll
+                    for (int k = 0; k < R; ++k)
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) p[c][k] = z[c][k] + beta * p[c][k];
+                    // (W > 1: the barriers inside the reductions above are behind
+                    // every wave's gathers of the old p)
+                    publish(p);
+                    rTz_s = rTz_next_s;
                 }
-                // (no barrier: a lane reads back what it wrote itself, and the
-                // LDS operations of one wave execute in order)
-                real Ap[C][R];
-                real pAp = 0;
+                it += its;
+                if constexpr (SEQ) {
+                    // the first solution waits in a lane-private LDS cell (its
+                    // R reals would be live across the whole second solve)
+                    if (sys == 0) {
+#pragma unroll
+                        for (int k = 0; k < R; ++k) lY[k * T + tid] = xq[k];
+                    }
+                }
+            }
+            if constexpr (SEQ) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    real y[C];
-                    if constexpr (STATIC || FLY) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) y[c] = ys[c][k];
-                    } else {
-                        load_elem<C>(lY, k * T + tid, y);
-                    }
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        Ap[c][k] = dg[k] * p[c][k] - y[c];
-                        pAp += p[c][k] * Ap[c][k];
-                    }
+                    x[1][k] = xq[k];
+                    x[0][k] = lY[k * T + tid];
                 }
-                pAp = reduce::sum(pAp, red0);
-                if (pAp == real(0)) break;
-                const real alpha = cg_ratio(rTz, pAp);
-                real rTr = 0, rTz_next = 0;
-                real z[C][R];
-                if constexpr (!KEEP_X) {
-                    real pdot = 0;   // (dead rows carry p = 0)
-#pragma unroll
-                    for (int k = 0; k < R; ++k) pdot += pp[k] * p[0][k];
-                    xs += alpha * pdot;
-                    // (here, not after the update of p: the old p can then be
-                    // overwritten in place instead of being copied)
-                    asm volatile("" : "+v"(xs));
-                }
-#pragma unroll
-                for (int k = 0; k < R; ++k)
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        if constexpr (KEEP_X) x[c][k] += alpha * p[c][k];
-                        r[c][k] -= alpha * Ap[c][k];
-                        z[c][k] = mi[k] * r[c][k];
-                        rTr += r[c][k] * r[c][k];
-                        rTz_next += r[c][k] * z[c][k];
-                    }
-                reduce::sum2(rTr, rTz_next, red1);
-                if (rTr < tol2) {   // sqrt(rTr) < tol
-                    ++it;
-                    break;
-                }
-                real beta = cg_ratio(rTz_next, rTz);
-                // (one scalar: without the pin fast-math turns z + beta p into
-                // (p rTz') (1 / rTz) + z, a multiplication more per element)
-                asm volatile("" : "+v"(beta));
-#pragma unroll
-                for (int k = 0; k < R; ++k)
-#pragma unroll
-                    for (int c = 0; c < C; ++c) p[c][k] = z[c][k] + beta * p[c][k];
-                // (W > 1: the barriers inside the reductions above are behind
-                // every wave's gathers of the old p)
-                publish(p);
-                rTz = rTz_next;
             }
+            if constexpr (SEQ) it = (it + 1u) / 2u;   // (iterations per system)
             GD_MARK(epilogue);
             if (prm.iters != nullptr && tid == 0) prm.iters[prm.order[t]] = it;
             if constexpr (LEAN) {
@@ -1564,7 +1657,17 @@ struct oc_solver {
             // ---- analytic gradient (graph-level), marginalized_kernel.h:806-997
             if constexpr (C == 2) {
                 job_sync<W>();
-                publish(x);   // lp[2i] = YDq_i, lp[2i+1] = Yp_i
+                if constexpr (SEQ) {
+                    // two planes: lp[i] = YDq_i (the slots' gather addresses
+                    // are those of the one-component solves), lp[cap + i] = Yp_i
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        lp[paddr[k]] = x[0][k];
+                        lp[(unsigned)prm.u_capacity + (unsigned)paddr[k]] = x[1][k];
+                    }
+                } else {
+                    publish(x);   // lp[2i] = YDq_i, lp[2i+1] = Yp_i
+                }
                 real jac[n_jac];
 #pragma unroll
                 for (int j = 0; j < n_jac; ++j) jac[j] = 0;
@@ -1648,7 +1751,11 @@ struct oc_solver {
                         grid = open_grid(0u, 0u);
                         cur.row = grid.row;
                     }
-                    real yrow = lp[cur.row * 2 + 1];
+                    auto yp_of = [&](int row) -> real {
+                        if constexpr (SEQ) return lp[(unsigned)prm.u_capacity + (unsigned)row];
+                        else return lp[row * 2 + 1];
+                    };
+                    real yrow = yp_of(cur.row);
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         if (s < n_slots) {   // wave-uniform
@@ -1674,7 +1781,7 @@ struct oc_solver {
                             if (flush_at(s, fm) && s != S - 1) {   // wave-uniform
                                 ++kb;
                                 cur = open_walk(kb);
-                                yrow = lp[cur.row * 2 + 1];
+                                yrow = yp_of(cur.row);
                             }
                         }
                     }

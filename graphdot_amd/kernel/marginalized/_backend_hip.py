@@ -795,14 +795,15 @@ struct ${name}_t : ${name}_theta_t {
 
     #: static layouts that lose to the dynamic variants behind them in the
     #: menu (measured, scripts/oc_sweep.py): (double?, C) -> {layout, ...}.
-    #: The two-right-hand-side solver in double moves 16 bytes per gathered
-    #: element: it runs at the LDS rate in either form (14.3 / 18.4 / 22.7 ns
-    #: per pair for the three- / four- / five-batch pairs in the static form
-    #: against 14.5 / 17.2 / 21.7 in the dynamic one), and from six row
-    #: batches on the row-sum registers of the static form cost more than its
-    #: tests save (33.5 against 25.6 ns per pair): double value + gradient
-    #: solves keep the dynamic variants.
-    _STATIC_OFF = {(True, 2): {v.L for v in OC_STATIC_VARIANTS}}
+    #: Round 3 had the double value + gradient solves here: the STACKED
+    #: two-right-hand-side solver moves 16 bytes per gathered element and
+    #: keeps both systems' vectors in registers, and its static form was no
+    #: faster than the dynamic one (14.3 / 18.4 / 22.7 ns per pair for the
+    #: three- / four- / five-batch pairs against 14.5 / 17.2 / 21.7).  The
+    #: static double kernels now solve the two systems one after the other
+    #: (mgk_oc.h SEQ) and are back in the menu; GD_OC_SEQ=0 restores round 3.
+    _STATIC_OFF = {(True, 2): {v.L for v in OC_STATIC_VARIANTS}} \
+        if os.environ.get('GD_OC_SEQ') == '0' else {}
 
     def _static_enabled(self, v, C):
         f64 = np.dtype(self.real) == np.float64

@@ -250,13 +250,24 @@ def test_fit_lands_on_the_optimum_of_the_oracle_driven_fit(real, tol):
     solver (kernel matrix and gradient planes stay on the GPU, dense algebra
     there) and once by the CPU oracle (oracle/mgk_oracle.c compute_duo +
     derivative through the same MarginalizedGraphKernel / regressor code,
-    dense algebra on the CPU).  Both must land on the same theta*: within
-    1e-3 in log theta with the double solver, and on the same objective to
-    1e-6.  The float solver (the reference's arithmetic) gets the tolerance
-    the reference's users give the optimiser (`fit(tol=1e-5)`, its default:
-    float gradients are good to ~1e-3 relative and a tighter line search only
-    fails): theta* within 0.1 along the flat directions of this likelihood,
-    the objective within 1e-3."""
+    dense algebra on the CPU).  Both must land on the same optimum:
+
+    * the objective at theta*_hip, EVALUATED BY THE ORACLE, is the oracle
+      run's minimum to 1e-7 relative (double; 1e-3 for the float solver);
+    * theta*_hip = theta*_oracle within 1e-3 in log theta (double) in every
+      coordinate the data determine.  A coordinate may differ by more only
+      where the likelihood is flat beyond what either solver resolves: moving
+      that coordinate alone from one optimum to the other changes the
+      objective by less than 1e-8 relative -- both solves stop at a residual
+      of 1e-10 * 2N (marginalized_kernel.h:769), i.e. the objective carries
+      ~1e-9 relative of solver noise, and L-BFGS-B's own stopping rule is a
+      relative decrease of 1e-9 (on this set: the `conjugated` Kronecker
+      delta, d objective / d theta = 1e-5).
+
+    The float solver (the reference's arithmetic) gets the tolerance the
+    reference's users give the optimiser (`fit(tol=1e-5)`, its default: float
+    gradients are good to ~1e-3 relative and a tighter line search only
+    fails): theta* within 0.1, the objective within 1e-3."""
     import cases
     from oracle_backend import OracleBackend
     from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
@@ -274,14 +285,23 @@ def test_fit_lands_on_the_optimum_of_the_oracle_driven_fit(real, tol):
         start = gpr.log_marginal_likelihood(X=G, y=(y - y.mean()) / y.std())
         gpr.fit(G, y, tol=1e-9 if real is np.float64 else 1e-5)
         out.append((np.array(gpr.kernel.theta),
-                    gpr.log_marginal_likelihood(), start))
-    (t_hip, f_hip, s_hip), (t_ref, f_ref, s_ref) = out
+                    gpr.log_marginal_likelihood(), start, gpr))
+    (t_hip, f_hip, s_hip, _), (t_ref, f_ref, s_ref, ref) = out
     assert f_ref < s_ref - 10            # the optimiser went somewhere
-    assert np.abs(t_hip - t_ref).max() <= tol, (t_hip, t_ref)
-    assert f_hip == pytest.approx(f_ref, rel=1e-6 if real is np.float64
-                                  else 1e-3)
     assert s_hip == pytest.approx(s_ref, rel=1e-7 if real is np.float64
                                   else 1e-4)
+    assert f_hip == pytest.approx(f_ref, rel=1e-6 if real is np.float64
+                                  else 1e-3)
+    # the HIP run's optimum through the oracle's eyes
+    f_at_hip = ref.log_marginal_likelihood(t_hip)
+    assert f_at_hip <= f_ref + (1e-7 if real is np.float64 else 1e-3) \
+        * abs(f_ref)
+    for i in np.flatnonzero(np.abs(t_hip - t_ref) > tol):
+        moved = t_ref.copy()
+        moved[i] = t_hip[i]
+        flat = abs(ref.log_marginal_likelihood(moved) - f_ref)
+        assert flat <= (1e-8 if real is np.float64 else 1e-4) * abs(f_ref), \
+            (i, t_hip, t_ref, flat)
 
 
 def test_normalization_and_exponentiation_follow_the_protocol(data):
