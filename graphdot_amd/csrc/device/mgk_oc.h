@@ -317,6 +317,18 @@ struct oc_solver {
     constexpr static bool SEQ = C == 2 && STATIC && !NODAL && W == 1 &&
                                 (GD_OC_SEQ == 2 || (GD_OC_SEQ == 1 && sizeof(real) == 8));
     constexpr static int CW = SEQ ? 1 : C;      // right-hand sides per CG iteration
+#ifndef GD_OC_SEQ_XLDS
+#define GD_OC_SEQ_XLDS 0
+#endif
+    // SEQ_XLDS (off; measured): the solution being accumulated lives in a
+    // lane-private LDS cell (x += alpha p is a read-modify-write of R cells
+    // per iteration, no bank conflicts) instead of 2 R registers -- what the
+    // four-batch kernel lacks to run three waves per SIMD without reloading
+    // gather addresses from scratch inside the iteration.  It then runs no
+    // faster at three waves (3.08 ms) than with x in registers at two (2.98):
+    // the extra LDS operations cost what the third wave hides; at two waves
+    // the LDS form loses 9 % (scripts/sessions/r4_session4.sh).
+    constexpr static bool SEQ_XLDS = SEQ && GD_OC_SEQ_XLDS != 0;
     constexpr static int NSYS = C / CW;         // solves per pair
     constexpr static bool LEAN = STATIC && C == 2 && !NODAL && !SEQ;
 #ifndef GD_OC_FSCAL
@@ -844,6 +856,7 @@ struct oc_solver {
             [[maybe_unused]] unsigned rowid[FLY ? R : 1];   // FLY: (i1 << 16) | i2, ~0u for dead rows
             real rTz = 0;
             unsigned it = 0;
+            [[maybe_unused]] sreal rTr_first = 0;   // SEQ: |r|^2 the first solve ended with
 
             // FLY: the owner of row (i1, i2) walks adj(i1) x adj(i2) and
             // evaluates the edge microkernel `ek` per term (per-lane trip
@@ -947,7 +960,8 @@ struct oc_solver {
                 mi[k] = ok ? cg_ratio(vx, dx) : real(0);
                 paddr[k] = ok ? (int)__umul24((unsigned)i1, (unsigned)ldp) + i2 : dump;
                 const real b = ok ? dx * bscale : real(0);
-                if constexpr (SEQ) xq[k] = 0;
+                if constexpr (SEQ_XLDS) lY[NR + k * T + tid] = 0;
+                else if constexpr (SEQ) xq[k] = 0;
                 else if constexpr (KEEP_X) x[0][k] = 0;
                 else pp[k] = real(prm.p_start(v1)) * real(prm.p_start(v2));
                 if constexpr (LEAN) {
@@ -981,7 +995,8 @@ struct oc_solver {
                             const unsigned rm = rowmap[ok ? pos : 0];
                             const node_t v1 = at32(g1.node, rm >> 16), v2 = at32(g2.node, rm & 0xFFFFu);
                             const real b = ok ? real(prm.p_start(v1)) * real(prm.p_start(v2)) : real(0);
-                            xq[k] = 0;
+                            if constexpr (SEQ_XLDS) lY[NR + k * T + tid] = 0;
+                            else xq[k] = 0;
                             r[0][k] = b;
                             p[0][k] = b * mi[k];
                             rTz += r[0][k] * p[0][k];
@@ -992,8 +1007,11 @@ struct oc_solver {
                 job_sync<W>();   // the previous pair's last reduction is read
                 sreal rTz_s = sreduce::sum((sreal)rTz, sred1);
 
-                const real tol = (C == 2) ? real(1e-10) * real(2 * N) * real(SEQ ? 0.70710678118654752 : 1.0) : prm.ftol * real(N);
-                const sreal tol2 = (sreal)(tol * tol);
+                const real tol = (C == 2) ? real(1e-10) * real(2 * N) : prm.ftol * real(N);
+                // SEQ: the stacked rule rTr_0 + rTr_1 < tol^2 -- half the budget
+                // for the first system, what it left for the second
+                sreal tol2 = (sreal)(tol * tol);
+                if constexpr (SEQ) tol2 = sys == 0 ? tol2 * sreal(0.5) : tol2 - rTr_first;
                 unsigned its = 0;
                 if constexpr (SEQ) {
                     // (a definition of every slot register in front of the
@@ -1171,7 +1189,8 @@ struct oc_solver {
                     for (int k = 0; k < R; ++k)
 #pragma unroll
                         for (int c = 0; c < CW; ++c) {
-                            if constexpr (SEQ) xq[k] += alpha * p[c][k];
+                            if constexpr (SEQ_XLDS) lY[NR + k * T + tid] += alpha * p[c][k];
+                            else if constexpr (SEQ) xq[k] += alpha * p[c][k];
                             else if constexpr (KEEP_X) x[c][k] += alpha * p[c][k];
                             r[c][k] -= alpha * Ap[c][k];
                             z[c][k] = mi[k] * r[c][k];
@@ -1181,6 +1200,7 @@ struct oc_solver {
                     sreal rTr_s = (sreal)rTr, rTz_next_s = (sreal)rTz_next;
                     sreduce::sum2(rTr_s, rTz_next_s, sred1);
                     if (rTr_s < tol2) {   // sqrt(rTr) < tol
+                        if constexpr (SEQ) rTr_first = rTr_s;
                         ++its;
                         break;
                     }
@@ -1203,14 +1223,18 @@ struct oc_solver {
                     // R reals would be live across the whole second solve)
                     if (sys == 0) {
 #pragma unroll
-                        for (int k = 0; k < R; ++k) lY[k * T + tid] = xq[k];
+                        for (int k = 0; k < R; ++k) {
+                            if constexpr (SEQ_XLDS) lY[k * T + tid] = lY[NR + k * T + tid];
+                            else lY[k * T + tid] = xq[k];
+                        }
                     }
                 }
             }
             if constexpr (SEQ) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    x[1][k] = xq[k];
+                    if constexpr (SEQ_XLDS) x[1][k] = lY[NR + k * T + tid];
+                    else x[1][k] = xq[k];
                     x[0][k] = lY[k * T + tid];
                 }
             }

@@ -782,11 +782,14 @@ struct ${name}_t : ${name}_theta_t {
                      (1, 12, 2, 4): 4, (1, 16, 3, 4): 4, (1, 20, 3, 4): 3,
                      (1, 20, 4, 4): 2, (1, 24, 4, 4): 3, (1, 28, 5, 4): 3,
                      (1, 28, 6, 4): 2, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2},
-        (True, 2): {(16,): 2, (16, 4): 2, (16, 4, 1): 2, (16, 4, 4): 2,
+        # (static layouts: the sequential solves of mgk_oc.h SEQ, round 4 --
+        # scripts/sessions/r4_session2.sh / r4_session4.sh: three waves only
+        # where the loop stays free of scratch reloads, the three-batch kernel)
+        (True, 2): {(16,): 2, (16, 4): 2, (16, 4, 1): 3, (16, 4, 4): 2,
                     (16, 4, 4, 1): 2, (16, 4, 4, 1, 1): 2,
                     (16, 4, 4, 3, 1): 2, (16, 4, 4, 3, 1, 1): 2,
-                    (16, 4, 4, 4, 1, 1, 1): 1,
-                    (16, 4, 4, 4, 3, 1, 1, 1): 1,
+                    (16, 4, 4, 4, 1, 1, 1): 2,
+                    (16, 4, 4, 4, 3, 1, 1, 1): 2,
                     (16, 4, 4, 4, 4, 1, 1, 1, 1): 1,
                     (1, 12, 2, 4): 3, (1, 16, 3, 4): 3, (1, 20, 3, 4): 3,
                     (1, 20, 4, 4): 2, (1, 24, 4, 4): 2, (1, 28, 5, 4): 2,
