@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -48,11 +49,42 @@ struct rect_order_t {
 };
 const rect_order_t RECT;
 
+// Worker threads of the passes over job lists and class pairs: GD_HOST_THREADS,
+// default min(8, hardware threads); lists below `min_items` per thread stay
+// on the calling thread.
+inline int host_threads(int64_t n, int64_t min_items) {
+    static const int configured = [] {
+        const char *e = std::getenv("GD_HOST_THREADS");
+        int t = e ? std::atoi(e) : 0;
+        if (t <= 0) {
+            t = (int)std::thread::hardware_concurrency();
+            t = t <= 0 ? 1 : (t > 8 ? 8 : t);
+        }
+        return t > 64 ? 64 : t;
+    }();
+    const int64_t by_size = min_items > 0 ? n / min_items : n;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(configured, by_size));
+}
+
+// fn(begin, end, thread index) over [0, n) cut into T contiguous ranges
+template<class F> inline void parallel_ranges(int64_t n, int T, F &&fn) {
+    if (T <= 1) {
+        fn((int64_t)0, n, 0);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)T - 1);
+    for (int k = 1; k < T; ++k)
+        pool.emplace_back([&, k] { fn(n * k / T, n * (k + 1) / T, k); });
+    fn((int64_t)0, n / T, 0);
+    for (auto &th : pool) th.join();
+}
+
 }  // namespace
 
 extern "C" {
 
-const char *gdh_version(void) { return "gdhost 3.0 (round 3)"; }
+const char *gdh_version(void) { return "gdhost 4.0 (round 4)"; }
 
 int gdh_pack_graphs(int32_t G, const int64_t *node_off, const int64_t *edge_off,
                     const int64_t *node_id, const int64_t *ei, const int64_t *ej,
@@ -212,31 +244,65 @@ int gdh_number_records(const uint8_t *rec, int64_t n, int32_t itemsize,
             k += part_len[p];
         }
     }
-    std::vector<int64_t> idx((size_t)n);
-    std::iota(idx.begin(), idx.end(), 0);
+    // Distinct keys through a hash table (first occurrence kept: what a
+    // stable sort of all records would put first), then only THEY are sorted
+    // into np.unique's order -- a data set has a few dozen label classes among
+    // tens of thousands of records (a stable sort of every record took 1 ms
+    // of a 2.4 ms arena on the GPU box's host).
+    auto row = [&](int64_t i) { return keys.data() + i * stride; };
+    auto hash = [&](const uint8_t *k) {
+        uint64_t h = 1469598103934665603ull;
+        if (klen <= 8) {
+            uint64_t v;
+            std::memcpy(&v, k, 8);
+            h = (v ^ (v >> 29)) * 0x9E3779B97F4A7C15ull;
+            return h ^ (h >> 32);
+        }
+        for (int64_t t = 0; t < klen; ++t) h = (h ^ k[t]) * 1099511628211ull;
+        return h ^ (h >> 32);
+    };
+    size_t cap = 64;
+    while (cap < (size_t)n * 2) cap <<= 1;
+    std::vector<int64_t> slot(cap, -1);          // index into `distinct`
+    std::vector<int64_t> distinct;               // first record of every distinct key
+    std::vector<int32_t> tmp((size_t)n);         // record -> position in `distinct`
+    for (int64_t i = 0; i < n; ++i) {
+        size_t at = (size_t)hash(row(i)) & (cap - 1);
+        for (;;) {
+            const int64_t d = slot[at];
+            if (d < 0) {
+                slot[at] = (int64_t)distinct.size();
+                tmp[(size_t)i] = (int32_t)distinct.size();
+                distinct.push_back(i);
+                break;
+            }
+            if (std::memcmp(row(distinct[(size_t)d]), row(i), (size_t)stride) == 0) {
+                tmp[(size_t)i] = (int32_t)d;
+                break;
+            }
+            at = (at + 1) & (cap - 1);
+        }
+    }
+    const int64_t nc = (int64_t)distinct.size();
+    std::vector<int64_t> ord((size_t)nc);
+    std::iota(ord.begin(), ord.end(), 0);
     if (klen <= 8) {      // little-endian unsigned integers
         const uint64_t *k64 = reinterpret_cast<const uint64_t *>(keys.data());
-        std::stable_sort(idx.begin(), idx.end(),
-                         [&](int64_t x, int64_t y) { return k64[x] < k64[y]; });
-        int64_t nc = 0;
-        for (int64_t t = 0; t < n; ++t) {
-            if (t == 0 || k64[idx[(size_t)t]] != k64[idx[(size_t)(t - 1)]]) first[nc++] = idx[(size_t)t];
-            cls[idx[(size_t)t]] = (int32_t)(nc - 1);
-        }
-        *n_classes = nc;
-    } else {              // byte rows, lexicographic
-        auto row = [&](int64_t i) { return keys.data() + i * stride; };
-        std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) {
-            return std::memcmp(row(x), row(y), (size_t)klen) < 0;
+        std::sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) {
+            return k64[distinct[(size_t)x]] < k64[distinct[(size_t)y]];
         });
-        int64_t nc = 0;
-        for (int64_t t = 0; t < n; ++t) {
-            if (t == 0 || std::memcmp(row(idx[(size_t)t]), row(idx[(size_t)(t - 1)]), (size_t)klen) != 0)
-                first[nc++] = idx[(size_t)t];
-            cls[idx[(size_t)t]] = (int32_t)(nc - 1);
-        }
-        *n_classes = nc;
+    } else {              // byte rows, lexicographic
+        std::sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) {
+            return std::memcmp(row(distinct[(size_t)x]), row(distinct[(size_t)y]), (size_t)klen) < 0;
+        });
     }
+    std::vector<int32_t> number((size_t)nc);
+    for (int64_t c = 0; c < nc; ++c) {
+        number[(size_t)ord[(size_t)c]] = (int32_t)c;
+        first[c] = distinct[(size_t)ord[(size_t)c]];
+    }
+    for (int64_t i = 0; i < n; ++i) cls[i] = number[(size_t)tmp[(size_t)i]];
+    *n_classes = nc;
     return 0;
 }
 
@@ -246,12 +312,13 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
                     const uint16_t *hist, int32_t n_var, const int32_t *W,
                     const int32_t *S, const int32_t *R, const int32_t *D,
                     const int32_t *n_L, const int32_t *L, int32_t C,
-                    int32_t real_size, int64_t lds_limit, int32_t *choice,
-                    int64_t *NP) {
+                    int32_t real_size, int64_t lds_limit, int32_t fly_min_degree,
+                    int32_t *choice, int64_t *NP) {
     if (n_pairs < 0 || n_var < 0 || (C != 1 && C != 2)) return -1;
     (void)n_nz;
     constexpr int MAXL = 12;
-    for (int64_t t = 0; t < n_pairs; ++t) {
+    parallel_ranges(n_pairs, host_threads(n_pairs, 2048), [&](int64_t t0, int64_t t1, int) {
+    for (int64_t t = t0; t < t1; ++t) {
         const int32_t a = ca[t], b = cb[t];
         const int64_t n1 = n_node[a], n2 = n_node[b];
         const int64_t N = n1 * n2, np_ = n1 * (n2 | 1);
@@ -310,7 +377,7 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
             const int64_t nb = (N + T - 1) / T;
             bool ok = true;
             if (fly) {             // on-the-fly: the high-degree pairs
-                ok = pmd_true > 8;
+                ok = pmd_true > fly_min_degree;
             } else if (n_L[v] > 0) {      // static layout: every batch under its segment
                 for (int64_t k = 0; k < nb && ok; ++k) {
                     const int cap = k < n_L[v] && k < MAXL ? L[(size_t)v * MAXL + k] : 0;
@@ -336,19 +403,37 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
             }
         }
     }
+    });
     return 0;
 }
 
 int gdh_pair_keys(const uint32_t *jobs, int64_t n_jobs, const int32_t *cid,
                   int32_t n_graphs, int32_t nc, int32_t *pk, int64_t *count) {
     if (n_jobs < 0 || nc <= 0) return -1;
-    std::memset(count, 0, sizeof(int64_t) * (size_t)nc * (size_t)nc);
-    for (int64_t t = 0; t < n_jobs; ++t) {
-        const uint32_t i = jobs[2 * t], j = jobs[2 * t + 1];
-        if (i >= (uint32_t)n_graphs || j >= (uint32_t)n_graphs) return -1;
-        const int32_t k = cid[i] * nc + cid[j];
-        pk[t] = k;
-        ++count[k];
+    const size_t nk = (size_t)nc * (size_t)nc;
+    const int T = host_threads(n_jobs, 65536);
+    std::vector<std::vector<int64_t>> local((size_t)T);
+    std::vector<int> bad((size_t)T, 0);
+    parallel_ranges(n_jobs, T, [&](int64_t t0, int64_t t1, int k) {
+        std::vector<int64_t> &cnt = local[(size_t)k];
+        cnt.assign(nk, 0);
+        for (int64_t t = t0; t < t1; ++t) {
+            const uint32_t i = jobs[2 * t], j = jobs[2 * t + 1];
+            if (i >= (uint32_t)n_graphs || j >= (uint32_t)n_graphs) {
+                bad[(size_t)k] = 1;
+                return;
+            }
+            const int32_t key = cid[i] * nc + cid[j];
+            pk[t] = key;
+            ++cnt[(size_t)key];
+        }
+    });
+    for (int k = 0; k < T; ++k)
+        if (bad[(size_t)k]) return -1;
+    for (size_t key = 0; key < nk; ++key) {
+        int64_t c = 0;
+        for (int k = 0; k < T; ++k) c += local[(size_t)k][key];
+        count[key] = c;
     }
     return 0;
 }
@@ -357,64 +442,96 @@ int gdh_order_jobs(const int32_t *pk, int64_t n_jobs, const int32_t *rank_of_key
                    int64_t n_keys, int64_t n_ranks, uint32_t *order,
                    const uint32_t *jobs, uint32_t *jobs_sorted) {
     if (n_jobs < 0 || n_keys < 0 || n_ranks < 0) return -1;
-    if (n_ranks <= (1 << 16)) {
-        // counting sort: one counter per rank (at most 512 KB: cache resident)
-        std::vector<int64_t> start((size_t)n_ranks + 1, 0);
-        for (int64_t t = 0; t < n_jobs; ++t) {
-            if (pk[t] < 0 || pk[t] >= n_keys) return -1;
-            const int32_t r = rank_of_key[pk[t]];
-            if (r < 0 || r >= n_ranks) return -1;
-            ++start[(size_t)r + 1];
+    if (n_jobs > 0xFFFFFFFFll) return -1;
+    // Stable counting sort by rank, the job list cut into contiguous ranges
+    // for T threads: every thread counts the ranks of its range, one serial
+    // pass turns the T x n_ranks counts into start positions (rank-major,
+    // thread-minor: stable), every thread scatters its range.  The rank of a
+    // job is looked up once (pass 1) and kept in 4 bytes per job.
+    // (More ranks than fit the caches -- a million class pairs -- still work,
+    // only slower: the radix sort of round 3 covered a case no data set of
+    // the benchmarks produces and is gone.)
+    int T = host_threads(n_jobs, 65536);
+    while (T > 1 && (int64_t)T * n_ranks > (int64_t(1) << 24)) --T;
+    std::vector<uint32_t> rank((size_t)n_jobs);
+    std::vector<std::vector<int64_t>> start((size_t)T);
+    std::vector<int> bad((size_t)T, 0);
+    parallel_ranges(n_jobs, T, [&](int64_t t0, int64_t t1, int k) {
+        std::vector<int64_t> &cnt = start[(size_t)k];
+        cnt.assign((size_t)n_ranks, 0);
+        for (int64_t t = t0; t < t1; ++t) {
+            const int32_t key = pk[t];
+            if (key < 0 || key >= n_keys) {
+                bad[(size_t)k] = 1;
+                return;
+            }
+            const int32_t r = rank_of_key[key];
+            if (r < 0 || r >= n_ranks) {
+                bad[(size_t)k] = 1;
+                return;
+            }
+            rank[(size_t)t] = (uint32_t)r;
+            ++cnt[(size_t)r];
         }
-        for (int64_t r = 0; r < n_ranks; ++r) start[(size_t)r + 1] += start[(size_t)r];
-        for (int64_t t = 0; t < n_jobs; ++t) {
-            const int64_t at = start[(size_t)rank_of_key[pk[t]]]++;
+    });
+    for (int k = 0; k < T; ++k)
+        if (bad[(size_t)k]) return -1;
+    int64_t run = 0;
+    for (int64_t r = 0; r < n_ranks; ++r)
+        for (int k = 0; k < T; ++k) {
+            const int64_t c = start[(size_t)k][(size_t)r];
+            start[(size_t)k][(size_t)r] = run;
+            run += c;
+        }
+    const bool with_jobs = jobs && jobs_sorted;
+    parallel_ranges(n_jobs, T, [&](int64_t t0, int64_t t1, int k) {
+        std::vector<int64_t> &pos = start[(size_t)k];
+        for (int64_t t = t0; t < t1; ++t) {
+            const int64_t at = pos[rank[(size_t)t]]++;
             order[at] = (uint32_t)t;
-            if (jobs && jobs_sorted) {     // the job list in launch order, as uploaded
+            if (with_jobs) {          // the job list in launch order, as uploaded
                 jobs_sorted[2 * at] = jobs[2 * t];
                 jobs_sorted[2 * at + 1] = jobs[2 * t + 1];
             }
         }
-        return 0;
+    });
+    return 0;
+}
+
+int gdh_gather_section(const uint8_t *blob, const int64_t *blob_off, const int64_t *sec_off,
+                       int32_t col, const int64_t *count, int64_t G, int32_t itemsize,
+                       uint8_t *out, int64_t out_bytes) {
+    if (G < 0 || col < 0 || col >= 6 || itemsize < 0) return -1;
+    int64_t at = 0;
+    for (int64_t g = 0; g < G; ++g) {
+        const int64_t nb = count[g] * (int64_t)itemsize;
+        if (nb < 0 || at + nb > out_bytes) return -2;
+        std::memcpy(out + at, blob + blob_off[g] + sec_off[g * 6 + col], (size_t)nb);
+        at += nb;
     }
-    // More ranks (1000 distinct graphs: one per class pair, 5e5): a counting
-    // sort is bound by its scattered counters (2.8 ms on the GPU box's host).
-    // Items (rank << 32) | job are sorted least significant digit first in
-    // passes of 11 bits -- 2048 counters and output streams, sequential
-    // reads, every pass stable (1.8 ms).
-    std::vector<uint64_t> item((size_t)n_jobs), other;
-    for (int64_t t = 0; t < n_jobs; ++t) {
-        if (pk[t] < 0 || pk[t] >= n_keys) return -1;
-        const int32_t r = rank_of_key[pk[t]];
-        if (r < 0 || r >= n_ranks) return -1;
-        item[(size_t)t] = ((uint64_t)(uint32_t)r << 32) | (uint64_t)t;
-    }
-    constexpr int BITS = 11;
-    constexpr uint64_t MASK = (1u << BITS) - 1u;
-    int n_pass = 1;
-    while (n_pass * BITS < 31 && (int64_t(1) << (n_pass * BITS)) < n_ranks) ++n_pass;
-    if (n_pass > 1) other.resize((size_t)n_jobs);
-    uint64_t *src = item.data(), *dst = other.data();
-    for (int p = 0; p < n_pass; ++p) {
-        const int shift = 32 + p * BITS;
-        int64_t count[MASK + 2] = {0};
-        for (int64_t k = 0; k < n_jobs; ++k) ++count[((src[k] >> shift) & MASK) + 1];
-        for (uint64_t d = 0; d <= MASK; ++d) count[d + 1] += count[d];
-        if (p == n_pass - 1) {              // the last pass writes the job ids
-            for (int64_t k = 0; k < n_jobs; ++k)
-                order[count[(src[k] >> shift) & MASK]++] = (uint32_t)src[k];
-        } else {
-            for (int64_t k = 0; k < n_jobs; ++k)
-                dst[count[(src[k] >> shift) & MASK]++] = src[k];
-            std::swap(src, dst);
+    return 0;
+}
+
+int gdh_assemble_arena(int64_t G, const uint8_t *blob, const int64_t *blob_off,
+                       const int64_t *starts, const int64_t *cbytes, const int64_t *n_node,
+                       const int64_t *n_nz, const uint8_t *ncls, const uint8_t *ecls,
+                       uint8_t *host, int64_t host_bytes) {
+    if (G < 0) return -1;
+    int64_t vn = 0, ve = 0;
+    for (int64_t g = 0; g < G; ++g) {
+        const int64_t nb = blob_off[g + 1] - blob_off[g];
+        if (nb < 0 || starts[g] < cbytes[g] || starts[g] + nb > host_bytes) return -2;
+        std::memcpy(host + starts[g], blob + blob_off[g], (size_t)nb);
+        if (ncls && ecls && cbytes[g] > 0) {
+            uint8_t *c0 = host + starts[g] - cbytes[g];
+            const int64_t npad = (n_node[g] + 3) / 4 * 4;
+            if (npad + n_nz[g] > cbytes[g]) return -2;
+            std::memcpy(c0, ncls + vn, (size_t)n_node[g]);
+            std::memcpy(c0 + npad, ecls + ve, (size_t)n_nz[g]);
         }
+        vn += n_node[g];
+        ve += n_nz[g];
     }
-    if (jobs && jobs_sorted)               // the job list in launch order, as uploaded
-        for (int64_t k = 0; k < n_jobs; ++k) {
-            const uint32_t t = order[k];
-            jobs_sorted[2 * k] = jobs[2 * (size_t)t];
-            jobs_sorted[2 * k + 1] = jobs[2 * (size_t)t + 1];
-        }
     return 0;
 }
 

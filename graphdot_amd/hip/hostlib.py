@@ -26,10 +26,12 @@ SIGNATURES = {
     + [_i64, _vp, _vp],
     'gdh_number_records': [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
     'gdh_classify_oc': [_i64] + [_vp] * 7 + [_i32] + [_vp] * 6
-    + [_i32, _i32, _i64, _vp, _vp],
+    + [_i32, _i32, _i64, _i32, _vp, _vp],
     'gdh_pair_keys': [_vp, _i64, _vp, _i32, _i32, _vp, _vp],
     'gdh_order_jobs': [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp],
     'gdh_pairwise_jobs': [_i64, _i64, _vp],
+    'gdh_gather_section': [_vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp, _i64],
+    'gdh_assemble_arena': [_i64] + [_vp] * 9 + [_i64],
 }
 
 
@@ -47,7 +49,8 @@ def build_library(force=False):
         return LIB_PATH
     cxx = os.environ.get('CXX', 'g++')
     tmp = LIB_PATH + f'.{os.getpid()}.tmp'
-    cmd = [cxx, '-O2', '-fPIC', '-shared', '-std=c++17', f'-I{INCLUDE}', src,
+    cmd = [cxx, '-O2', '-fPIC', '-shared', '-std=c++17', '-pthread',
+           f'-I{INCLUDE}', src,
            '-o', tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -153,7 +156,7 @@ def number_records(records, parts):
 
 
 def classify_oc(ca, cb, n_node, n_nz, image_bytes, maxdeg, hist, variants, C,
-                real_size, lds_limit):
+                real_size, lds_limit, fly_min_degree=8):
     """Variant index (into `variants`, a list of (W, S, R, D, L or None)) per
     class pair, or -1; and NP per pair."""
     ca, cb = _c(ca, np.int32), _c(cb, np.int32)
@@ -176,7 +179,7 @@ def classify_oc(ca, cb, n_node, n_nz, image_bytes, maxdeg, hist, variants, C,
         _p(_c(n_nz, np.int32)), _p(_c(image_bytes, np.int64)),
         _p(_c(maxdeg, np.int32)), _p(_c(hist, np.uint16)), nv, _p(W), _p(S),
         _p(R), _p(D), _p(nL), _p(L), int(C), int(real_size), int(lds_limit),
-        _p(choice), _p(NP)), 'gdh_classify_oc')
+        int(fly_min_degree), _p(choice), _p(NP)), 'gdh_classify_oc')
     return choice, NP
 
 
@@ -219,3 +222,30 @@ def pairwise_jobs(nx, ny=None, dtype=None):
     _check(lib().gdh_pairwise_jobs(int(nx), -1 if ny is None else int(ny),
                                    _p(jobs)), 'gdh_pairwise_jobs')
     return jobs if dtype is None else jobs.view(dtype)
+
+
+def gather_section(blob, blob_off, sec_off, col, count, dtype):
+    """Records of section `col` of every graph of a packed batch as one
+    array of `dtype`."""
+    dtype = np.dtype(dtype)
+    count = _c(count, np.int64)
+    blob_off = _c(blob_off, np.int64)
+    out = np.empty(int(count.sum()), dtype=dtype)
+    raw = out.view(np.uint8) if dtype.itemsize else out
+    _check(lib().gdh_gather_section(
+        _p(blob), _p(blob_off), _p(_c(sec_off, np.int64)), int(col), _p(count),
+        len(count), dtype.itemsize, _p(raw), out.nbytes), 'gdh_gather_section')
+    return out
+
+
+def assemble_arena(blob, blob_off, starts, cbytes, n_node, n_nz, ncls, ecls,
+                   host):
+    """Blobs (and label-class sections) of a packed batch into the arena
+    image `host` (uint8)."""
+    _check(lib().gdh_assemble_arena(
+        len(starts), _p(blob), _p(_c(blob_off, np.int64)),
+        _p(_c(starts, np.int64)), _p(_c(cbytes, np.int64)),
+        _p(_c(n_node, np.int64)), _p(_c(n_nz, np.int64)),
+        None if ncls is None else _p(_c(ncls, np.uint8)),
+        None if ecls is None else _p(_c(ecls, np.uint8)),
+        _p(host), host.nbytes), 'gdh_assemble_arena')

@@ -148,9 +148,14 @@ def ensure_device(device=None):
         if n.value <= 0:
             raise HIPError('no HIP device')
         if _device != device % n.value:
+            first = _device is None
             check(lib().gd_init(device % n.value))
             _device = device % n.value
             _thread.device = _device
+            if first and os.environ.get('GD_PINNED_RESULTS', '1') != '0':
+                # (with the context: two result blocks pinned ahead of the
+                # first evaluation, 3 ms once per process)
+                warm_pinned_pool()
     if getattr(_thread, 'device', None) != _device:
         check(lib().gd_set_device(_device))
         _thread.device = _device
@@ -187,6 +192,107 @@ def _staging(nbytes):
         _staging_view = np.frombuffer(
             (ctypes.c_uint8 * cap).from_address(p.value), dtype=np.uint8)
     return _staging_view
+
+
+# --------------------------------------------------------------------------
+# pinned host arrays for results
+# --------------------------------------------------------------------------
+#: result arrays of this many bytes and more come from the pinned pool
+PINNED_MIN_BYTES = 256 << 10
+#: ... up to this size each (a nodal matrix of gigabytes stays pageable)
+PINNED_MAX_BYTES = 96 << 20
+#: pinned bytes the pool may hold idle (what is lent out is not counted)
+PINNED_POOL_BYTES = 256 << 20
+_pinned_lock = threading.Lock()
+_pinned_free = {}        # capacity -> [pointer, ...]
+_pinned_idle = 0
+_pinned_live = {}        # pointer -> capacity (lent out)
+
+
+class _PinnedBlock:
+    """Owner of one pinned allocation lent to a numpy array: numpy keeps it
+    as the `base` of the array and of every view of it; when the last one is
+    gone the block goes back to the pool."""
+
+    def __init__(self, ptr, cap, nbytes):
+        self.ptr, self.cap = ptr, cap
+        self.__array_interface__ = dict(
+            shape=(nbytes,), typestr='|u1', data=(ptr, False), version=3)
+
+    def __del__(self):
+        global _pinned_idle
+        if _lib is None:
+            return
+        with _pinned_lock:
+            _pinned_live.pop(self.ptr, None)
+            if _pinned_idle + self.cap <= PINNED_POOL_BYTES:
+                _pinned_free.setdefault(self.cap, []).append(self.ptr)
+                _pinned_idle += self.cap
+                return
+        try:
+            _lib.gd_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(size, dtype):
+    """A 1-D numpy array of `size` elements in pinned host memory
+    (hipHostMalloc through gd_host_alloc), from a process-wide pool: the
+    device copies results into it by DMA, where a pageable array takes the
+    bytes through the pinned staging buffer and one more memcpy (0.7 ms for
+    the 8 MB matrix of 1000 graphs, 5 ms for its seven gradient planes).  The
+    role of the reference's managed-memory output arrays
+    (graphdot/cuda/array.py:14-31, `umempty`).  Blocks return to the pool when
+    the array and all its views are gone; pinning costs 0.2 ms per MB, which
+    is why they are kept.  Small and very large arrays stay pageable."""
+    import numpy as np
+    global _pinned_idle
+    dtype = np.dtype(dtype)
+    nbytes = int(size) * dtype.itemsize
+    if not (PINNED_MIN_BYTES <= nbytes <= PINNED_MAX_BYTES) \
+            or dtype.hasobject \
+            or os.environ.get('GD_PINNED_RESULTS', '1') == '0':
+        return np.empty(int(size), dtype)
+    cap = 1 << (nbytes - 1).bit_length() if nbytes <= (8 << 20) \
+        else -(-nbytes // (8 << 20)) * (8 << 20)
+    ptr = None
+    with _pinned_lock:
+        free = _pinned_free.get(cap)
+        if free:
+            ptr = free.pop()
+            _pinned_idle -= cap
+    if ptr is None:
+        try:
+            ensure_device()
+            p = ctypes.c_void_p()
+            check(lib().gd_host_alloc(ctypes.byref(p), cap))
+        except HIPError:
+            # (no device, or no pinnable memory left: a pageable array; the
+            # evaluation that follows reports a missing device itself)
+            return np.empty(int(size), dtype)
+        ptr = p.value
+    with _pinned_lock:
+        _pinned_live[ptr] = cap
+    block = _PinnedBlock(ptr, cap, nbytes)
+    return np.asarray(block).view(dtype)
+
+
+def is_pinned(array):
+    """Does `array` lie in a block of the pinned pool?"""
+    a = array.ctypes.data
+    with _pinned_lock:
+        for ptr, cap in _pinned_live.items():
+            if ptr <= a and a + array.nbytes <= ptr + cap:
+                return True
+    return False
+
+
+def warm_pinned_pool(sizes=(8 << 20, 8 << 20)):
+    """Pin a few result blocks ahead of the first evaluation (called with
+    the device context by HIPBackend: process start-up, not per call)."""
+    import numpy as np
+    held = [pinned_empty(n, np.uint8) for n in sizes]
+    del held
 
 
 class DeviceBuffer:
@@ -229,7 +335,7 @@ class DeviceBuffer:
         import numpy as np
         assert array.flags['C_CONTIGUOUS']
         assert offset + array.nbytes <= self.nbytes
-        if array.nbytes >= STAGED_UPLOAD_BYTES:
+        if array.nbytes >= STAGED_UPLOAD_BYTES and not is_pinned(array):
             # large pageable destinations: through the pinned staging buffer
             # (the 8 MB matrix of 1000 graphs into a fresh numpy array took
             # 10 ms directly: the runtime pins the untouched pages)

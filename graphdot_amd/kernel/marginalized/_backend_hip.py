@@ -94,7 +94,7 @@ OC_VARIANTS = OC_STATIC_VARIANTS + [
 ] + OC_FLY_VARIANTS
 #: pairs with a node of more than this many neighbours are what the
 #: on-the-fly variants are for (the slot variants stop at degree 8)
-FLY_MIN_DEGREE = int(os.environ.get('GD_FLY_MIN_DEGREE', 8))   # (the override: numpy classification only)
+FLY_MIN_DEGREE = int(os.environ.get('GD_FLY_MIN_DEGREE', 8))
 #: sentinel: the global-memory general solver (any pair size)
 GENERAL = Variant(0, 0, 0)
 #: sentinel: the kernel that fills the global microkernel tables
@@ -380,7 +380,11 @@ class HIPBackend(Backend):
 
     @staticmethod
     def empty(size, dtype=np.float32):
-        return np.empty(size, dtype)
+        """Output buffers of the caller (reference: managed memory,
+        graphdot/cuda/array.py:14-31): large ones come from a pool of pinned
+        host blocks, so that `collect` copies the result by DMA straight into
+        the array the user gets (hip/runtime.py::pinned_empty)."""
+        return runtime.pinned_empty(size, dtype)
 
     def __init__(self, **kwargs):
         self.uuid = uuid.uuid4()
@@ -1076,8 +1080,17 @@ void ${name}(params_t prm) {
                 key[k, :width] = np.bincount(g.adjacency_count,
                                              minlength=width)
                 key[k, width] = g.image_bytes
-        _, rep, cid = np.unique(key, axis=0, return_index=True,
-                                return_inverse=True)
+        if self.native:
+            # (distinct rows through a hash table, gdh_number_records:
+            # np.unique(axis=0) sorts the rows as byte strings, 0.7 ms)
+            from ...hip import hostlib
+            rows = np.ascontiguousarray(key)
+            rows = rows.view(np.dtype((np.void, rows.shape[1]
+                                       * rows.itemsize))).reshape(-1)
+            cid, rep = hostlib.number_records(rows, [(0, rows.dtype.itemsize)])
+        else:
+            _, rep, cid = np.unique(key, axis=0, return_index=True,
+                                    return_inverse=True)
         cid, nc = cid.reshape(-1).astype(np.int32), len(rep)
         if self.native and jobs is not None:
             from ...hip import hostlib
@@ -1169,7 +1182,7 @@ void ${name}(params_t prm) {
             ch, _ = hostlib.classify_oc(
                 ji, jj, n_node, n_nz, image_oc, maxdeg, hist,
                 [(v.W, v.S, v.R, v.D, v.L) for _, v in menu], C,
-                np.dtype(self.real).itemsize, LDS_LIMIT)
+                np.dtype(self.real).itemsize, LDS_LIMIT, FLY_MIN_DEGREE)
             idx = np.array([k for k, _ in menu], dtype=np.int64)
             hit = ch >= 0
             choice[hit] = idx[ch[hit]]

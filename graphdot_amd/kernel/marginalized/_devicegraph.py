@@ -25,6 +25,7 @@ many graphs are concatenated into one arena and uploaded with a single copy.
 """
 import itertools as it
 import numpy as np
+from operator import itemgetter
 from numpy.lib.recfunctions import repack_fields
 from ...codegen.cpptool import cpptype
 from ...codegen.typetool import common_min_type, is_scalar_type
@@ -427,13 +428,25 @@ def pack_many(graphs, real=np.float32, native=True):
         return out
     gs = [graphs[k] for k in batch]
     G = len(gs)
+    nframes, eframes = [g.nodes for g in gs], [g.edges for g in gs]
+
+    def columns(frames):
+        """{column: the arrays of all frames} with one C-level lookup per
+        frame (the frames have the first one's columns: `same` above)"""
+        keys = list(frames[0]._data)
+        get = itemgetter(*keys)
+        rows = [get(f._data) for f in frames]
+        if len(keys) == 1:
+            return {keys[0]: rows}
+        return dict(zip(keys, zip(*rows)))
+
+    ncols, ecols = columns(nframes), columns(eframes)
 
     def cat(frames, key):
-        return np.concatenate([f._data[key] for f in frames])
+        return np.concatenate((ncols if frames is nframes else ecols)[key])
 
-    nframes, eframes = [g.nodes for g in gs], [g.edges for g in gs]
-    n = np.array([len(f._data['!i']) for f in nframes], dtype=np.int64)
-    m = np.array([len(f._data['!i']) for f in eframes], dtype=np.int64)
+    n = np.fromiter(map(len, ncols['!i']), dtype=np.int64, count=G)
+    m = np.fromiter(map(len, ecols['!i']), dtype=np.int64, count=G)
     node0 = np.concatenate(([0], np.cumsum(n)))
     edge0 = np.concatenate(([0], np.cumsum(m)))
     Nn, Ne = int(node0[-1]), int(edge0[-1])
@@ -810,6 +823,11 @@ def _label_classes(dgraphs, vfields=None, efields=None, max_classes=255,
         if dt.itemsize == 0:
             return np.zeros(int(sum(count)), dt)
         b0 = whole_batch(dgraphs)
+        if b0 is not None and native:
+            from ...hip import hostlib
+            return hostlib.gather_section(
+                b0['blob'], b0['blob_off'], b0['sec_off'],
+                SECTIONS.index(section), count, dt)
         if b0 is not None:
             # (plain lists of offsets into the batch's blob: no per-graph
             # views or offset dictionaries)
@@ -903,7 +921,15 @@ class GraphArena:
                 erep.view(np.uint8).ravel() if erep.nbytes else []
         self._relocs = []
         hdr = np.zeros(self.n, dtype=HEADER_DTYPE)
-        if b0 is not None and not cbytes.any():
+        natively = native and b0 is not None and self.n > 0
+        if natively:
+            # blobs and class sections in one native pass (gdh_assemble_arena)
+            from ...hip import hostlib
+            hostlib.assemble_arena(
+                b0['blob'], b0['blob_off'], starts, cbytes, feat['n_node'],
+                feat['n_nz'], None if cls is None else ncls,
+                None if cls is None else ecls, self.host)
+        elif b0 is not None and not cbytes.any():
             # the batch's blobs are back to back already: one copy
             self.host[cursor:] = b0['blob']
         elif b0 is not None:
@@ -927,7 +953,7 @@ class GraphArena:
                     b0['sec_off'][:, s_] if b0 is not None else np.array(
                         [g.offsets[name] for g in dgraphs], dtype=np.int64))
             hdr['hist'] = feat['hist']
-            if cls is not None:
+            if cls is not None and not natively:
                 # class ids in front of every blob: [node classes, padded to
                 # 4][edge classes], one scatter per kind
                 c0 = starts - cbytes

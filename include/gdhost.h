@@ -92,7 +92,8 @@ int gdh_number_records(const uint8_t *rec, int64_t n, int32_t itemsize,
  * [16 per class] (hist[15]: 15 and above).
  * Per variant v: waves W, slots S, rows R, degree bound D, static layout
  * L [12 per variant, zero padded] of n_L entries (0: dynamic layout).  S = 0
- * marks an on-the-fly variant: the pairs with a degree above 8.
+ * marks an on-the-fly variant: the pairs with a degree above fly_min_degree
+ * (8: where the slot variants end).
  * C: right-hand sides (1 value, 2 value + gradient); real_size 4 or 8;
  * lds_limit bytes per workgroup.
  * Outputs per pair: choice (variant index or -1), NP (rows with the odd LDS
@@ -103,8 +104,8 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
                     const uint16_t *hist, int32_t n_var, const int32_t *W,
                     const int32_t *S, const int32_t *R, const int32_t *D,
                     const int32_t *n_L, const int32_t *L, int32_t C,
-                    int32_t real_size, int64_t lds_limit, int32_t *choice,
-                    int64_t *NP);
+                    int32_t real_size, int64_t lds_limit, int32_t fly_min_degree,
+                    int32_t *choice, int64_t *NP);
 
 /* Class-pair key of every job: pk[t] = cid[jobs[t].i] * nc + cid[jobs[t].j]
  * (jobs: n_jobs (u32 i, u32 j) pairs), and count [nc * nc] the number of jobs
@@ -120,6 +121,26 @@ int gdh_pair_keys(const uint32_t *jobs, int64_t n_jobs, const int32_t *cid,
 int gdh_order_jobs(const int32_t *pk, int64_t n_jobs, const int32_t *rank_of_key,
                    int64_t n_keys, int64_t n_ranks, uint32_t *order,
                    const uint32_t *jobs, uint32_t *jobs_sorted);
+
+/* One section (col: 0 degree, 1 node, 2 rowptr, 3 nz, 4 edge, 5 perm) of every
+ * graph of a packed batch back to back: count[g] records of itemsize bytes
+ * from blob + blob_off[g] + sec_off[6 g + col].  (The label-class numbering
+ * reads all node / edge records of a call as one array; numpy concatenated
+ * a thousand slices for it.) */
+int gdh_gather_section(const uint8_t *blob, const int64_t *blob_off, const int64_t *sec_off,
+                       int32_t col, const int64_t *count, int64_t G, int32_t itemsize,
+                       uint8_t *out, int64_t out_bytes);
+
+/* The graph part of the arena image (GraphArena, _devicegraph.py; role of the
+ * per-graph device copies of the reference, _octilegraph.py:170-189): blob g
+ * of a packed batch goes to host + starts[g], and -- when ncls / ecls are
+ * given -- the u8 label classes of its nodes (pad4) and nonzeros to the
+ * cbytes[g] bytes in front of it.  ncls / ecls: the classes of all graphs
+ * back to back. */
+int gdh_assemble_arena(int64_t G, const uint8_t *blob, const int64_t *blob_off,
+                       const int64_t *starts, const int64_t *cbytes, const int64_t *n_node,
+                       const int64_t *n_nz, const uint8_t *ncls, const uint8_t *ecls,
+                       uint8_t *host, int64_t host_bytes);
 
 /* The job list of a kernel-matrix evaluation, (u32 i, u32 j) per pair in
  * row-major order: ny < 0: the upper triangle of an nx x nx symmetric matrix

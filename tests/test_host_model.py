@@ -586,3 +586,31 @@ def test_reference_kernel_object_drives_the_hip_backend():
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'drop-in seam ok' in r.stdout
     assert r.stdout.count('10 backend calls') == 4
+
+
+@pytest.mark.parametrize('weighted', [False, True])
+def test_native_arena_assembly_equals_the_numpy_restatement(weighted):
+    """gdh_gather_section / gdh_number_records (hash numbering) /
+    gdh_assemble_arena against the numpy GraphArena: the same image, headers,
+    class representatives, byte for byte -- molecules (label classes in use)
+    and weighted random graphs with continuous edge labels (many classes)."""
+    import cases
+    from graphdot_amd.kernel.marginalized._devicegraph import (
+        pack_many, GraphArena)
+    if weighted:
+        G = cases.config2_graphs(40, seed=4)
+        fields = (('category',), ('length',))
+    else:
+        G = cases.config3_graphs(120, seed=8)
+        fields = (('aromatic', 'atomic_number', 'hcount'),
+                  ('conjugated', 'order'))
+    for real in (np.float32, np.float64):
+        dgs = pack_many(G, real=real)
+        for f in (fields, (None, None), ((), ())):
+            a = GraphArena(dgs, *f, native=True)
+            b = GraphArena(dgs, *f, native=False)
+            assert a.nbytes == b.nbytes and (a.classes is None) == (b.classes is None)
+            if a.classes is not None:
+                assert a.classes == b.classes
+            assert np.array_equal(a.host, b.host)
+            assert np.array_equal(a.relocated(4096), b.relocated(4096))
