@@ -292,9 +292,15 @@ struct oc_solver {
     // workgroup -- everything else spilled (268 B of scratch per lane,
     // profiles/r02_c2_pmc.csv).  Packed, a slot costs one extra VALU per
     // iteration (the unpack, kept inside the loop) and half an address
-    // register.  The one-pass float value solvers only.
-    constexpr static bool PACK = GD_OC_PACK != 0 && sizeof(real) == 4 && C == 1 && !NODAL && !STATIC && !FLY &&
-                                 ((S >= 64 && W >= 8) || GD_OC_PACK == 2);
+    // register.  Float: the one-pass value solvers with 64 slots and 8 or 16
+    // waves.  Double (round 4; two-pass setup): the 16-wave value solvers,
+    // capped at 128 registers -- a slot is 2 + 1/2 registers instead of 3:
+    // configuration 2's (16,40,2) 1.85 -> 1.18 ms, (16,64,3) 1.02 -> 0.88;
+    // the 4- and 8-wave variants have the registers and only pay the unpack
+    // (+6 ... 9 %, scripts/sessions/r4_session8.sh).  GD_OC_PACK=3: double out.
+    constexpr static bool PACK = GD_OC_PACK != 0 && C == 1 && !NODAL && !STATIC && !FLY &&
+                                 ((sizeof(real) == 4 ? (S >= 64 && W >= 8)
+                                                     : (GD_OC_PACK != 3 && W >= 16)) || GD_OC_PACK == 2);
     constexpr static int NADR = PACK ? (S + 1) / 2 : SA;
     // LEAN (static layouts, value + gradient): the solution x lives in a
     // lane-private LDS region and p only in its published copy -- the update
@@ -803,11 +809,15 @@ struct oc_solver {
                     // pass 1 (unrolled): the nonzero pair (a, b) of every slot
                     int kb = 0, j = 0, ja = 0, jb = 0;
                     row_t cur = open_row(0);
+                    // (PACK: the (a, b) pairs of pass 1 in an array of their
+                    // own, consumed slot by slot while `adr` fills up)
+                    [[maybe_unused]] unsigned ab_[PACK ? SA : 1];
+                    unsigned (&ab)[PACK ? SA : NADR] = select_array<PACK>(ab_, adr);
     #pragma unroll
                     for (int s = 0; s < S; ++s) {
-                        adr[s] = (s < n_slots && j < cur.prod)
+                        ab[s] = (s < n_slots && j < cur.prod)
                             ? ((unsigned)(cur.rs1 + ja) << 16) | (unsigned)(cur.rs2 + jb) : ~0u;
-                        asm volatile("" : "+v"(adr[s]));
+                        asm volatile("" : "+v"(ab[s]));
                         ++j;
                         ++jb;
                         if (jb >= cur.d2) {
@@ -824,8 +834,8 @@ struct oc_solver {
     #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         if (s % SETUP_CHUNK == 0) __builtin_amdgcn_sched_barrier(0);
-                        const bool ok = adr[s] != ~0u;
-                        const unsigned a = ok ? (adr[s] >> 16) : 0u, b = ok ? (adr[s] & 0xFFFFu) : 0u;
+                        const bool ok = ab[s] != ~0u;
+                        const unsigned a = ok ? (ab[s] >> 16) : 0u, b = ok ? (ab[s] & 0xFFFFu) : 0u;
                         const nz_t z1 = at32(g1.nz, a), z2 = at32(g2.nz, b);
                         real e;
                         if constexpr (TAB) {
@@ -841,7 +851,13 @@ struct oc_solver {
                         unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
                         col = lp_off + col * ELEM;
                         asm volatile("" : "+v"(val[s]), "+v"(col));
-                        adr[s] = col;
+                        if constexpr (PACK) {
+                            // (byte addresses below 64 KB: at most 4096 rows of 8 bytes)
+                            if (s % 2 == 0) adr[s / 2] = col;
+                            else adr[s / 2] |= col << 16;
+                        } else {
+                            adr[s] = col;
+                        }
                     }
                 }
             }
@@ -1829,6 +1845,11 @@ struct oc_solver {
         }
     }
 
+    // the first array if B, else the second (their extents differ)
+    template<bool B, class X, class Y> __device__ static __forceinline__ auto &select_array(X &x, Y &y) {
+        if constexpr (B) return x;
+        else return y;
+    }
     // lane LANE of v = s (s wave-uniform)
     template<int LANE> __device__ static __forceinline__ void writelane(int &v, int s) {
         asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));

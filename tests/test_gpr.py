@@ -293,7 +293,7 @@ def test_fit_lands_on_the_optimum_of_the_oracle_driven_fit(real, tol):
     (t_hip, f_hip, s_hip, _), (t_ref, f_ref, s_ref, ref) = out
     assert f_ref < s_ref - 10            # the optimiser went somewhere
     assert s_hip == pytest.approx(s_ref, rel=1e-7 if real is np.float64
-                                  else 1e-4)
+                                  else 1e-3)
     assert f_hip == pytest.approx(f_ref, rel=1e-6 if real is np.float64
                                   else 1e-3)
     # the HIP run's optimum through the oracle's eyes

@@ -1237,7 +1237,9 @@ def test_full_size_gram_matrix_properties(real, ftol):
     d = k.diag(G)
     assert np.allclose(np.diag(K), d, rtol=1e-6 if real is np.float32 else 1e-12)
     Kn = K / np.sqrt(np.outer(d, d))
-    assert Kn.max() <= 1 + (2e-6 if real is np.float32 else 1e-9)
+    # (Cauchy-Schwarz to what the stopping rule leaves of it)
+    assert Kn.max() <= 1 + (2e-6 if real is np.float32 else
+                            (1e-7 if ftol > 1e-12 else 1e-9))
     w = np.linalg.eigvalsh(Kn.astype(np.float64))
     assert w.min() > -(1e-4 if real is np.float32 else 1e-7) * w.max()
     ii, jj = np.triu_indices(1000)
@@ -1615,8 +1617,16 @@ def test_mixed_degree_structures_all_pairs(real):
     it = backend.iterations(backend.last_plan)
     val, it_ref = batch.run(i, j, q=q, tol=k.ftol,
                             real='f32' if real is np.float32 else 'f64')
-    assert np.allclose(Kv[i, j], val, rtol=2e-5 if real is np.float32 else 1e-9)
+    # (both sides stop at sqrt(rTr) < 1e-8 N: they agree to what that rule
+    # leaves -- the double solver's scalars alpha / beta are float-rounded,
+    # mgk_oc.h FSCAL, so its iterates are not the restatement's bit for bit)
+    assert np.allclose(Kv[i, j], val, rtol=2e-5 if real is np.float32 else 2e-7)
     if real is np.float64:
-        # same arithmetic, same rule: counts agree up to the last-bit cases
+        # same rule: the iteration counts agree up to the borderline cases
         assert len(it) == len(it_ref)
         assert abs(int(it.sum()) - int(it_ref.sum())) <= 0.02 * it_ref.sum()
+        # converged, the double solver meets the fp64 parity bar
+        kc = MarginalizedGraphKernel(knode, kedge, q=q, ftol=1e-13,
+                                     backend=backend)
+        conv, _ = batch.run(i, j, q=q, tol=1e-13, real='f64')
+        assert np.allclose(kc(graphs)[i, j], conv, rtol=1e-9)
