@@ -251,6 +251,34 @@ struct oc_solver {
     using node_t = typename Graph::node_t;
     using edge_t = typename Graph::edge_t;
     constexpr static int T = 64 * W;            // threads per pair (= per workgroup)
+#ifndef GD_FLY_DENSE
+#define GD_FLY_DENSE 1
+#endif
+    // DENSE (on-the-fly variants, weighted graphs, direct microkernel
+    // evaluation): from_ase-like molecular graphs are 88 % dense, and a pair
+    // whose adjacency matrices are more than ~60 % full is cheaper as a DENSE
+    // product.  Both graphs' edge records are scattered once per pair into
+    // dense n x n arrays in LDS -- weight 0 where there is no edge, graph 2's
+    // TRANSPOSED -- and the owner of row (i1, i2) runs j1 over 0..n1, j2 over
+    // 0..n2: no row pointers, no column indices, every lane of the workgroup
+    // reads the SAME element p[j1, j2] at the same time (one LDS broadcast
+    // instead of a random gather), consecutive lanes (consecutive i2) read
+    // consecutive records E2T[j2][i2] (the CSR walk had the lanes of a wave
+    // read the records of THEIR rows at one offset: 59 % of the LDS cycles
+    // were bank conflicts), and graph 1's record is loaded once per j1.
+    // ~9 issue slots per term against ~23, for (n1 n2) / (d1 d2) ~ 1.3 times
+    // the terms.  Decided per pair (wave-uniform) from the four counts in the
+    // graph headers.
+    // Measured on the dense molecular set (scripts/sessions/r4_session10.sh):
+    // float values 4.98 -> 5.51 M pairs/s -- 12 vector instructions per term
+    // against 19, for 1.3 x the terms; the exponential and its argument (5
+    // issue slots) are in both.  Float value + gradient -4 %, double -20 %
+    // (the double exponential dominates either way, and the dense form has
+    // more of them): on for float graph-level value solves only (nodal
+    // solves feed finite differences, whose two sides should sum in one
+    // order).  GD_FLY_DENSE=2: all.
+    constexpr static bool DENSE = FLY && !TAB && GD_WEIGHTED && edge_weight<edge_t>::value &&
+                                  (GD_FLY_DENSE == 2 || (GD_FLY_DENSE == 1 && sizeof(real) == 4 && C == 1 && !NODAL && !NGRAD && !MAXIMIN));
     constexpr static int NR = R * T;            // row capacity
     constexpr static int NC = DMAX + 1;         // degree classes 0..DMAX
     constexpr static int NCP = NC * NC;         // degree-pair rectangles
@@ -561,6 +589,35 @@ struct oc_solver {
             std::uint16_t const *const lrp1 = g1.rowptr;
             std::uint16_t const *const lrp2 = g2.rowptr;
             job_sync<W>();
+
+            // DENSE: does this pair take the dense product?  Dense costs
+            // ~9 issue slots for each of (n1 n2)^2 terms, the CSR walk ~23 for
+            // each of nnz1 nnz2 N / N ... i.e. per row n1 n2 against d1 d2 terms
+            [[maybe_unused]] bool dense_pair = false;
+            [[maybe_unused]] edge_t *dE1 = nullptr, *dE2T = nullptr;
+            if constexpr (DENSE) {
+                const unsigned nn1 = (unsigned)n1 * (unsigned)n1, nn2 = (unsigned)n2 * (unsigned)n2;
+                dense_pair = (prm.flags & F_DENSE) && 23u * (unsigned)h1.n_nz * (unsigned)h2.n_nz > 9u * nn1 * nn2;
+                dE1 = reinterpret_cast<edge_t *>(lG2 + prm.g_capacity);
+                dE2T = dE1 + ((nn1 * (unsigned)sizeof(edge_t) + 15u) / 16u * 16u) / (unsigned)sizeof(edge_t);
+                if (dense_pair) {
+                    // (16-byte units: sizeof(edge_t) divides 16 or the pad
+                    // rounds up -- zero-fill by whole records instead)
+                    const edge_t zero{};
+                    for (unsigned k = tid; k < nn1; k += T) dE1[k] = zero;
+                    for (unsigned k = tid; k < nn2; k += T) dE2T[k] = zero;
+                    job_sync<W>();
+                    for (unsigned e = tid; e < (unsigned)h1.n_nz; e += T) {
+                        const nz_t z = at32(g1.nz, e);
+                        dE1[(unsigned)z.i * (unsigned)n1 + z.j] = at32(g1.edge, e);
+                    }
+                    for (unsigned e = tid; e < (unsigned)h2.n_nz; e += T) {
+                        const nz_t z = at32(g2.nz, e);
+                        dE2T[(unsigned)z.j * (unsigned)n2 + z.i] = at32(g2.edge, e);   // transposed
+                    }
+                    job_sync<W>();
+                }
+            }
 
             GD_MARK(rectangles);
             // ---- degree histograms -> offsets of the degree-pair rectangles ---
@@ -880,6 +937,57 @@ struct oc_solver {
             // off-diagonal sum of row batch k for right-hand side c over the
             // vector published in lp
             [[maybe_unused]] auto fly_matvec = [&](auto const &ek, real (&ysum)[CW][(STATIC || FLY) ? R : 1]) {
+                if constexpr (DENSE) if (dense_pair) {      // (workgroup-uniform)
+#pragma unroll
+                    for (int k = 0; k < R; ++k) {
+                        const unsigned rm = rowid[k];
+                        const bool live = rm != ~0u;
+                        const unsigned i1 = live ? rm >> 16 : 0u, i2 = live ? rm & 0xFFFFu : 0u;
+                        edge_t const *const e1row = dE1 + i1 * (unsigned)n1;
+                        edge_t const *const e2col = dE2T + i2;
+                        real acc[CW];
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) acc[c] = 0;
+                        const unsigned jlast = (unsigned)n2 - 1u;
+                        for (unsigned j1 = 0; j1 < (unsigned)n1; ++j1) {
+                            const edge_t e1 = e1row[j1];
+                            const unsigned rowp = lp_off + __umul24(j1, (unsigned)ldp) * ELEM;
+                            real part[CW][FLY_U];
+#pragma unroll
+                            for (int c = 0; c < CW; ++c)
+#pragma unroll
+                                for (int u = 0; u < FLY_U; ++u) part[c][u] = 0;
+                            for (unsigned j2 = 0; j2 < (unsigned)n2; j2 += FLY_U) {
+                                real e[FLY_U], pv[CW][FLY_U];
+#pragma unroll
+                                for (int u = 0; u < FLY_U; ++u) {
+                                    const unsigned jj = j2 + u < (unsigned)n2 ? j2 + u : jlast;
+                                    e[u] = real(ek(e1, e2col[jj * (unsigned)n2]));
+                                    real pe[CW];
+                                    load_elem_at<CW>(rowp + jj * ELEM, pe);   // the same address in every lane
+#pragma unroll
+                                    for (int c = 0; c < CW; ++c) pv[c][u] = pe[c];
+                                }
+#pragma unroll
+                                for (int u = 0; u < FLY_U; ++u) {
+                                    const real eu = (j2 + u < (unsigned)n2) ? e[u] : real(0);
+#pragma unroll
+                                    for (int c = 0; c < CW; ++c) part[c][u] += eu * pv[c][u];
+                                }
+                            }
+#pragma unroll
+                            for (int c = 0; c < CW; ++c) {
+                                real psum = 0;
+#pragma unroll
+                                for (int u = 0; u < FLY_U; ++u) psum += part[c][u];
+                                acc[c] += psum;
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < CW; ++c) ysum[c][k] = live ? acc[c] : real(0);
+                    }
+                    return;
+                }
                 if constexpr (FLY) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {

@@ -56,6 +56,7 @@ enum : unsigned {
     F_BLOCK = 16u,     // diag(nodal='block'): n x n block per graph
     F_PACKED = 32u,    // graph-level: out[job id] instead of K(I1, I2)
     F_REFCOMPAT = 64u, // maximin gradient: k12 of the last perturbed solve (mgk_oc.h)
+    F_DENSE = 128u,    // on-the-fly launches: LDS holds room for the dense edge arrays (mgk_oc.h DENSE)
 };
 
 struct job_t {

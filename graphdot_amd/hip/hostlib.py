@@ -249,3 +249,75 @@ def assemble_arena(blob, blob_off, starts, cbytes, n_node, n_nz, ncls, ecls,
         None if ncls is None else _p(_c(ncls, np.uint8)),
         None if ecls is None else _p(_c(ecls, np.uint8)),
         _p(host), host.nbytes), 'gdh_assemble_arena')
+
+
+# --------------------------------------------------------------------------
+# CPython helper: the attribute tables of a list of graphs as flat columns
+# --------------------------------------------------------------------------
+_collect = None
+
+
+def collector():
+    """The `_gdcollect` extension module (csrc/gdcollect.cpp, built with g++
+    against this interpreter's headers on first use), or False when it cannot
+    be built -- no Python.h on the machine: `pack_many` then gathers the
+    tables in Python, the path the tests hold the native one to."""
+    global _collect
+    if _collect is None:
+        with _lock:
+            if _collect is None:
+                _collect = _build_collector()
+    return _collect
+
+
+def _build_collector():
+    import importlib.machinery
+    import importlib.util
+    import sysconfig
+    if os.environ.get('GD_NATIVE_COLLECT', '1') == '0':
+        return False
+    src = os.path.join(CSRC, 'gdcollect.cpp')
+    suffix = sysconfig.get_config_var('EXT_SUFFIX') or '.so'
+    out = os.path.join(CSRC, '_gdcollect' + suffix)
+    inc = sysconfig.get_paths().get('include')
+    try:
+        if not (os.path.exists(out)
+                and os.path.getmtime(out) >= os.path.getmtime(src)):
+            if not inc or not os.path.exists(os.path.join(inc, 'Python.h')):
+                return False
+            tmp = out + f'.{os.getpid()}.tmp'
+            r = subprocess.run(
+                [os.environ.get('CXX', 'g++'), '-O2', '-fPIC', '-shared',
+                 '-std=c++17', f'-I{inc}', src, '-o', tmp],
+                capture_output=True, text=True)
+            if r.returncode != 0:
+                return False
+            os.replace(tmp, out)
+        spec = importlib.util.spec_from_file_location(
+            '_gdcollect', out,
+            loader=importlib.machinery.ExtensionFileLoader('_gdcollect', out))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    except Exception:
+        return False
+
+
+def collect_columns(graphs, attr, keys, dtypes):
+    """{key: column of all graphs back to back}, rows per graph (int64) --
+    or None if the tables are not uniform (or there is no extension).
+    `dtypes`: {key: numpy dtype of the first graph's column}."""
+    mod = collector()
+    if not mod:
+        return None
+    res = mod.collect(graphs, attr, tuple(keys))
+    if res is None:
+        return None
+    cols, lengths, formats = res
+    out = {}
+    for k, raw, (_, isz) in zip(keys, cols, formats):
+        dt = np.dtype(dtypes[k])
+        if dt.itemsize != isz or dt.hasobject:
+            return None
+        out[k] = np.frombuffer(raw, dtype=dt)
+    return out, np.frombuffer(lengths, dtype=np.int64)

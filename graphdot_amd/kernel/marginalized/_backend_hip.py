@@ -30,8 +30,8 @@ from ._devicegraph import (DeviceGraph, GraphArena, HIST_BINS, class_bytes,
 _TEMPLATE = os.path.join(os.path.dirname(__file__), 'template.hip')
 
 # solver flags, mirror graphdot::mgk::F_* (mgk_solver.h)
-F_NODAL, F_DIAGONAL, F_SYMMETRIC, F_LMIN1, F_BLOCK, F_PACKED, F_REFCOMPAT = \
-    1, 2, 4, 8, 16, 32, 64
+F_NODAL, F_DIAGONAL, F_SYMMETRIC, F_LMIN1, F_BLOCK, F_PACKED, F_REFCOMPAT, \
+    F_DENSE = 1, 2, 4, 8, 16, 32, 64, 128
 
 Variant = namedtuple('Variant', 'W S R')
 #: owner-computes solver (csrc/device/mgk_oc.h): S nonzero slots and R rows
@@ -490,7 +490,7 @@ class HIPBackend(Backend):
 
     # -- graphs ---------------------------------------------------------------
     def _register_graph(self, graph):
-        key = (self.uuid, np.dtype(self.real).str)
+        key = (self.uuid.int, np.dtype(self.real).str)   # (an int hashes in C)
         if key not in graph.cookie:
             graph.cookie[key] = DeviceGraph(graph, real=self.real)
         return graph.cookie[key]
@@ -933,6 +933,14 @@ void ${name}(params_t prm) {
         return mod
 
     # -- job partitioning ---------------------------------------------------------
+    @staticmethod
+    def _dense_bytes(dgraphs):
+        """LDS bytes of one dense n x n array of edge records (mgk_oc.h
+        DENSE), for the largest graph of the list, 16-byte padded."""
+        n = int(graph_features(dgraphs)['n_node'].max()) if len(dgraphs) else 0
+        return -(-(n * n * max(np.dtype(dgraphs[0].edge_t).itemsize, 1))
+                 // 16) * 16 if n else 0
+
     def lds_bytes(self, v, C, ntask=0, gbytes=0, tab_bytes=0):
         """LDS bytes of one workgroup: static p + scratch, dynamic U, the two
         staged graph images per pair slot and the microkernel tables."""
@@ -1302,7 +1310,7 @@ void ${name}(params_t prm) {
             graphs = list(graphs)
         ckey, dgraphs = self._dgraph_lists.get(graphs)
         if dgraphs is None:
-            key = (self.uuid, np.dtype(self.real).str)
+            key = (self.uuid.int, np.dtype(self.real).str)   # (an int hashes in C)
             new = [g for g in graphs if key not in g.cookie]
             if new:
                 for g, dg in zip(new, pack_many(new, real=self.real,
@@ -1439,11 +1447,21 @@ void ${name}(params_t prm) {
                 NR = 64 * v.W * v.R
                 dyn = (pcap + (0 if ((v.L and C != 2) or v.S == 0)
                                else NR)) * C * rsize + 4 * NR + 2 * gcap
+                dense = False
+                if v.S == 0:
+                    # on-the-fly variants: the dense n x n edge-record arrays
+                    # of both graphs (mgk_oc.h DENSE), sized for the largest
+                    # graph of the call -- when they fit (F_DENSE tells the
+                    # kernel that they are there)
+                    extra = 2 * self._dense_bytes(dgraphs)
+                    if extra and dyn + extra + 4096 <= LDS_LIMIT:
+                        dyn += extra
+                        dense = True
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=pcap, gcap=gcap,
                     dynamic_lds=dyn, count=count,
                     grid=int(max(1, -(-count // self.jobs_per_unit))),
-                    threads=64 * v.W, tab=gtab))
+                    threads=64 * v.W, tab=gtab, dense=dense))
                 cursor += count
                 continue
             wpb = WPB1 if v.W == 1 else 1
@@ -1790,6 +1808,8 @@ void ${name}(params_t prm) {
             a['n_launch_jobs'] = L['count']
             a['order_offset'] = L['offset']
             a['u_capacity'] = L['ucap']
+            if L.get('dense'):
+                a['flags'] |= F_DENSE
             if fd is not None:
                 f_ = fd.copy()
                 f_['base'] = a

@@ -410,6 +410,21 @@ def pack_many(graphs, real=np.float32, native=True):
     rt0 = graphs[0].cookie.get('rowtypes') if hasattr(
         graphs[0].cookie, 'get') else None
 
+    # The tables of all graphs as flat columns in one native pass over the
+    # objects (hostlib.collect_columns, csrc/gdcollect.cpp: it also checks
+    # that every graph has the first one's columns and element types); any
+    # irregularity -- or no extension module -- takes the Python path below.
+    fast = None
+    if sig_n is not None and sig_e is not None:
+        f0n, f0e = graphs[0].nodes._data, graphs[0].edges._data
+        cn = hostlib.collect_columns(graphs, 'nodes', list(f0n),
+                                     {k: v.dtype for k, v in f0n.items()})
+        ce = cn and hostlib.collect_columns(
+            graphs, 'edges', list(f0e), {k: v.dtype for k, v in f0e.items()})
+        if cn and ce and int(cn[1].max(initial=0)) <= 0xFFFF \
+                and 2 * int(ce[1].max(initial=0)) <= 0xFFFF:
+            fast = (cn, ce)
+
     def same(g):
         rt = g.cookie.get('rowtypes') if rt0 is not None else None
         if rt is not None:
@@ -417,10 +432,11 @@ def pack_many(graphs, real=np.float32, native=True):
                 (rt[1] is rt0[1] or rt[1] == rt0[1])
         return _scalar_frame(g.nodes) == sig_n and \
             _scalar_frame(g.edges) == sig_e
-    batch = [k for k, g in enumerate(graphs)
-             if sig_n is not None and sig_e is not None and same(g)
-             and len(g.nodes._data['!i']) <= 0xFFFF
-             and 2 * len(g.edges._data['!i']) <= 0xFFFF]
+    batch = list(range(len(graphs))) if fast else \
+        [k for k, g in enumerate(graphs)
+         if sig_n is not None and sig_e is not None and same(g)
+         and len(g.nodes._data['!i']) <= 0xFFFF
+         and 2 * len(g.edges._data['!i']) <= 0xFFFF]
     out = [None] * len(graphs)
     for k in sorted(set(range(len(graphs))) - set(batch)):
         out[k] = DeviceGraph(graphs[k], real=real)
@@ -428,7 +444,7 @@ def pack_many(graphs, real=np.float32, native=True):
         return out
     gs = [graphs[k] for k in batch]
     G = len(gs)
-    nframes, eframes = [g.nodes for g in gs], [g.edges for g in gs]
+    nframes, eframes = [g.nodes for g in gs[:1]], [g.edges for g in gs[:1]]
 
     def columns(frames):
         """{column: the arrays of all frames} with one C-level lookup per
@@ -440,13 +456,20 @@ def pack_many(graphs, real=np.float32, native=True):
             return {keys[0]: rows}
         return dict(zip(keys, zip(*rows)))
 
-    ncols, ecols = columns(nframes), columns(eframes)
+    if fast:
+        (ncols, n), (ecols, m) = fast
 
-    def cat(frames, key):
-        return np.concatenate((ncols if frames is nframes else ecols)[key])
+        def cat(frames, key):
+            return (ncols if frames is nframes else ecols)[key]
+    else:
+        nframes, eframes = [g.nodes for g in gs], [g.edges for g in gs]
+        ncols, ecols = columns(nframes), columns(eframes)
 
-    n = np.fromiter(map(len, ncols['!i']), dtype=np.int64, count=G)
-    m = np.fromiter(map(len, ecols['!i']), dtype=np.int64, count=G)
+        def cat(frames, key):
+            return np.concatenate((ncols if frames is nframes else ecols)[key])
+
+        n = np.fromiter(map(len, ncols['!i']), dtype=np.int64, count=G)
+        m = np.fromiter(map(len, ecols['!i']), dtype=np.int64, count=G)
     node0 = np.concatenate(([0], np.cumsum(n)))
     edge0 = np.concatenate(([0], np.cumsum(m)))
     Nn, Ne = int(node0[-1]), int(edge0[-1])
