@@ -269,16 +269,22 @@ struct oc_solver {
     // ~9 issue slots per term against ~23, for (n1 n2) / (d1 d2) ~ 1.3 times
     // the terms.  Decided per pair (wave-uniform) from the four counts in the
     // graph headers.
-    // Measured on the dense molecular set (scripts/sessions/r4_session10.sh):
-    // float values 4.98 -> 5.51 M pairs/s -- 12 vector instructions per term
-    // against 19, for 1.3 x the terms; the exponential and its argument (5
-    // issue slots) are in both.  Float value + gradient -4 %, double -20 %
-    // (the double exponential dominates either way, and the dense form has
-    // more of them): on for float graph-level value solves only (nodal
-    // solves feed finite differences, whose two sides should sum in one
-    // order).  GD_FLY_DENSE=2: all.
-    constexpr static bool DENSE = FLY && !TAB && GD_WEIGHTED && edge_weight<edge_t>::value &&
-                                  (GD_FLY_DENSE == 2 || (GD_FLY_DENSE == 1 && sizeof(real) == 4 && C == 1 && !NODAL && !NGRAD && !MAXIMIN));
+    // Measured on the dense molecular set (scripts/sessions/r4_session10.sh,
+    // r4_session12.sh): float values 4.98 -> 6.31 M pairs/s, float value +
+    // gradient 3.55 -> 3.93 M; 8 vector instructions per term against 19 for
+    // 1.3 x the terms, bank conflicts 59 % -> 2 % of the LDS cycles, and the
+    // vector pipe saturated (VALU busy 101-107 %): what is left per term is
+    // the exponential and its argument (sub, mul, mul, mul, v_exp_f32).  A
+    // first layout -- records in blocks of four columns per lane, for
+    // ds_read_b128 -- put sixteen lanes on one bank (62 % conflict cycles,
+    // 3.4 M pairs/s).  In double the software exponential dominates either
+    // way and the dense form has 1.3 x as many: 1.81 against 2.26 M pairs/s,
+    // off.  Nodal solves (they feed finite differences, whose two sides
+    // should sum in one order) keep the CSR walk.  GD_FLY_DENSE=2: all.
+    constexpr static unsigned EW = sizeof(edge_t) / 4u;      // words per edge record
+    constexpr static unsigned DSTRIDE = 32u;                 // words per row of the dense planes
+    constexpr static bool DENSE = FLY && !TAB && GD_WEIGHTED && edge_weight<edge_t>::value && sizeof(edge_t) % 4 == 0 &&
+                                  (GD_FLY_DENSE == 2 || (GD_FLY_DENSE == 1 && sizeof(real) == 4 && !NODAL && !NGRAD && !MAXIMIN));
     constexpr static int NR = R * T;            // row capacity
     constexpr static int NC = DMAX + 1;         // degree classes 0..DMAX
     constexpr static int NCP = NC * NC;         // degree-pair rectangles
@@ -596,16 +602,27 @@ struct oc_solver {
             [[maybe_unused]] bool dense_pair = false;
             [[maybe_unused]] edge_t *dE1 = nullptr, *dE2T = nullptr;
             if constexpr (DENSE) {
-                const unsigned nn1 = (unsigned)n1 * (unsigned)n1, nn2 = (unsigned)n2 * (unsigned)n2;
-                dense_pair = (prm.flags & F_DENSE) && 23u * (unsigned)h1.n_nz * (unsigned)h2.n_nz > 9u * nn1 * nn2;
+                // graph 2's array as dword planes, E2T[word d of the record][j2][i2]
+                // with rows of DSTRIDE words (hosts sets F_DENSE for graphs of at
+                // most DSTRIDE nodes): the lanes of a wave -- consecutive i2 --
+                // read consecutive words (no bank conflicts: blocks of four
+                // 8-byte records per lane put 16 lanes on one bank and ran at
+                // 62 % conflict cycles, 3.4 M pairs/s), and the words of the
+                // four columns of a trip sit at compile-time offsets from one
+                // running address
+                const unsigned n2p = ((unsigned)n2 + 3u) & ~3u;   // rows per plane: whole trips of four, the padding rows zero
+                const unsigned nn1 = (unsigned)n1 * (unsigned)n1, nn2 = EW * n2p * DSTRIDE;
+                dense_pair = (prm.flags & F_DENSE) && n2 <= (int)DSTRIDE &&
+                             23u * (unsigned)h1.n_nz * (unsigned)h2.n_nz > 9u * nn1 * (unsigned)n2 * (unsigned)n2;
                 dE1 = reinterpret_cast<edge_t *>(lG2 + prm.g_capacity);
-                dE2T = dE1 + ((nn1 * (unsigned)sizeof(edge_t) + 15u) / 16u * 16u) / (unsigned)sizeof(edge_t);
+                dE2T = reinterpret_cast<edge_t *>(reinterpret_cast<char *>(dE1) + (nn1 * (unsigned)sizeof(edge_t) + 15u) / 16u * 16u);
                 if (dense_pair) {
                     // (16-byte units: sizeof(edge_t) divides 16 or the pad
                     // rounds up -- zero-fill by whole records instead)
                     const edge_t zero{};
+                    unsigned *const planes = reinterpret_cast<unsigned *>(dE2T);
                     for (unsigned k = tid; k < nn1; k += T) dE1[k] = zero;
-                    for (unsigned k = tid; k < nn2; k += T) dE2T[k] = zero;
+                    for (unsigned k = tid; k < nn2; k += T) planes[k] = 0u;
                     job_sync<W>();
                     for (unsigned e = tid; e < (unsigned)h1.n_nz; e += T) {
                         const nz_t z = at32(g1.nz, e);
@@ -613,7 +630,12 @@ struct oc_solver {
                     }
                     for (unsigned e = tid; e < (unsigned)h2.n_nz; e += T) {
                         const nz_t z = at32(g2.nz, e);
-                        dE2T[(unsigned)z.j * (unsigned)n2 + z.i] = at32(g2.edge, e);   // transposed
+                        const edge_t rec = at32(g2.edge, e);
+                        unsigned words[EW];
+                        __builtin_memcpy(words, &rec, sizeof(edge_t));
+#pragma unroll
+                        for (unsigned d = 0; d < EW; ++d)
+                            planes[(d * n2p + z.j) * DSTRIDE + z.i] = words[d];
                     }
                     job_sync<W>();
                 }
@@ -938,50 +960,54 @@ struct oc_solver {
             // vector published in lp
             [[maybe_unused]] auto fly_matvec = [&](auto const &ek, real (&ysum)[CW][(STATIC || FLY) ? R : 1]) {
                 if constexpr (DENSE) if (dense_pair) {      // (workgroup-uniform)
+                    static_assert(FLY_U == 4, "the dense product walks blocks of four columns");
+                    const unsigned jlast = (unsigned)n2 - 1u, n2p_ = ((unsigned)n2 + 3u) & ~3u;
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         const unsigned rm = rowid[k];
                         const bool live = rm != ~0u;
                         const unsigned i1 = live ? rm >> 16 : 0u, i2 = live ? rm & 0xFFFFu : 0u;
                         edge_t const *const e1row = dE1 + i1 * (unsigned)n1;
-                        edge_t const *const e2col = dE2T + i2;
+                        unsigned const *const e2lane = reinterpret_cast<unsigned const *>(dE2T) + i2;
                         real acc[CW];
 #pragma unroll
                         for (int c = 0; c < CW; ++c) acc[c] = 0;
-                        const unsigned jlast = (unsigned)n2 - 1u;
                         for (unsigned j1 = 0; j1 < (unsigned)n1; ++j1) {
                             const edge_t e1 = e1row[j1];
                             const unsigned rowp = lp_off + __umul24(j1, (unsigned)ldp) * ELEM;
-                            real part[CW][FLY_U];
+                            real part[CW][4];
 #pragma unroll
                             for (int c = 0; c < CW; ++c)
 #pragma unroll
-                                for (int u = 0; u < FLY_U; ++u) part[c][u] = 0;
-                            for (unsigned j2 = 0; j2 < (unsigned)n2; j2 += FLY_U) {
-                                real e[FLY_U], pv[CW][FLY_U];
+                                for (int u = 0; u < 4; ++u) part[c][u] = 0;
+                            for (unsigned j2 = 0; j2 < (unsigned)n2; j2 += 4) {
+                                // (j2 is uniform: the block address and the clamped
+                                // columns of p are scalar arithmetic)
+                                unsigned const *const col = e2lane + j2 * DSTRIDE;
+                                edge_t e2[4];
 #pragma unroll
-                                for (int u = 0; u < FLY_U; ++u) {
+                                for (int u = 0; u < 4; ++u) {
+                                    // (columns beyond n2 - 1 of the last trip: zero rows,
+                                    // weight 0)
+                                    unsigned words[EW];
+#pragma unroll
+                                    for (unsigned d = 0; d < EW; ++d) words[d] = col[d * n2p_ * DSTRIDE + u * DSTRIDE];
+                                    __builtin_memcpy(&e2[u], words, sizeof(edge_t));
+                                }
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    // p beyond the row end is not read (its records are
+                                    // zero, but the cells behind p are not numbers)
                                     const unsigned jj = j2 + u < (unsigned)n2 ? j2 + u : jlast;
-                                    e[u] = real(ek(e1, e2col[jj * (unsigned)n2]));
                                     real pe[CW];
                                     load_elem_at<CW>(rowp + jj * ELEM, pe);   // the same address in every lane
+                                    const real e = real(ek(e1, e2[u]));
 #pragma unroll
-                                    for (int c = 0; c < CW; ++c) pv[c][u] = pe[c];
-                                }
-#pragma unroll
-                                for (int u = 0; u < FLY_U; ++u) {
-                                    const real eu = (j2 + u < (unsigned)n2) ? e[u] : real(0);
-#pragma unroll
-                                    for (int c = 0; c < CW; ++c) part[c][u] += eu * pv[c][u];
+                                    for (int c = 0; c < CW; ++c) part[c][u] += e * pe[c];
                                 }
                             }
 #pragma unroll
-                            for (int c = 0; c < CW; ++c) {
-                                real psum = 0;
-#pragma unroll
-                                for (int u = 0; u < FLY_U; ++u) psum += part[c][u];
-                                acc[c] += psum;
-                            }
+                            for (int c = 0; c < CW; ++c) acc[c] += (part[c][0] + part[c][1]) + (part[c][2] + part[c][3]);
                         }
 #pragma unroll
                         for (int c = 0; c < CW; ++c) ysum[c][k] = live ? acc[c] : real(0);

@@ -10,6 +10,7 @@ menu of register-resident solver variants (see ``csrc/device/mgk_solver.h``).
 There is no CPU path: a missing ``libgdhip.so`` / hipcc / device raises.
 """
 import copy
+import gc
 import os
 import re
 import uuid
@@ -935,11 +936,15 @@ void ${name}(params_t prm) {
     # -- job partitioning ---------------------------------------------------------
     @staticmethod
     def _dense_bytes(dgraphs):
-        """LDS bytes of one dense n x n array of edge records (mgk_oc.h
-        DENSE), for the largest graph of the list, 16-byte padded."""
+        """LDS bytes of the two dense edge arrays of a pair (mgk_oc.h DENSE)
+        for the largest graph of the list: n x n records, and the record's
+        dword planes in rows of 32 words -- 0 if a graph has more than 32
+        nodes (the kernel's row stride) or the records are not whole words."""
         n = int(graph_features(dgraphs)['n_node'].max()) if len(dgraphs) else 0
-        return -(-(n * n * max(np.dtype(dgraphs[0].edge_t).itemsize, 1))
-                 // 16) * 16 if n else 0
+        esize = np.dtype(dgraphs[0].edge_t).itemsize if len(dgraphs) else 0
+        if not 0 < n <= 32 or esize == 0 or esize % 4:
+            return 0
+        return -(-(n * n * esize) // 16) * 16 + esize * (n + 3) * 32 + 256
 
     def lds_bytes(self, v, C, ntask=0, gbytes=0, tab_bytes=0):
         """LDS bytes of one workgroup: static p + scratch, dynamic U, the two
@@ -1453,7 +1458,7 @@ void ${name}(params_t prm) {
                     # of both graphs (mgk_oc.h DENSE), sized for the largest
                     # graph of the call -- when they fit (F_DENSE tells the
                     # kernel that they are there)
-                    extra = 2 * self._dense_bytes(dgraphs)
+                    extra = self._dense_bytes(dgraphs)
                     if extra and dyn + extra + 4096 <= LDS_LIMIT:
                         dyn += extra
                         dense = True
@@ -2067,10 +2072,21 @@ void ${name}(params_t prm) {
             # (template.cu:226,422: neither branch is compiled for 'block')
             traits = traits._replace(eval_gradient=False)
             gradient = None
-        plan = self.prepare(graphs, node_kernel, edge_kernel, p, q, eps, ftol,
-                            gtol, jobs, starts, nX, nY, nJ, traits, timer)
-        timer.tic('GPU kernel execution')
-        self.launch(plan)
-        runtime.synchronize()
-        timer.toc('GPU kernel execution')
-        self.collect(plan, gramian, gradient)
+        # (the host side of a first call makes a few thousand small objects --
+        # packed-graph handles, cookies -- none of them part of a cycle: the
+        # cyclic collector, which would walk the caller's whole heap of graphs
+        # for ~8 ms if its threshold fell inside, waits until the call is over)
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            plan = self.prepare(graphs, node_kernel, edge_kernel, p, q, eps,
+                                ftol, gtol, jobs, starts, nX, nY, nJ, traits,
+                                timer)
+            timer.tic('GPU kernel execution')
+            self.launch(plan)
+            runtime.synchronize()
+            timer.toc('GPU kernel execution')
+            self.collect(plan, gramian, gradient)
+        finally:
+            if gc_was_on:
+                gc.enable()
