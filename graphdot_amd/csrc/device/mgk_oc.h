@@ -972,6 +972,12 @@ struct oc_solver {
                         real acc[CW];
 #pragma unroll
                         for (int c = 0; c < CW; ++c) acc[c] = 0;
+                        // (rows are dealt in natural order: a wave whose 64 rows of
+                        // this batch all lie beyond N has nothing to sum -- the CSR
+                        // walk gives dead rows zero trips, the dense loops are
+                        // uniform and would run in full)
+                        const bool wave_live = row_pos(k, wv, 0) < N;
+                        if (wave_live)
                         for (unsigned j1 = 0; j1 < (unsigned)n1; ++j1) {
                             const edge_t e1 = e1row[j1];
                             const unsigned rowp = lp_off + __umul24(j1, (unsigned)ldp) * ELEM;
