@@ -445,6 +445,7 @@ class HIPBackend(Backend):
         if self.native:
             from ...hip import hostlib
             hostlib.lib()                  # fail loudly if it cannot be built
+            hostlib.collector()            # (optional helper: loaded here, not in the first call)
         if self.occupancy is None and os.environ.get('GD_OCCUPANCY'):
             # e.g. GD_OCCUPANCY="1:16:5,1:24:4"  (W:S:waves)
             self.occupancy = {
