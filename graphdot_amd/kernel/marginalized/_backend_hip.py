@@ -222,6 +222,15 @@ class ClassPairs:
         return self.count[self.upk].astype(np.int64)
 
 
+class Partition(tuple):
+    """Result of `HIPBackend._partition`: (jobs, used, order_all, launches)
+    as a tuple, plus `.jobs_sorted` -- the job records in launch order when
+    the native ordering wrote them (else None) -- and `.merge_map`, the
+    launch merging that was applied ({variant index: variant index})."""
+    jobs_sorted = None
+    merge_map = {}
+
+
 class NotOwnerComputes(Exception):
     """Some pair of the call does not fit an owner-computes solver variant
     (raised when a feature only those solvers have was asked for)."""
@@ -754,12 +763,12 @@ struct ${name}_t : ${name}_theta_t {
     #: (float (28, 5) at 5 waves is 2 % faster than at 4 but writes 2 KB of
     #: scratch per pair to HBM, profiles/r02_f32_pmc.csv: not taken)
     _OC_WAVES = {
-        (False, 1): {(16,): 6, (16, 4): 6, (16, 4, 1): 5, (16, 4, 4): 5,
-                     (16, 4, 4, 1): 3, (16, 4, 4, 1, 1): 3,
-                     (16, 4, 4, 3, 1): 4, (16, 4, 4, 3, 1, 1): 4,
-                     (16, 4, 4, 4, 1, 1, 1): 3,
-                     (16, 4, 4, 4, 3, 1, 1, 1): 3,
-                     (16, 4, 4, 4, 4, 1, 1, 1, 1): 3,
+        (False, 1): {('L', 16): 6, ('L', 16, 4): 6, ('L', 16, 4, 1): 5, ('L', 16, 4, 4): 5,
+                     ('L', 16, 4, 4, 1): 3, ('L', 16, 4, 4, 1, 1): 3,
+                     ('L', 16, 4, 4, 3, 1): 4, ('L', 16, 4, 4, 3, 1, 1): 4,
+                     ('L', 16, 4, 4, 4, 1, 1, 1): 3,
+                     ('L', 16, 4, 4, 4, 3, 1, 1, 1): 3,
+                     ('L', 16, 4, 4, 4, 4, 1, 1, 1, 1): 3,
                      (1, 12, 2, 4): 6, (1, 16, 3, 4): 6, (1, 20, 3, 4): 6,
                      (1, 20, 4, 4): 4, (1, 24, 4, 4): 5, (1, 28, 5, 4): 4,
                      (1, 28, 6, 4): 4, (1, 32, 7, 4): 4, (1, 36, 9, 4): 2,
@@ -768,35 +777,35 @@ struct ${name}_t : ${name}_theta_t {
                      (4, 64, 5, 8): 3, (8, 40, 2, 8): 4, (8, 48, 3, 8): 4,
                      (8, 64, 4, 8): 4, (16, 32, 2, 8): 4, (16, 40, 2, 8): 4,
                      (16, 48, 3, 8): 4, (16, 64, 3, 8): 4},
-        (True, 1): {(16,): 4, (16, 4): 4, (16, 4, 1): 3, (16, 4, 4): 3,
-                    (16, 4, 4, 1): 3, (16, 4, 4, 1, 1): 2,
-                    (16, 4, 4, 3, 1): 2, (16, 4, 4, 3, 1, 1): 2,
-                    (16, 4, 4, 4, 1, 1, 1): 2,
-                    (16, 4, 4, 4, 3, 1, 1, 1): 2,
-                    (16, 4, 4, 4, 4, 1, 1, 1, 1): 2,
+        (True, 1): {('L', 16): 4, ('L', 16, 4): 4, ('L', 16, 4, 1): 3, ('L', 16, 4, 4): 3,
+                    ('L', 16, 4, 4, 1): 3, ('L', 16, 4, 4, 1, 1): 2,
+                    ('L', 16, 4, 4, 3, 1): 2, ('L', 16, 4, 4, 3, 1, 1): 2,
+                    ('L', 16, 4, 4, 4, 1, 1, 1): 2,
+                    ('L', 16, 4, 4, 4, 3, 1, 1, 1): 2,
+                    ('L', 16, 4, 4, 4, 4, 1, 1, 1, 1): 2,
                     (1, 12, 2, 4): 4, (1, 16, 3, 4): 4, (1, 20, 3, 4): 4,
                     (1, 20, 4, 4): 3, (1, 24, 4, 4): 3, (1, 28, 5, 4): 3,
                     (1, 28, 6, 4): 3, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2,
                     (1, 64, 9, 8): 1, (4, 32, 3, 8): 3, (4, 40, 2, 8): 3,
                     (4, 64, 5, 8): 2, (8, 40, 2, 8): 2, (8, 64, 4, 8): 2},
-        (False, 2): {(16,): 4, (16, 4): 4, (16, 4, 1): 4, (16, 4, 4): 2,
-                     (16, 4, 4, 1): 2, (16, 4, 4, 1, 1): 3,
-                     (16, 4, 4, 3, 1): 3, (16, 4, 4, 3, 1, 1): 3,
-                     (16, 4, 4, 4, 1, 1, 1): 2,
-                     (16, 4, 4, 4, 3, 1, 1, 1): 2,
-                     (16, 4, 4, 4, 4, 1, 1, 1, 1): 2,
+        (False, 2): {('L', 16): 4, ('L', 16, 4): 4, ('L', 16, 4, 1): 4, ('L', 16, 4, 4): 2,
+                     ('L', 16, 4, 4, 1): 2, ('L', 16, 4, 4, 1, 1): 3,
+                     ('L', 16, 4, 4, 3, 1): 3, ('L', 16, 4, 4, 3, 1, 1): 3,
+                     ('L', 16, 4, 4, 4, 1, 1, 1): 2,
+                     ('L', 16, 4, 4, 4, 3, 1, 1, 1): 2,
+                     ('L', 16, 4, 4, 4, 4, 1, 1, 1, 1): 2,
                      (1, 12, 2, 4): 4, (1, 16, 3, 4): 4, (1, 20, 3, 4): 3,
                      (1, 20, 4, 4): 2, (1, 24, 4, 4): 3, (1, 28, 5, 4): 3,
                      (1, 28, 6, 4): 2, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2},
         # (static layouts: the sequential solves of mgk_oc.h SEQ, round 4 --
         # scripts/sessions/r4_session2.sh / r4_session4.sh: three waves only
         # where the loop stays free of scratch reloads, the three-batch kernel)
-        (True, 2): {(16,): 2, (16, 4): 2, (16, 4, 1): 3, (16, 4, 4): 2,
-                    (16, 4, 4, 1): 2, (16, 4, 4, 1, 1): 2,
-                    (16, 4, 4, 3, 1): 2, (16, 4, 4, 3, 1, 1): 2,
-                    (16, 4, 4, 4, 1, 1, 1): 2,
-                    (16, 4, 4, 4, 3, 1, 1, 1): 2,
-                    (16, 4, 4, 4, 4, 1, 1, 1, 1): 1,
+        (True, 2): {('L', 16): 2, ('L', 16, 4): 2, ('L', 16, 4, 1): 3, ('L', 16, 4, 4): 2,
+                    ('L', 16, 4, 4, 1): 2, ('L', 16, 4, 4, 1, 1): 2,
+                    ('L', 16, 4, 4, 3, 1): 2, ('L', 16, 4, 4, 3, 1, 1): 2,
+                    ('L', 16, 4, 4, 4, 1, 1, 1): 2,
+                    ('L', 16, 4, 4, 4, 3, 1, 1, 1): 2,
+                    ('L', 16, 4, 4, 4, 4, 1, 1, 1, 1): 1,
                     (1, 12, 2, 4): 3, (1, 16, 3, 4): 3, (1, 20, 3, 4): 3,
                     (1, 20, 4, 4): 2, (1, 24, 4, 4): 2, (1, 28, 5, 4): 2,
                     (1, 28, 6, 4): 2, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2},
@@ -830,8 +839,10 @@ struct ${name}_t : ${name}_theta_t {
             # on-the-fly kernels: no slot arrays, but the unrolled term loops
             # keep ~140 registers busy (spill-free at three waves per SIMD)
             return max(self._FLY_WAVES, -(-64 * v.W // 256))
+        # (static layouts under ('L',) + layout: a four-batch layout is a
+        # 4-tuple like the (W, S, R, D) of a dynamic variant)
         hit = self._OC_WAVES.get((f64, C), {}).get(
-            v.L if v.L else tuple(v)[:4])
+            ('L',) + v.L if v.L else tuple(v)[:4])
         if hit and not ngrad:
             return hit
         w = 2 if f64 else 1
@@ -1350,7 +1361,7 @@ void ${name}(params_t prm) {
         """Host half of a layout: solver variant per job, launch order (by
         variant, then descending cost) and launch geometry.  No device."""
         jobs = np.ascontiguousarray(jobs)
-        self._jobs_sorted = None       # (set by the native ordering)
+        jobs_sorted = None             # (set by the native ordering)
         sel, (choice, cost, ntask, gbytes, NP, gbytes_oc) = \
             self._classify_classes(None, None, dgraphs, C, tab_bytes, gtab,
                                    oc_only, jobs=jobs)
@@ -1366,13 +1377,13 @@ void ${name}(params_t prm) {
         # -- fewer, fuller launches, which matters most for the shards of a
         # multi-GPU run (scripts/minlaunch_experiment.sh: 8192 against 2048
         # waves: -1 % on the full matrix, -2...8 % on 1/2...1/8 of it).
-        self._last_merge_map = {}
+        applied = {}                   # launch merging of this job list
         if merge_map is not None:
             # decided elsewhere, on a larger job list this one is a shard of
             # (_sharded.ShardPlan.merge_map)
             for k, k2 in merge_map.items():
                 choice = np.where(choice == k, k2, choice)
-            self._last_merge_map = dict(merge_map)
+            applied = dict(merge_map)
         elif self.min_launch > 0:
             members_ = np.ones(len(choice), dtype=np.int64) if sel is None \
                 else sel.members
@@ -1398,10 +1409,10 @@ void ${name}(params_t prm) {
                     if True:
                         choice = np.where(here, k2, choice)
                         # (chains collapse: what rode in k now rides in k2)
-                        for k0, k1 in list(self._last_merge_map.items()):
+                        for k0, k1 in list(applied.items()):
                             if k1 == k:
-                                self._last_merge_map[k0] = k2
-                        self._last_merge_map[k] = k2
+                                applied[k0] = k2
+                        applied[k] = k2
                         break
         rank_of = np.empty(len(choice), dtype=np.int64)
         by_rank = np.lexsort((-cost, choice))
@@ -1419,7 +1430,7 @@ void ${name}(params_t prm) {
             from ...hip import hostlib
             rank_of_key = np.full(sel.nc * sel.nc, -1, dtype=np.int32)
             rank_of_key[sel.upk] = rank_of
-            order_all, self._jobs_sorted = hostlib.order_jobs(
+            order_all, jobs_sorted = hostlib.order_jobs(
                 sel.pk, rank_of_key, int(rank_of.max()) + 1, jobs)
             members = sel.members
         else:
@@ -1487,7 +1498,9 @@ void ${name}(params_t prm) {
                                  gcap=gcap, dynamic_lds=dyn, count=count,
                                  grid=grid, threads=threads))
             cursor += count
-        return jobs, used, order_all, launches
+        out = Partition((jobs, used, order_all, launches))
+        out.jobs_sorted, out.merge_map = jobs_sorted, applied
+        return out
 
     @staticmethod
     def _code_signature(node_kernel, edge_kernel, p, dgraphs, C, nodal,
@@ -1597,9 +1610,9 @@ void ${name}(params_t prm) {
         if ngrad or maximin:
             lay.tab_bytes = 0
         tic('  solver variants and launch order')
-        jobs, lay.used, lay.order_host, lay.launches = self._partition(
-            dgraphs, jobs, C, lay.tab_bytes, lay.gtab,
-            oc_only=ngrad or maximin, merge_map=merge_map)
+        part = self._partition(dgraphs, jobs, C, lay.tab_bytes, lay.gtab,
+                               oc_only=ngrad or maximin, merge_map=merge_map)
+        jobs, lay.used, lay.order_host, lay.launches = part
         toc('  solver variants and launch order')
         tic('  job list to the device')
         lay.n_jobs = len(jobs)
@@ -1607,9 +1620,8 @@ void ${name}(params_t prm) {
         lay.b_order = runtime.DeviceBuffer(max(lay.order_host.nbytes, 4))
         lay.b_starts = runtime.DeviceBuffer(max(starts.nbytes, 4))
         # jobs travel in launch order: the kernel reads jobs[t] directly
-        sorted_jobs = self._jobs_sorted if self._jobs_sorted is not None \
+        sorted_jobs = part.jobs_sorted if part.jobs_sorted is not None \
             else np.ascontiguousarray(jobs[lay.order_host])
-        self._jobs_sorted = None
         lay.b_jobs.upload(sorted_jobs.view(np.uint32))
         lay.b_order.upload(lay.order_host)
         lay.b_starts.upload(starts)

@@ -339,9 +339,9 @@ def measured_shard_plan(backend, graphs, node_kernel, edge_kernel, jobs, nX,
     tab_bytes = backend._table_bytes(arena)
     gtab = backend._global_tables(arena)
     jobs = np.ascontiguousarray(jobs)
-    _, used, order_all, launches = backend._partition(
-        dgraphs, jobs, C, tab_bytes, gtab)
-    merge_map = dict(getattr(backend, '_last_merge_map', {}))
+    part = backend._partition(dgraphs, jobs, C, tab_bytes, gtab)
+    _, used, order_all, launches = part
+    merge_map = dict(part.merge_map)
     ji, jj = jobs['i'].astype(np.int64), jobs['j'].astype(np.int64)
     n_node = np.array([g.n_node for g in dgraphs], np.int64)
     n_nz = np.array([g.n_nz for g in dgraphs], np.int64)

@@ -177,6 +177,22 @@ def test_singular_matrix_on_the_gpu_falls_back_to_pseudoinverse():
     with pytest.warns(UserWarning, match='singular'):
         Sinv, _ = la.factor(S, 1e-8)
     assert bool(torch.isfinite(Sinv).all())
+    # a bad pivot in a LATER 64-column block of a matrix whose size is not a
+    # multiple of 64: the two-column factor turns it into NaN
+    # (rsqrt of a non-positive pivot) and the NaN reaches the log-determinant
+    # through the look-ahead factorisation and the panel / trailing updates --
+    # `factor` notices and takes the pseudo-inverse
+    from graphdot_amd.model.gaussian_process._potrf import cholesky_
+    B = (A @ A.T / n + torch.eye(n, dtype=torch.float64)).to('cuda')
+    for bad in (70, 150, 199):
+        Bk = B.clone()
+        Bk[bad, bad] = -5.0
+        d = torch.diagonal(torch.tril(cholesky_(Bk.clone())))
+        assert bool(torch.isfinite(d[:bad]).all()) and bool((d[:bad] > 0).all())
+        assert not bool(torch.isfinite(d[bad:]).all())
+        with pytest.warns(UserWarning, match='singular'):
+            Binv, ld = la.factor(Bk, 1e-8)
+        assert bool(torch.isfinite(Binv).all()) and np.isfinite(ld)
     # and a well-conditioned one takes the Cholesky route silently
     P = (A @ A.T / n + torch.eye(n, dtype=torch.float64)).to('cuda')
     import warnings
