@@ -570,8 +570,8 @@ def test_measured_shard_plan_is_host_only_and_covers_every_job():
     dgs, ek, C, fields = b._graphs_and_kernels(G, kn, ke,
                                                k.traits(symmetric=True))
     arena = b._host_arena(dgs, fields)
-    b._partition(dgs, jobs, C, 0, b._global_tables(arena))
-    assert sp.merge_map == b._last_merge_map
+    whole = b._partition(dgs, jobs, C, 0, b._global_tables(arena))
+    assert sp.merge_map == whole.merge_map
     # a shard laid out with that map uses only variants the whole list uses
     _, used_all, _, _ = b._partition(dgs, jobs, C, 0,
                                      b._global_tables(arena))
