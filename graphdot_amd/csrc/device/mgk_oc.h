@@ -336,6 +336,35 @@ struct oc_solver {
                                  ((sizeof(real) == 4 ? (S >= 64 && W >= 8)
                                                      : (GD_OC_PACK != 3 && W >= 16)) || GD_OC_PACK == 2);
     constexpr static int NADR = PACK ? (S + 1) / 2 : SA;
+    // SL: the values of the LAST SL slots of a lane live in a lane-private
+    // LDS column instead of registers (round 4; dynamic multi-wave value
+    // solvers).  A workgroup of 16 waves is capped at 128 registers per lane
+    // and 40 double slots are 80 of them before addresses, rows and gathers:
+    // the allocator spilled what did not fit INTO the iteration, 1.4 GB of
+    // scratch traffic per launch of configuration 2's (16,40,2).  An LDS slot
+    // costs one conflict-free lane-contiguous read per iteration and frees
+    // one register (two in double); the workgroup's 160 KB of LDS has ~100 KB
+    // to spare beside p, the row sums, the row map and the images.  The table
+    // is mirrored by HIPBackend.lds_slot_bytes (LDS sizing and the LDS limit
+    // of the classification); -DGD_OC_SL=0 turns it off, =n sets n slots.
+    // Configuration 2 in double (scripts/sessions/r4_session17.sh), 10 slots
+    // (80 KB of a 1024-lane workgroup; 12 overflow the 160 KB with (16,64,3)):
+    // (16,40,2) 1.19 -> 0.97 ms, (16,64,3) 0.87 -> 0.74 ms, the step 4.95 ->
+    // 4.64 ms; 4 / 6 / 8 slots: 4.76 / 4.72 / 4.67 ms.
+#ifndef GD_OC_SL
+#define GD_OC_SL 1
+#endif
+    constexpr static int lds_slot_count() {
+        if (GD_OC_SL == 0 || C != 1 || NODAL || NGRAD || STATIC || FLY || W == 1) return 0;
+        // (only where the registers are short by construction: in the 4- and
+        // 8-wave variants and in float the allocator answered LDS slots with
+        // MORE scratch operations inside the loop, 4 -> 37 in the double
+        // (8,64,4), 9 -> 26 in the float (4,64,5))
+        if (sizeof(real) == 8 && W == 16 && (S == 40 || S == 64)) return GD_OC_SL == 1 ? 10 : GD_OC_SL;
+        return 0;
+    }
+    constexpr static int SL = lds_slot_count();
+    constexpr static int SREG = S - SL;          // slots whose values are registers
     // LEAN (static layouts, value + gradient): the solution x lives in a
     // lane-private LDS region and p only in its published copy -- the update
     // block re-reads p (once for A p, once for the x / p update) and
@@ -543,6 +572,8 @@ struct oc_solver {
         unsigned *const rowmap = reinterpret_cast<unsigned *>(lY + (HAS_Y ? (size_t)NR * C : (size_t)0));
         char *const lG1 = reinterpret_cast<char *>(rowmap + NR);
         char *const lG2 = lG1 + prm.g_capacity;
+        // SL: [SL][T] slot values behind the second image
+        [[maybe_unused]] creal *const lV = reinterpret_cast<creal *>(lG2 + prm.g_capacity);
         real *const red0 = lds.red[0], *const red1 = lds.red[1];
         using reduce = alternating_reduce<real, W>;
         using sreduce = alternating_reduce<sreal, W>;
@@ -887,6 +918,8 @@ struct oc_solver {
                             const real ev = ok ? e : real(0);
                             val[s] = (creal)ev;
                             vlo[s] = (float)(ev - (real)val[s]);
+                        } else if (SL > 0 && s >= SREG) {
+                            lV[(s - SREG) * T + tid] = ok ? e : real(0);
                         } else {
                             val[s] = ok ? e : real(0);
                         }
@@ -904,7 +937,10 @@ struct oc_solver {
                         if (s % SETUP_CHUNK == SETUP_CHUNK - 1 || s == S - 1) {
 #pragma unroll
                             for (int u = s - s % SETUP_CHUNK; u <= s; ++u) {
-                                if constexpr (PACK) asm volatile("" : "+v"(val[u]), "+v"(adr[u / 2]));
+                                if (SL > 0 && u >= SREG) {
+                                    if constexpr (PACK) asm volatile("" : "+v"(adr[u / 2]));
+                                    else asm volatile("" : "+v"(adr[u]));
+                                } else if constexpr (PACK) asm volatile("" : "+v"(val[u]), "+v"(adr[u / 2]));
                                 else asm volatile("" : "+v"(val[u]), "+v"(adr[u]));
                             }
                         }
@@ -959,10 +995,15 @@ struct oc_solver {
                             const edge_t e1 = at32(g1.edge, a), e2 = at32(g2.edge, b);
                             e = prm.edge_kernel(e1, e2);
                         }
-                        val[s] = ok ? e : real(0);
                         unsigned col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
                         col = lp_off + col * ELEM;
-                        asm volatile("" : "+v"(val[s]), "+v"(col));
+                        if (SL > 0 && s >= SREG) {
+                            lV[(s - SREG) * T + tid] = ok ? e : real(0);
+                            asm volatile("" : "+v"(col));
+                        } else {
+                            val[s] = ok ? e : real(0);
+                            asm volatile("" : "+v"(val[s]), "+v"(col));
+                        }
                         if constexpr (PACK) {
                             // (byte addresses below 64 KB: at most 4096 rows of 8 bytes)
                             if (s % 2 == 0) adr[s / 2] = col;
@@ -988,6 +1029,7 @@ struct oc_solver {
             real rTz = 0;
             unsigned it = 0;
             [[maybe_unused]] sreal rTr_first = 0;   // SEQ: |r|^2 the first solve ended with
+            [[maybe_unused]] const unsigned lv_lane0 = lds_offset(lV) + (unsigned)tid * (unsigned)sizeof(creal);
 
             // FLY: the owner of row (i1, i2) walks adj(i1) x adj(i2) and
             // evaluates the edge microkernel `ek` per term (per-lane trip
@@ -1276,8 +1318,16 @@ struct oc_solver {
                             // -- 16 instead of 8 vectors in flight, and spills)
                             if constexpr (STATIC) __builtin_amdgcn_sched_barrier(0);
                             creal g[CW][GCH];
+                            [[maybe_unused]] creal vl[SL > 0 ? GCH : 1];   // SL: this chunk's LDS-resident values
+                            // (the lane's column address is re-defined here: a
+                            // loop-invariant LDS load would be hoisted out of the
+                            // iteration -- back into the registers it was to free)
+                            [[maybe_unused]] unsigned lv_lane = lv_lane0;
+                            if (SL > 0 && s0 + GCH > SREG) asm volatile("" : "+v"(lv_lane));
 #pragma unroll
                             for (int jj = 0; jj < GCH; ++jj) {
+                                if (SL > 0 && s0 + jj >= SREG && s0 + jj < S)
+                                    vl[jj] = load_real_at<creal>(lv_lane + (unsigned)((s0 + jj - SREG) * T * (int)sizeof(creal)));
                                 creal e[CW];
 #pragma unroll
                                 for (int c = 0; c < CW; ++c) e[c] = 0;
@@ -1300,7 +1350,8 @@ struct oc_solver {
                                 const int s = s0 + jj;
                                 if (s < S) {
 #pragma unroll
-                                    for (int c = 0; c < CW; ++c) acc[c] += val[s] * g[c][jj];
+                                    for (int c = 0; c < CW; ++c)
+                                        acc[c] += ((SL > 0 && s >= SREG) ? vl[jj] : val[s < SREG ? s : 0]) * g[c][jj];
                                     if (flush_at(s, fmv)) {   // wave-uniform
                                         if constexpr (STATIC) {
 #pragma unroll

@@ -313,7 +313,7 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
                     const int32_t *S, const int32_t *R, const int32_t *D,
                     const int32_t *n_L, const int32_t *L, int32_t C,
                     int32_t real_size, int64_t lds_limit, int32_t fly_min_degree,
-                    int32_t *choice, int64_t *NP) {
+                    const int64_t *extra_lds, int32_t *choice, int64_t *NP) {
     if (n_pairs < 0 || n_var < 0 || (C != 1 && C != 2)) return -1;
     (void)n_nz;
     constexpr int MAXL = 12;
@@ -372,7 +372,8 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
             const int64_t pcap = (np_ + 1 + 3) / 4 * 4;
             const int64_t NRy = ((n_L[v] > 0 && C != 2) || fly) ? 0 : NR;
             const int64_t lds = (pcap + NRy) * C * real_size + 4 * NR + 2 * gbytes +
-                                4 * (int64_t)W[v] * real_size + 4 * (D[v] > 6 ? 128 : 64) + 256 + 16;
+                                4 * (int64_t)W[v] * real_size + 4 * (D[v] > 6 ? 128 : 64) + 256 + 16 +
+                                (extra_lds ? extra_lds[v] : 0);
             if (lds > lds_limit) continue;
             const int64_t nb = (N + T - 1) / T;
             bool ok = true;

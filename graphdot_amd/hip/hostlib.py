@@ -26,7 +26,7 @@ SIGNATURES = {
     + [_i64, _vp, _vp],
     'gdh_number_records': [_vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
     'gdh_classify_oc': [_i64] + [_vp] * 7 + [_i32] + [_vp] * 6
-    + [_i32, _i32, _i64, _i32, _vp, _vp],
+    + [_i32, _i32, _i64, _i32, _vp, _vp, _vp],
     'gdh_pair_keys': [_vp, _i64, _vp, _i32, _i32, _vp, _vp],
     'gdh_order_jobs': [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp],
     'gdh_pairwise_jobs': [_i64, _i64, _vp],
@@ -156,7 +156,7 @@ def number_records(records, parts):
 
 
 def classify_oc(ca, cb, n_node, n_nz, image_bytes, maxdeg, hist, variants, C,
-                real_size, lds_limit, fly_min_degree=8):
+                real_size, lds_limit, fly_min_degree=8, extra_lds=None):
     """Variant index (into `variants`, a list of (W, S, R, D, L or None)) per
     class pair, or -1; and NP per pair."""
     ca, cb = _c(ca, np.int32), _c(cb, np.int32)
@@ -174,12 +174,16 @@ def classify_oc(ca, cb, n_node, n_nz, image_bytes, maxdeg, hist, variants, C,
             L[k, :len(v[4])] = v[4]
     choice = np.zeros(len(ca), np.int32)
     NP = np.zeros(len(ca), np.int64)
+    extra = np.zeros(max(nv, 1), np.int64)
+    if extra_lds is not None:
+        extra[:nv] = extra_lds
     _check(lib().gdh_classify_oc(
         len(ca), _p(ca), _p(cb), _p(_c(n_node, np.int32)),
         _p(_c(n_nz, np.int32)), _p(_c(image_bytes, np.int64)),
         _p(_c(maxdeg, np.int32)), _p(_c(hist, np.uint16)), nv, _p(W), _p(S),
         _p(R), _p(D), _p(nL), _p(L), int(C), int(real_size), int(lds_limit),
-        int(fly_min_degree), _p(choice), _p(NP)), 'gdh_classify_oc')
+        int(fly_min_degree), _p(extra), _p(choice), _p(NP)),
+        'gdh_classify_oc')
     return choice, NP
 
 

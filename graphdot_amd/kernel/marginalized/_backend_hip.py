@@ -958,6 +958,20 @@ void ${name}(params_t prm) {
             return 0
         return -(-(n * n * esize) // 16) * 16 + esize * (n + 3) * 32 + 256
 
+    def lds_slot_bytes(self, v, C):
+        """LDS bytes of the slot values a variant keeps in LDS instead of
+        registers (mgk_oc.h SL: the 16-wave double value solvers, 10 slots per
+        lane)."""
+        if (isinstance(v, OCVariant) and not v.L and C == 1 and v.W == 16
+                and v.S in (40, 64) and np.dtype(self.real) == np.float64):
+            n = 10
+            for f in self.hipcc_extra:           # (-DGD_OC_SL=n: experiments)
+                if f.startswith('-DGD_OC_SL='):
+                    n = int(f.split('=')[1])
+                    n = 10 if n == 1 else n
+            return n * 64 * v.W * 8
+        return 0
+
     def lds_bytes(self, v, C, ntask=0, gbytes=0, tab_bytes=0):
         """LDS bytes of one workgroup: static p + scratch, dynamic U, the two
         staged graph images per pair slot and the microkernel tables."""
@@ -971,7 +985,8 @@ void ${name}(params_t prm) {
             # except the value + gradient solvers, which keep x there
             NR_y = 0 if ((v.L and C != 2) or v.S == 0) else NR
             return (pcap + NR_y) * C * rs + 4 * NR + 2 * np.asarray(gbytes) \
-                + 4 * v.W * rs + 4 * (128 if v.D > 6 else 64) + 256 + 16
+                + 4 * v.W * rs + 4 * (128 if v.D > 6 else 64) + 256 + 16 \
+                + self.lds_slot_bytes(v, C)
         wpb = WPB1 if v.W == 1 else 1
         T = 64 * v.W
         ucap = -(-np.asarray(ntask) // 64) * 64 + 64
@@ -1207,7 +1222,8 @@ void ${name}(params_t prm) {
             ch, _ = hostlib.classify_oc(
                 ji, jj, n_node, n_nz, image_oc, maxdeg, hist,
                 [(v.W, v.S, v.R, v.D, v.L) for _, v in menu], C,
-                np.dtype(self.real).itemsize, LDS_LIMIT, FLY_MIN_DEGREE)
+                np.dtype(self.real).itemsize, LDS_LIMIT, FLY_MIN_DEGREE,
+                [self.lds_slot_bytes(v, C) for _, v in menu])
             idx = np.array([k for k, _ in menu], dtype=np.int64)
             hit = ch >= 0
             choice[hit] = idx[ch[hit]]
@@ -1464,6 +1480,7 @@ void ${name}(params_t prm) {
                 NR = 64 * v.W * v.R
                 dyn = (pcap + (0 if ((v.L and C != 2) or v.S == 0)
                                else NR)) * C * rsize + 4 * NR + 2 * gcap
+                dyn += self.lds_slot_bytes(v, C)
                 dense = False
                 if v.S == 0:
                     # on-the-fly variants: the dense n x n edge-record arrays

@@ -95,7 +95,9 @@ int gdh_number_records(const uint8_t *rec, int64_t n, int32_t itemsize,
  * marks an on-the-fly variant: the pairs with a degree above fly_min_degree
  * (8: where the slot variants end).
  * C: right-hand sides (1 value, 2 value + gradient); real_size 4 or 8;
- * lds_limit bytes per workgroup.
+ * lds_limit bytes per workgroup; extra_lds [n_var] (or NULL): LDS bytes a
+ * variant needs beyond p, row sums, row map and images (slot values kept in
+ * LDS, mgk_oc.h SL).
  * Outputs per pair: choice (variant index or -1), NP (rows with the odd LDS
  * stride, n1 * (n2 | 1)). */
 int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
@@ -105,7 +107,7 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
                     const int32_t *S, const int32_t *R, const int32_t *D,
                     const int32_t *n_L, const int32_t *L, int32_t C,
                     int32_t real_size, int64_t lds_limit, int32_t fly_min_degree,
-                    int32_t *choice, int64_t *NP);
+                    const int64_t *extra_lds, int32_t *choice, int64_t *NP);
 
 /* Class-pair key of every job: pk[t] = cid[jobs[t].i] * nc + cid[jobs[t].j]
  * (jobs: n_jobs (u32 i, u32 j) pairs), and count [nc * nc] the number of jobs
