@@ -62,6 +62,7 @@ _float_func_re = re.compile(
 _intrinsics = {'__powf': 'graphdot::pow', '__logf': 'graphdot::log',
                '__expf': 'graphdot::exp'}
 _intrinsic_re = re.compile(r'(?<![\w.])(__powf|__logf|__expf)\s*\(')
+_expf_re = re.compile(r'(?<![\w.:])expf\s*\(')
 
 
 def to_real_expr(expr, real='float32'):
@@ -73,7 +74,9 @@ def to_real_expr(expr, real='float32'):
     ``expf``-style calls for their double overloads."""
     expr = _intrinsic_re.sub(lambda m: _intrinsics[m.group(1)] + '(', expr)
     if real == 'float32':
-        return expr
+        # (expf through the overload of device/fmath.h, which spells it
+        # exp2(x * log2 e) for the optimiser to fold the constant)
+        return _expf_re.sub('graphdot::exp(', expr)
     expr = _float_literal.sub(
         lambda m: m.group(1) if any(c in m.group(1) for c in '.eE')
         else m.group(1) + '.0', expr)

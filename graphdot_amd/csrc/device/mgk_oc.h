@@ -582,6 +582,15 @@ struct oc_solver {
         graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
         const int dump = (int)prm.u_capacity - 1;   // cell that dead rows publish to
 
+        if constexpr (DENSE) {
+            // the dense product reads cells of p that no row publishes (the
+            // padding column of an even n2, up to three cells behind the
+            // vector) against records of weight 0: they must be numbers
+            if (prm.flags & F_DENSE) {
+                for (unsigned k = tid; k < prm.u_capacity * (unsigned)C; k += T) lp[k] = real(0);
+                job_sync<W>();
+            }
+        }
         for (unsigned t = blockIdx.x; t < prm.n_launch_jobs; t += gridDim.x) {
             const job_t job = scalar_load(prm.jobs + t);
             const graph_header_t h1 = scalar_load(headers + job.i), h2 = scalar_load(headers + job.j);
@@ -659,14 +668,16 @@ struct oc_solver {
             [[maybe_unused]] bool dense_pair = false;
             [[maybe_unused]] edge_t *dE1 = nullptr, *dE2T = nullptr;
             if constexpr (DENSE) {
-                // graph 2's array as dword planes, E2T[word d of the record][j2][i2]
-                // with rows of DSTRIDE words (hosts sets F_DENSE for graphs of at
-                // most DSTRIDE nodes): the lanes of a wave -- consecutive i2 --
-                // read consecutive words (no bank conflicts: blocks of four
-                // 8-byte records per lane put 16 lanes on one bank and ran at
-                // 62 % conflict cycles, 3.4 M pairs/s), and the words of the
-                // four columns of a trip sit at compile-time offsets from one
-                // running address
+                // graph 2's array as dword rows, E2T[j2 / 4][word d of the
+                // record][j2 % 4][i2] with rows of DSTRIDE words (hosts sets
+                // F_DENSE for graphs of at most DSTRIDE nodes): the lanes of a
+                // wave -- consecutive i2 -- read consecutive words (no bank
+                // conflicts: blocks of four 8-byte records per lane put 16
+                // lanes on one bank and ran at 62 % conflict cycles, 3.4 M
+                // pairs/s), and all the words of the four columns of a trip
+                // sit within 1 KB of ONE running address (ds_read2_b32 reaches
+                // 255 words: whole planes per record word took an address
+                // register and an addition per plane and trip)
                 const unsigned n2p = ((unsigned)n2 + 3u) & ~3u;   // rows per plane: whole trips of four, the padding rows zero
                 const unsigned nn1 = (unsigned)n1 * (unsigned)n1, nn2 = EW * n2p * DSTRIDE;
                 dense_pair = (prm.flags & F_DENSE) && n2 <= (int)DSTRIDE &&
@@ -692,7 +703,7 @@ struct oc_solver {
                         __builtin_memcpy(words, &rec, sizeof(edge_t));
 #pragma unroll
                         for (unsigned d = 0; d < EW; ++d)
-                            planes[(d * n2p + z.j) * DSTRIDE + z.i] = words[d];
+                            planes[(((unsigned)z.j >> 2) * (EW * 4u) + d * 4u + ((unsigned)z.j & 3u)) * DSTRIDE + z.i] = words[d];
                     }
                     job_sync<W>();
                 }
@@ -1039,7 +1050,6 @@ struct oc_solver {
             [[maybe_unused]] auto fly_matvec = [&](auto const &ek, real (&ysum)[CW][(STATIC || FLY) ? R : 1]) {
                 if constexpr (DENSE) if (dense_pair) {      // (workgroup-uniform)
                     static_assert(FLY_U == 4, "the dense product walks blocks of four columns");
-                    const unsigned jlast = (unsigned)n2 - 1u, n2p_ = ((unsigned)n2 + 3u) & ~3u;
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         const unsigned rm = rowid[k];
@@ -1067,7 +1077,7 @@ struct oc_solver {
                             for (unsigned j2 = 0; j2 < (unsigned)n2; j2 += 4) {
                                 // (j2 is uniform: the block address and the clamped
                                 // columns of p are scalar arithmetic)
-                                unsigned const *const col = e2lane + j2 * DSTRIDE;
+                                unsigned const *const blk = e2lane + j2 * (EW * DSTRIDE);
                                 edge_t e2[4];
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
@@ -1075,16 +1085,20 @@ struct oc_solver {
                                     // weight 0)
                                     unsigned words[EW];
 #pragma unroll
-                                    for (unsigned d = 0; d < EW; ++d) words[d] = col[d * n2p_ * DSTRIDE + u * DSTRIDE];
+                                    for (unsigned d = 0; d < EW; ++d) words[d] = blk[(d * 4u + (unsigned)u) * DSTRIDE];
                                     __builtin_memcpy(&e2[u], words, sizeof(edge_t));
                                 }
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) {
-                                    // p beyond the row end is not read (its records are
-                                    // zero, but the cells behind p are not numbers)
-                                    const unsigned jj = j2 + u < (unsigned)n2 ? j2 + u : jlast;
+                                    // (the last trip reads up to three cells behind the
+                                    // row of p -- the next row, the padding column or
+                                    // the cells behind the vector, all of them numbers
+                                    // (zeroed at the start of the launch, the host sizes
+                                    // p four cells longer): their records have weight 0.
+                                    // Clamped columns cost a scalar select and a
+                                    // register move per term.)
                                     real pe[CW];
-                                    load_elem_at<CW>(rowp + jj * ELEM, pe);   // the same address in every lane
+                                    load_elem_at<CW>(rowp + (j2 + (unsigned)u) * ELEM, pe);   // the same address in every lane
                                     const real e = real(ek(e1, e2[u]));
 #pragma unroll
                                     for (int c = 0; c < CW; ++c) part[c][u] += e * pe[c];
@@ -1333,11 +1347,16 @@ struct oc_solver {
                                 for (int c = 0; c < CW; ++c) e[c] = 0;
                                 if (s0 + jj < S) {
                                     if constexpr (PACK) {
-                                        // (the pin keeps the unpack -- one VALU --
-                                        // in the loop instead of S hoisted registers)
-                                        unsigned pk = adr[(s0 + jj) / 2];
-                                        asm volatile("" : "+v"(pk));
-                                        load_elem_at<CW>(((s0 + jj) & 1) ? pk >> 16 : pk & 0xFFFFu, e);
+                                        // (the unpack -- one VALU -- as a volatile
+                                        // instruction: it stays in the loop instead
+                                        // of S hoisted registers, and without the
+                                        // register copy a pinned operand costs)
+                                        unsigned col;
+                                        if ((s0 + jj) & 1)
+                                            asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(col) : "v"(adr[(s0 + jj) / 2]));
+                                        else
+                                            asm volatile("v_and_b32 %0, 0xffff, %1" : "=v"(col) : "v"(adr[(s0 + jj) / 2]));
+                                        load_elem_at<CW>(col, e);
                                     } else {
                                         load_elem_at<CW>(adr[s0 + jj], e);
                                     }

@@ -1489,7 +1489,10 @@ void ${name}(params_t prm) {
                     # kernel that they are there)
                     extra = self._dense_bytes(dgraphs)
                     if extra and dyn + extra + 4096 <= LDS_LIMIT:
-                        dyn += extra
+                        # (+ 4 cells of p: the last trip of a row of the
+                        # dense product reads up to three cells past it)
+                        pcap += 4
+                        dyn += extra + 4 * C * rsize
                         dense = True
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=pcap, gcap=gcap,

@@ -2,7 +2,7 @@
 """Dump the gfx950 ISA of one solver variant built for the bench workload
 (QM7-like TensorProduct kernels) -- for instruction-count work on the CG loop.
 
-    python scripts/dump_isa.py W S R [C] [--f64] [--oc=D] [--layout=16x4x4x1] [--tab|--tab=2] [--config2] > out.s
+    python scripts/dump_isa.py W S R [C] [--f64] [--oc=D] [--layout=16x4x4x1] [--tab|--tab=2] [--config2|--tang] > out.s
 """
 import os
 import subprocess
@@ -24,6 +24,9 @@ backend = HIPBackend(real=real)
 if '--config2' in sys.argv:      # weighted graphs, continuous edge labels
     kn, ke, q = cases.config2b_kernels()
     G = cases.config2_graphs(8, seed=0)
+elif '--tang' in sys.argv:       # dense molecular graphs (on-the-fly solvers)
+    kn, ke, q = cases.tang2019_kernels()
+    G = cases.tang2019_graphs(8)
 else:
     kn, ke, q = cases.config3_kernels()
     G = cases.config3_graphs(8)
