@@ -90,6 +90,9 @@ PyObject *collect(PyObject *, PyObject *args) {
                 break;
             }
             std::vector<char> &out = cols[(size_t)k];
+            // (room for every graph at the size of the first ones: one
+            // allocation per column instead of a dozen doublings)
+            if (g == 1) out.reserve((size_t)(out.size() + (size_t)view.len) * (size_t)G / 2 + 64);
             out.insert(out.end(), (const char *)view.buf, (const char *)view.buf + view.len);
             PyBuffer_Release(&view);
         }
@@ -126,8 +129,78 @@ PyObject *collect(PyObject *, PyObject *args) {
     return Py_BuildValue("(NNN)", tcols, len, tfmt);
 }
 
+// same_tables(graphs, attr) -> True | None.  True: the table `attr` of every
+// graph has the first graph's columns, in its order, each a one-dimensional
+// contiguous buffer of the same element format -- i.e. DataFrame.rowtype() is
+// the same for all of them (what Graph.has_unified_types establishes with two
+// rowtype() calls per graph, 3-4 ms per 1000 graphs on the first call).  None:
+// anything else -- the caller decides in Python.
+PyObject *same_tables(PyObject *, PyObject *args) {
+    PyObject *graphs, *attr;
+    if (!PyArg_ParseTuple(args, "O!U", &PyList_Type, &graphs, &attr)) return nullptr;
+    const Py_ssize_t G = PyList_GET_SIZE(graphs);
+    PyObject *data_name = PyUnicode_InternFromString("_data");
+    if (!data_name) return nullptr;
+    std::vector<PyObject *> keys;         // the first graph's column names (owned)
+    std::vector<std::string> fmt;
+    std::vector<Py_ssize_t> isz;
+    bool same = true, error = false;
+    for (Py_ssize_t g = 0; g < G && same && !error; ++g) {
+        PyObject *frame = PyObject_GetAttr(PyList_GET_ITEM(graphs, g), attr);
+        PyObject *data = frame ? PyObject_GetAttr(frame, data_name) : nullptr;
+        Py_XDECREF(frame);
+        if (!data) {
+            error = true;
+            break;
+        }
+        if (!PyDict_Check(data) || (g > 0 && PyDict_GET_SIZE(data) != (Py_ssize_t)keys.size())) {
+            Py_DECREF(data);
+            same = false;
+            break;
+        }
+        Py_ssize_t pos = 0, k = 0;
+        PyObject *key, *col;
+        while (same && PyDict_Next(data, &pos, &key, &col)) {
+            if (g > 0 && key != keys[(size_t)k]) {
+                const int eq = PyObject_RichCompareBool(key, keys[(size_t)k], Py_EQ);
+                if (eq < 0) error = true;
+                if (eq <= 0) {
+                    same = false;
+                    break;
+                }
+            }
+            Py_buffer view;
+            if (PyObject_GetBuffer(col, &view, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS) != 0) {
+                PyErr_Clear();
+                same = false;
+                break;
+            }
+            const char *f = view.format ? view.format : "B";
+            bool ok = view.ndim == 1 && view.itemsize > 0 && std::strchr(f, 'O') == nullptr;
+            if (ok && g == 0) {
+                Py_INCREF(key);
+                keys.push_back(key);
+                fmt.emplace_back(f);
+                isz.push_back(view.itemsize);
+            } else if (ok) {
+                ok = fmt[(size_t)k] == f && isz[(size_t)k] == view.itemsize;
+            }
+            PyBuffer_Release(&view);
+            if (!ok) same = false;
+            ++k;
+        }
+        Py_DECREF(data);
+    }
+    for (PyObject *k : keys) Py_DECREF(k);
+    Py_DECREF(data_name);
+    if (error) return nullptr;
+    if (same) Py_RETURN_TRUE;
+    Py_RETURN_NONE;
+}
+
 PyMethodDef methods[] = {
     {"collect", collect, METH_VARARGS, "collect(graphs, attr, keys) -> (columns, lengths, formats) | None"},
+    {"same_tables", same_tables, METH_VARARGS, "same_tables(graphs, attr) -> True | None"},
     {nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef module = {PyModuleDef_HEAD_INIT, "_gdcollect", "table gathering for the native graph packer", -1, methods,

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -102,118 +103,159 @@ int gdh_pack_graphs(int32_t G, const int64_t *node_off, const int64_t *edge_off,
         int64_t key;
         int32_t src, dst, e;
     };
-    std::vector<entry_t> ent, uniq;
-    std::vector<float> deg;
-    std::vector<int64_t> cnt;
-    std::vector<int32_t> order;
+    // Three passes: (A) per graph, in parallel -- degrees, directed nonzeros,
+    // the degree renumbering and everything addressed by the graph's node /
+    // edge offsets; the nonzeros wait in a scratch array at twice the edge
+    // offset (their upper bound); (B) serial -- the running offsets of the
+    // nonzero arrays and of the blobs, which need every graph's nonzero count;
+    // (C) per graph, in parallel -- nz / eid and the blobs.
+    if (G == 0) {
+        blob_off[0] = 0;
+        nz_off[0] = 0;
+        return 0;
+    }
+    const int64_t total_m = edge_off[G] - edge_off[0];
+    if (total_m < 0) return -1;
+    std::vector<entry_t> all_uniq((size_t)(2 * total_m));
+    std::atomic<int> status{0};
+    const int T = host_threads(G, 64);
+    parallel_ranges(G, T, [&](int64_t g0, int64_t g1, int) {
+        std::vector<entry_t> ent;
+        std::vector<float> deg;
+        std::vector<int64_t> cnt;
+        std::vector<int32_t> order;
+        for (int64_t g = g0; g < g1 && status.load(std::memory_order_relaxed) == 0; ++g) {
+            const int64_t n0 = node_off[g], n = node_off[g + 1] - n0;
+            const int64_t e0 = edge_off[g], m = edge_off[g + 1] - e0;
+            if (n < 0 || m < 0 || n > 0xFFFF || 2 * m > 0xFFFF) {
+                status = -1;
+                return;
+            }
+            // ---- degrees: float32 sums in the order of the per-graph packer
+            // (ei pass, ej pass, self loops taken back once) ----------------
+            deg.assign((size_t)n, 0.f);
+            for (int64_t e = 0; e < m; ++e) {
+                const int64_t a = ei[e0 + e], b = ej[e0 + e];
+                if (a < 0 || a >= n || b < 0 || b >= n) {
+                    status = -1;
+                    return;
+                }
+            }
+            for (int64_t e = 0; e < m; ++e) deg[(size_t)ei[e0 + e]] += w ? w[e0 + e] : 1.f;
+            for (int64_t e = 0; e < m; ++e) deg[(size_t)ej[e0 + e]] += w ? w[e0 + e] : 1.f;
+            for (int64_t e = 0; e < m; ++e)
+                if (ei[e0 + e] == ej[e0 + e]) deg[(size_t)ei[e0 + e]] -= w ? w[e0 + e] : 1.f;
+            for (int64_t i = 0; i < n; ++i)
+                if (deg[(size_t)i] == 0.f) deg[(size_t)i] = 1.f;
+            // ---- directed nonzeros: both orientations, duplicates collapse
+            // onto their first occurrence (forward orientations first) -------
+            ent.resize((size_t)(2 * m));
+            for (int64_t e = 0; e < m; ++e) {
+                const int32_t a = (int32_t)ei[e0 + e], b = (int32_t)ej[e0 + e];
+                ent[(size_t)e] = {a * n + b, a, b, (int32_t)e};
+                ent[(size_t)(m + e)] = {b * n + a, b, a, (int32_t)e};
+            }
+            std::stable_sort(ent.begin(), ent.end(),
+                             [](entry_t const &x, entry_t const &y) { return x.key < y.key; });
+            entry_t *const uniq = all_uniq.data() + 2 * (e0 - edge_off[0]);
+            int64_t z = 0;
+            for (size_t k = 0; k < ent.size(); ++k)
+                if (k == 0 || ent[k].key != ent[k - 1].key) uniq[z++] = ent[k];
+            // ---- renumber the nodes by descending adjacency count (stable) -
+            cnt.assign((size_t)n, 0);
+            for (int64_t k = 0; k < z; ++k) ++cnt[(size_t)uniq[k].src];
+            order.resize((size_t)n);
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(),
+                             [&](int32_t x, int32_t y) { return cnt[(size_t)x] > cnt[(size_t)y]; });
+            int64_t md = 0;
+            for (int64_t k = 0; k < n; ++k) {
+                const int32_t old = order[(size_t)k];
+                perm[n0 + k] = (uint16_t)old;
+                rank[n0 + old] = k;
+                degree[n0 + k] = deg[(size_t)old];
+                count[n0 + k] = cnt[(size_t)old];
+                md = std::max(md, cnt[(size_t)old]);
+            }
+            maxdeg[g] = md;
+            for (int64_t k = 0; k < z; ++k) {
+                entry_t &u = uniq[k];
+                u.src = (int32_t)rank[n0 + u.src];
+                u.dst = (int32_t)rank[n0 + u.dst];
+                u.key = (int64_t)u.src * n + u.dst;
+            }
+            std::sort(uniq, uniq + z,
+                      [](entry_t const &x, entry_t const &y) { return x.key < y.key; });
+            uint16_t *rp = rowptr + n0 + g;
+            rp[0] = 0;
+            for (int64_t k = 0; k < n; ++k) rp[k + 1] = (uint16_t)(rp[k] + count[n0 + k]);
+            nnz[g] = z;
+            for (int64_t r = 0; r < n; ++r) {
+                const int64_t id = node_id[n0 + r];
+                if (id < 0 || id >= n) {
+                    status = -1;
+                    return;
+                }
+            }
+        }
+    });
+    if (status != 0) return status;
+    // ---- (B) offsets -------------------------------------------------------
     int64_t cursor = 0, zc = 0;
     blob_off[0] = 0;
     nz_off[0] = 0;
     for (int32_t g = 0; g < G; ++g) {
-        const int64_t n0 = node_off[g], n = node_off[g + 1] - n0;
-        const int64_t e0 = edge_off[g], m = edge_off[g + 1] - e0;
-        if (n < 0 || m < 0 || n > 0xFFFF || 2 * m > 0xFFFF) return -1;
-        // ---- degrees: float32 sums in the order of the per-graph packer
-        // (ei pass, ej pass, self loops taken back once) --------------------
-        deg.assign((size_t)n, 0.f);
-        for (int64_t e = 0; e < m; ++e) deg[(size_t)ei[e0 + e]] += w ? w[e0 + e] : 1.f;
-        for (int64_t e = 0; e < m; ++e) deg[(size_t)ej[e0 + e]] += w ? w[e0 + e] : 1.f;
-        for (int64_t e = 0; e < m; ++e)
-            if (ei[e0 + e] == ej[e0 + e]) deg[(size_t)ei[e0 + e]] -= w ? w[e0 + e] : 1.f;
-        for (int64_t i = 0; i < n; ++i)
-            if (deg[(size_t)i] == 0.f) deg[(size_t)i] = 1.f;
-        // ---- directed nonzeros: both orientations, duplicates collapse onto
-        // their first occurrence (forward orientations first) ----------------
-        ent.resize((size_t)(2 * m));
-        for (int64_t e = 0; e < m; ++e) {
-            const int32_t a = (int32_t)ei[e0 + e], b = (int32_t)ej[e0 + e];
-            if (a < 0 || a >= n || b < 0 || b >= n) return -1;
-            ent[(size_t)e] = {a * n + b, a, b, (int32_t)e};
-            ent[(size_t)(m + e)] = {b * n + a, b, a, (int32_t)e};
-        }
-        std::stable_sort(ent.begin(), ent.end(),
-                         [](entry_t const &x, entry_t const &y) { return x.key < y.key; });
-        uniq.clear();
-        for (size_t k = 0; k < ent.size(); ++k)
-            if (k == 0 || ent[k].key != ent[k - 1].key) uniq.push_back(ent[k]);
-        const int64_t z = (int64_t)uniq.size();
-        if (zc + z > nz_capacity) return -2;
-        // ---- renumber the nodes by descending adjacency count (stable) ----
-        cnt.assign((size_t)n, 0);
-        for (auto const &u : uniq) ++cnt[(size_t)u.src];
-        order.resize((size_t)n);
-        std::iota(order.begin(), order.end(), 0);
-        std::stable_sort(order.begin(), order.end(),
-                         [&](int32_t x, int32_t y) { return cnt[(size_t)x] > cnt[(size_t)y]; });
-        int64_t md = 0;
-        for (int64_t k = 0; k < n; ++k) {
-            const int32_t old = order[(size_t)k];
-            perm[n0 + k] = (uint16_t)old;
-            rank[n0 + old] = k;
-            degree[n0 + k] = deg[(size_t)old];
-            count[n0 + k] = cnt[(size_t)old];
-            md = std::max(md, cnt[(size_t)old]);
-        }
-        maxdeg[g] = md;
-        for (auto &u : uniq) {
-            u.src = (int32_t)rank[n0 + u.src];
-            u.dst = (int32_t)rank[n0 + u.dst];
-            u.key = (int64_t)u.src * n + u.dst;
-        }
-        std::sort(uniq.begin(), uniq.end(),
-                  [](entry_t const &x, entry_t const &y) { return x.key < y.key; });
-        // ---- flat views ----------------------------------------------------
-        uint16_t *rp = rowptr + n0 + g;
-        rp[0] = 0;
-        for (int64_t k = 0; k < n; ++k) rp[k + 1] = (uint16_t)(rp[k] + count[n0 + k]);
-        for (int64_t k = 0; k < z; ++k) {
-            nz[2 * (zc + k)] = (uint16_t)uniq[(size_t)k].src;
-            nz[2 * (zc + k) + 1] = (uint16_t)uniq[(size_t)k].dst;
-            eid[zc + k] = uniq[(size_t)k].e;
-        }
-        nnz[g] = z;
-        // ---- blob ----------------------------------------------------------
+        const int64_t n = node_off[g + 1] - node_off[g], z = nnz[g];
         const int64_t sizes[6] = {4 * n, (int64_t)node_size * n, 2 * (n + 1), 4 * z,
                                   (int64_t)edge_size * z, 2 * n};
-        int64_t off[6], c = 0;
-        for (int s = 0; s < 6; ++s) {
-            off[s] = c;
-            sec_off[(size_t)g * 6 + s] = c;
-            c += pad(sizes[s]);
+        int64_t c = 0;
+        for (int s_ = 0; s_ < 6; ++s_) {
+            sec_off[(size_t)g * 6 + s_] = c;
+            c += pad(sizes[s_]);
         }
-        const int64_t len = std::max<int64_t>(c, ALIGN);
-        if (cursor + len > blob_capacity) return -2;
-        uint8_t *B = blob + cursor;
-        std::memset(B, 0, (size_t)len);
-        std::memcpy(B + off[0], degree + n0, (size_t)(4 * n));
-        for (int64_t r = 0; r < n; ++r) {      // node row r -> its new index
-            const int64_t id = node_id[n0 + r];
-            if (id < 0 || id >= n) return -1;
-            std::memcpy(B + off[1] + rank[n0 + id] * node_size,
-                        node_rec + (size_t)(n0 + r) * node_size, (size_t)node_size);
-        }
-        std::memcpy(B + off[2], rp, (size_t)(2 * (n + 1)));
-        std::memcpy(B + off[3], nz + 2 * zc, (size_t)(4 * z));
-        for (int64_t k = 0; k < z; ++k) {
-            uint8_t *rec = B + off[4] + k * edge_size;
-            const int64_t e = e0 + eid[zc + k];
-            if (weight_bytes == 4) {
-                const float v = w ? w[e] : 1.f;
-                std::memcpy(rec, &v, 4);
-            } else if (weight_bytes == 8) {
-                const double v = (double)(w ? w[e] : 1.f);
-                std::memcpy(rec, &v, 8);
-            }
-            if (label_size > 0)
-                std::memcpy(rec + label_offset, label_rec + (size_t)e * label_size,
-                            (size_t)label_size);
-        }
-        std::memcpy(B + off[5], perm + n0, (size_t)(2 * n));
-        cursor += len;
+        cursor += std::max<int64_t>(c, ALIGN);
         zc += z;
+        if (zc > nz_capacity || cursor > blob_capacity) return -2;
         blob_off[g + 1] = cursor;
         nz_off[g + 1] = zc;
     }
+    // ---- (C) flat nonzero views and blobs ------------------------------------
+    parallel_ranges(G, T, [&](int64_t g0, int64_t g1, int) {
+        for (int64_t g = g0; g < g1; ++g) {
+            const int64_t n0 = node_off[g], n = node_off[g + 1] - n0;
+            const int64_t e0 = edge_off[g], z = nnz[g], z0 = nz_off[g];
+            entry_t const *const uniq = all_uniq.data() + 2 * (e0 - edge_off[0]);
+            for (int64_t k = 0; k < z; ++k) {
+                nz[2 * (z0 + k)] = (uint16_t)uniq[k].src;
+                nz[2 * (z0 + k) + 1] = (uint16_t)uniq[k].dst;
+                eid[z0 + k] = uniq[k].e;
+            }
+            const int64_t *off = sec_off + (size_t)g * 6;
+            uint8_t *B = blob + blob_off[g];
+            std::memset(B, 0, (size_t)(blob_off[g + 1] - blob_off[g]));
+            std::memcpy(B + off[0], degree + n0, (size_t)(4 * n));
+            for (int64_t r = 0; r < n; ++r)      // node row r -> its new index
+                std::memcpy(B + off[1] + rank[n0 + node_id[n0 + r]] * node_size,
+                            node_rec + (size_t)(n0 + r) * node_size, (size_t)node_size);
+            std::memcpy(B + off[2], rowptr + n0 + g, (size_t)(2 * (n + 1)));
+            std::memcpy(B + off[3], nz + 2 * z0, (size_t)(4 * z));
+            for (int64_t k = 0; k < z; ++k) {
+                uint8_t *rec = B + off[4] + k * edge_size;
+                const int64_t e = e0 + eid[z0 + k];
+                if (weight_bytes == 4) {
+                    const float v = w ? w[e] : 1.f;
+                    std::memcpy(rec, &v, 4);
+                } else if (weight_bytes == 8) {
+                    const double v = (double)(w ? w[e] : 1.f);
+                    std::memcpy(rec, &v, 8);
+                }
+                if (label_size > 0)
+                    std::memcpy(rec + label_offset, label_rec + (size_t)e * label_size,
+                                (size_t)label_size);
+            }
+            std::memcpy(B + off[5], perm + n0, (size_t)(2 * n));
+        }
+    });
     return 0;
 }
 

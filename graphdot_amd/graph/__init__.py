@@ -117,6 +117,17 @@ class Graph:
         key, hit = _UNIFIED.get(graphs)
         if hit:
             return True
+        if len(graphs) >= 16:
+            # plain numeric tables: one native pass over the objects (the
+            # per-graph comparison below costs 3-4 us per graph, most of what
+            # the first call of a process paid over a later fresh backend's)
+            try:
+                from ..hip.hostlib import same_tables
+                if same_tables(graphs):
+                    _UNIFIED.put(key, graphs, True)
+                    return True
+            except Exception:          # no compiler, no headers: Python
+                pass
         first = next(iter(graphs))
         node_t, edge_t = rowtypes(first)
         for other in graphs:

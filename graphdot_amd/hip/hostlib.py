@@ -307,6 +307,22 @@ def _build_collector():
         return False
 
 
+def same_tables(graphs):
+    """True if the node and the edge tables of all `graphs` have the first
+    graph's columns and element types (one native pass, csrc/gdcollect.cpp
+    `same_tables`); None if not, or not decidable natively (no extension,
+    object columns): the caller compares row types in Python."""
+    mod = collector()
+    if not mod or not hasattr(mod, 'same_tables'):
+        return None
+    graphs = graphs if isinstance(graphs, list) else list(graphs)
+    try:
+        return (mod.same_tables(graphs, 'nodes')
+                and mod.same_tables(graphs, 'edges')) or None
+    except (AttributeError, TypeError):
+        return None
+
+
 def collect_columns(graphs, attr, keys, dtypes):
     """{key: column of all graphs back to back}, rows per graph (int64) --
     or None if the tables are not uniform (or there is no extension).

@@ -527,15 +527,18 @@ def pack_many(graphs, real=np.float32, native=True):
     gc_was_on = gc.isenabled()
     gc.disable()
     try:
+        new = _BatchMember.__new__
+        ibytes = r['features']['image_bytes'].tolist()
         for b_, k in enumerate(batch):
-            # (the per-graph array views are cut on first use: _BatchMember)
-            dg = _BatchMember.__new__(_BatchMember)
-            dg._b, dg._k = r, b_
-            dg.n_node, dg.n_nz, dg.weighted = nl[b_], nnz[b_], weighted
-            dg.node_t, dg.edge_t, dg.signature = node_t, edge_t, signature
-            dg.image_bytes = _pad(offs[b_][5] + 2 * nl[b_])
-            dg._max_degree = maxdeg[b_]
-            out[k] = dg
+            # (the per-graph array views are cut on first use: _BatchMember;
+            # the attributes as one dictionary: a third of the time of ten
+            # attribute stores)
+            dg = out[k] = new(_BatchMember)
+            dg.__dict__ = {
+                '_b': r, '_k': b_, 'n_node': nl[b_], 'n_nz': nnz[b_],
+                'weighted': weighted, 'node_t': node_t, 'edge_t': edge_t,
+                'signature': signature, 'image_bytes': ibytes[b_],
+                '_max_degree': maxdeg[b_]}
     finally:
         if gc_was_on:
             gc.enable()

@@ -290,6 +290,47 @@ def test_row_type_cache_follows_graph_mutation():
     assert Graph.has_unified_types([ga, gb]) is True
 
 
+def test_native_table_check_agrees_with_the_row_type_comparison():
+    """`Graph.has_unified_types` on a long list goes through one native pass
+    (hostlib.same_tables, csrc/gdcollect.cpp); it may only say "unified" where
+    the per-graph row-type comparison does, and must leave every other case
+    -- another element type, another column order, a missing column, an
+    object column -- to it."""
+    import cases
+    from graphdot_amd.hip import hostlib
+    if not hostlib.collector():
+        pytest.skip('no CPython extension on this machine')
+    G = cases.config3_graphs(40)
+    for g in G:
+        g.cookie.clear()
+    assert hostlib.same_tables(G) is True
+    assert Graph.has_unified_types(G) is True
+    assert all('rowtypes' not in g.cookie for g in G)     # (the native path)
+
+    def python_says(H):
+        for g in H:
+            g.cookie.clear()
+        first = (H[0].nodes.rowtype(), H[0].edges.rowtype())
+        return all((g.nodes.rowtype(), g.edges.rowtype()) == first for g in H)
+
+    retyped = G[5].copy(deep=True)
+    retyped.nodes['hcount'] = np.asarray(retyped.nodes['hcount']).astype(np.float64)
+    reordered = G[7].copy(deep=True)
+    reordered.edges._data = dict(reversed(list(reordered.edges._data.items())))
+    dropped = G[9].copy(deep=True)
+    del dropped.edges._data['stereo']
+    boxed = G[11].copy(deep=True)
+    boxed.nodes['tag'] = [(1, 2)] * len(boxed.nodes)
+    for k, h in ((5, retyped), (7, reordered), (9, dropped), (11, boxed)):
+        H = list(G)
+        H[k] = h
+        assert hostlib.same_tables(H) is None
+        assert python_says(H) is False
+        bad = Graph.has_unified_types(H)
+        assert bad is not True and bad[2] is h
+    assert python_says(G) is True
+
+
 def test_graph_list_identity_cache_dies_with_the_cookie_epoch():
     """`has_unified_types` and the backend remember what they derived from a
     list of graphs by the identities of its members
