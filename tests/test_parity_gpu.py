@@ -900,6 +900,58 @@ def test_mixed_degree_sets_cross_every_solver_family(backend):
                                       2e-3, 2e-5) <= 1.0
 
 
+@pytest.mark.parametrize('sizes', [(5, 8, 28, 29, 30, 31, 32),
+                                   (4, 17, 24, 32, 33)])
+def test_dense_product_at_the_row_limit(sizes):
+    """The dense product of the on-the-fly solvers (mgk_oc.h DENSE) walks the
+    columns of graph 2 in trips of four and reads p unclamped: sizes whose
+    last trip runs one, two and three columns past the row (n2 = 29, 30, 31),
+    whole trips (28, 32), even sizes (a padding column in p) and the 32-node
+    limit of the staged rows, every pair of them in one matrix, value and
+    gradient against the dense oracle.  One node more (33) and the call keeps
+    the sparse walk: same results."""
+    import networkx as nx
+    from graphdot_amd.kernel.marginalized._backend_hip import (
+        HIPBackend, OCVariant)
+    rng = np.random.default_rng(321)
+    gs = []
+    for n in sizes:
+        g = nx.gnp_random_graph(n, 0.85, seed=int(rng.integers(1 << 30)))
+        for u in range(n - 1):              # connected
+            g.add_edge(u, u + 1)
+        for v in g.nodes:
+            g.nodes[v]['category'] = int(rng.integers(1, 4))
+        for e in g.edges:
+            g.edges[e]['w'] = float(rng.choice([0.5, 1.0, 2.0]))
+            g.edges[e]['length'] = float(rng.uniform(0.5, 2.5))
+        gs.append(Graph.from_networkx(g, weight='w'))
+    G = Graph.unify_datatype(gs)
+    knode, kedge, q = cases.config2b_kernels()
+    be = HIPBackend(real=np.float32)
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=be)
+    K = k(G)
+    fly = [L for L in be.last_plan.launches
+           if isinstance(L['variant'], OCVariant) and L['variant'].S == 0]
+    assert fly
+    assert all(bool(L.get('dense')) == (max(sizes) <= 32) for L in fly)
+    ref = oracle.gram(G, knode, kedge, q=q)
+    assert np.isfinite(K).all()
+    assert np.allclose(K, ref, rtol=1e-5), np.abs(K / ref - 1).max()
+    assert np.array_equal(K, K.T)
+    Kxy = k(G[:3], G[3:])                   # both orders of every size pair
+    assert np.allclose(Kxy, ref[:3, 3:], rtol=1e-5)
+    Kyx = k(G[3:], G[:3])
+    assert np.allclose(Kyx, ref[3:, :3], rtol=1e-5)
+    K2, dK = k(G, eval_gradient=True)
+    ref2, dref = oracle.gram(G, knode, kedge, q=q, eval_gradient=True)
+    assert np.allclose(K2, ref, rtol=1e-5)
+    assert elementwise_gradient_error(dK, dref[:, :, k.active_theta_mask],
+                                      2e-3, 2e-5) <= 1.0
+    # again on the same backend: the cells behind p hold the last pair's
+    # leftovers now, not the zeros of the first launch
+    assert np.array_equal(k(G), K)
+
+
 @pytest.mark.parametrize('real', [np.float32, np.float64])
 def test_dense_graphs_take_the_on_the_fly_solver(real):
     """Dense, from_ase-like molecular graphs (the reference's flagship preset,
