@@ -62,6 +62,25 @@ __device__ __forceinline__ double log(double x) { return ::log(x); }
 __device__ __forceinline__ float exp(float x) { return __builtin_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ double exp(double x) { return ::exp(x); }
 
+// Two evaluations of a microkernel at once: the generated functors are
+// templates of their argument type, and a record whose 4-byte leaves are
+// replaced by pairs (`pk2<float>`, `pk2<int32>`: the backend prints such an
+// `edge2_t` next to `edge_t` when every leaf qualifies and the expression only
+// calls what is overloaded here) evaluates the same expression on two records
+// with the packed float instructions of gfx950 (v_pk_add_f32, v_pk_mul_f32,
+// v_pk_fma_f32: two lanes' worth per issue).  Comparisons, ?: with scalar
+// branches and arithmetic with scalar hyperparameters work on these vector
+// types as they are.
+template<class T> using pk2 = T __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk2<float> exp(pk2<float> x) {
+    const pk2<float> y = x * 1.44269504088896340736f;
+    return pk2<float>{__builtin_exp2f(y.x), __builtin_exp2f(y.y)};
+}
+// (element k of a packed or a plain result)
+template<class T> __device__ __forceinline__ T lane_of(pk2<T> v, int k) { return k ? v.y : v.x; }
+__device__ __forceinline__ float lane_of(float v, int) { return v; }
+__device__ __forceinline__ float lane_of(int v, int) { return (float)v; }
+
 }  // namespace graphdot
 
 #endif

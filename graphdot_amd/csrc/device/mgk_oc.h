@@ -222,6 +222,18 @@ template<class real, int W> struct alternating_reduce {
     }
 };
 
+// EdgeK::packed_edge_t (printed by the backend when the edge record and the
+// expression qualify, _backend_hip.py `declstruct2`): the record type of two
+// edges side by side, for two evaluations of the microkernel per call
+template<class K, class = void> struct packed_edge {
+    constexpr static bool value = false;
+    using type = void;
+};
+template<class K> struct packed_edge<K, std::void_t<typename K::packed_edge_t>> {
+    constexpr static bool value = true;
+    using type = typename K::packed_edge_t;
+};
+
 template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB, bool NGRAD, bool MAXIMIN, class LAY, class Graph, class NodeK, class EdgeK, class PStart>
 struct oc_solver {
     constexpr static bool STATIC = LAY::is_static;
@@ -285,6 +297,14 @@ struct oc_solver {
     constexpr static unsigned DSTRIDE = 32u;                 // words per row of the dense planes
     constexpr static bool DENSE = FLY && !TAB && GD_WEIGHTED && edge_weight<edge_t>::value && sizeof(edge_t) % 4 == 0 &&
                                   (GD_FLY_DENSE == 2 || (GD_FLY_DENSE == 1 && sizeof(real) == 4 && !NODAL && !NGRAD && !MAXIMIN));
+    // PK2 (dense product, float): the edge microkernel on the records of two
+    // columns at once -- difference, square, scale, the weights' product and
+    // the products with p as packed instructions (v_pk_add_f32, v_pk_mul_f32,
+    // v_pk_fma_f32), 19 vector instructions per trip of four terms against 24
+#ifndef GD_FLY_PK2
+#define GD_FLY_PK2 1
+#endif
+    constexpr static bool PK2 = DENSE && GD_FLY_PK2 != 0 && packed_edge<EdgeK>::value && sizeof(real) == 4;
     constexpr static int NR = R * T;            // row capacity
     constexpr static int NC = DMAX + 1;         // degree classes 0..DMAX
     constexpr static int NCP = NC * NC;         // degree-pair rectangles
@@ -1074,35 +1094,78 @@ struct oc_solver {
                             for (int c = 0; c < CW; ++c)
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) part[c][u] = 0;
+                            // graph 1's record in both halves of a packed one
+                            [[maybe_unused]] std::conditional_t<PK2, typename packed_edge<EdgeK>::type, int> e1p{};
+                            if constexpr (PK2) {
+                                static_assert(sizeof(e1p) == 2 * sizeof(edge_t), "packed edge record: two records, leaf by leaf");
+                                unsigned w1[EW], w2[2 * EW];
+                                __builtin_memcpy(w1, &e1, sizeof(edge_t));
+#pragma unroll
+                                for (unsigned d = 0; d < EW; ++d) w2[2 * d] = w2[2 * d + 1] = w1[d];
+                                __builtin_memcpy(&e1p, w2, sizeof(e1p));
+                            }
+                            // one trip: four columns of graph 2 against e1.
+                            // word(d * 4 + u): word d of the record of column u;
+                            // pat: LDS address of p[j1, first column].  (The last
+                            // trip reads up to three cells behind the row of p --
+                            // the next row, the padding column or the cells
+                            // behind the vector, all of them numbers (zeroed at
+                            // the start of the launch, the host sizes p four cells
+                            // longer): their records have weight 0.  Clamped
+                            // columns cost a scalar select and a register move per
+                            // term.)
+                            auto trip = [&](auto const &word, unsigned pat) {
+                                if constexpr (PK2) {
+                                    using edge2_t = typename packed_edge<EdgeK>::type;
+#pragma unroll
+                                    for (int h = 0; h < 2; ++h) {
+                                        unsigned w2[2 * EW];
+#pragma unroll
+                                        for (unsigned d = 0; d < EW; ++d) {
+                                            w2[2 * d] = word(d * 4u + 2u * (unsigned)h);
+                                            w2[2 * d + 1] = word(d * 4u + 2u * (unsigned)h + 1u);
+                                        }
+                                        edge2_t e2p;
+                                        __builtin_memcpy(&e2p, w2, sizeof(edge2_t));
+                                        real pe[2][CW];
+                                        load_elem_at<CW>(pat + 2u * (unsigned)h * ELEM, pe[0]);   // the same address in every lane
+                                        load_elem_at<CW>(pat + (2u * (unsigned)h + 1u) * ELEM, pe[1]);
+                                        const auto e = ek(e1p, e2p);
+#pragma unroll
+                                        for (int c = 0; c < CW; ++c) {
+                                            part[c][2 * h] += real(lane_of(e, 0)) * pe[0][c];
+                                            part[c][2 * h + 1] += real(lane_of(e, 1)) * pe[1][c];
+                                        }
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int u = 0; u < 4; ++u) {
+                                        unsigned words[EW];
+#pragma unroll
+                                        for (unsigned d = 0; d < EW; ++d) words[d] = word(d * 4u + (unsigned)u);
+                                        edge_t e2;
+                                        __builtin_memcpy(&e2, words, sizeof(edge_t));
+                                        real pe[CW];
+                                        load_elem_at<CW>(pat + (unsigned)u * ELEM, pe);
+                                        const real e = real(ek(e1, e2));
+#pragma unroll
+                                        for (int c = 0; c < CW; ++c) part[c][u] += e * pe[c];
+                                    }
+                                }
+                            };
+                            // (j2 is uniform: the block address and the columns
+                            // of p are scalar arithmetic.  This lane's column of
+                            // graph 2's records is the same for every j1; kept in
+                            // registers for the row batch -- 64 of them, the trips
+                            // unrolled to the 32-node limit behind uniform
+                            // branches -- the kernels fell from five waves per
+                            // SIMD to three and lost: 7.9 against 9.8 M pairs/s,
+                            // scripts/sessions/r4_session25.sh.  The loop is bound
+                            // by the vector pipe -- four v_exp_f32 at quarter rate
+                            // are half of a trip -- not by these reads.)
                             for (unsigned j2 = 0; j2 < (unsigned)n2; j2 += 4) {
-                                // (j2 is uniform: the block address and the clamped
-                                // columns of p are scalar arithmetic)
                                 unsigned const *const blk = e2lane + j2 * (EW * DSTRIDE);
-                                edge_t e2[4];
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    // (columns beyond n2 - 1 of the last trip: zero rows,
-                                    // weight 0)
-                                    unsigned words[EW];
-#pragma unroll
-                                    for (unsigned d = 0; d < EW; ++d) words[d] = blk[(d * 4u + (unsigned)u) * DSTRIDE];
-                                    __builtin_memcpy(&e2[u], words, sizeof(edge_t));
-                                }
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    // (the last trip reads up to three cells behind the
-                                    // row of p -- the next row, the padding column or
-                                    // the cells behind the vector, all of them numbers
-                                    // (zeroed at the start of the launch, the host sizes
-                                    // p four cells longer): their records have weight 0.
-                                    // Clamped columns cost a scalar select and a
-                                    // register move per term.)
-                                    real pe[CW];
-                                    load_elem_at<CW>(rowp + (j2 + (unsigned)u) * ELEM, pe);   // the same address in every lane
-                                    const real e = real(ek(e1, e2[u]));
-#pragma unroll
-                                    for (int c = 0; c < CW; ++c) part[c][u] += e * pe[c];
-                                }
+                                trip([&](unsigned w_) { return blk[w_ * DSTRIDE]; }, rowp + j2 * ELEM);
                             }
 #pragma unroll
                             for (int c = 0; c < CW; ++c) acc[c] += (part[c][0] + part[c][1]) + (part[c][2] + part[c][3]);
@@ -1142,6 +1205,12 @@ struct oc_solver {
 #pragma unroll
                             for (int u = 0; u < FLY_U; ++u) part[c][u] = 0;
                         const unsigned blast = b1 - 1u;     // (b1 > b0 inside the loop)
+                        // (as written: with a second instantiation of the
+                        // microkernel in the function -- PK2 -- the loop
+                        // vectoriser interleaved two trips of this body, 168
+                        // registers and 316 bytes of scratch for the whole
+                        // kernel instead of 85 and none)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
                         for (unsigned b = b0; b < b1; b += FLY_U) {
                             real e[FLY_U], pv[C][FLY_U];
 #pragma unroll

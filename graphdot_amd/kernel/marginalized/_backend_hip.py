@@ -147,6 +147,67 @@ def declstruct(dtype, name):
     return f'struct {name} {{' + ' '.join(members) + '};'
 
 
+def packable(dtype):
+    """Can two records of this struct dtype ride in one record of pairs
+    (`declstruct2`)?  Every leaf a 4-byte number, no arrays, no
+    variable-length attributes, no padding."""
+    dtype = np.dtype(dtype)
+    if dtype.names is None:
+        return False
+
+    def leaves(t):
+        n = 0
+        for key in t.names:
+            ft = t.fields[key][0]
+            if key.startswith('$') or _dtype_util.is_array(ft):
+                return -1
+            if _dtype_util.is_object(ft):
+                if ft.itemsize == 0:
+                    continue
+                sub = leaves(ft)
+                if sub < 0:
+                    return -1
+                n += sub
+            elif ft.kind in 'fiu' and ft.itemsize == 4:
+                n += 1
+            else:
+                return -1
+        return n
+    n = leaves(dtype)
+    return n > 0 and 4 * n == dtype.itemsize
+
+
+def declstruct2(dtype, name):
+    """`declstruct` with every 4-byte leaf a pair, ``graphdot::pk2<T>``: two
+    records side by side, leaf by leaf (device/fmath.h; mgk_oc.h evaluates the
+    edge microkernel of the dense product on two terms at once)."""
+    dtype = np.dtype(dtype)
+    members = []
+    for key in dtype.names:
+        ft = dtype.fields[key][0]
+        if _dtype_util.is_object(ft):
+            if ft.itemsize == 0:
+                members.append(f'constexpr static _empty {key} {{}};')
+            else:
+                members.append(declstruct2(ft, f'{name}_{key}')[:-1]
+                               + f' {key};')
+        else:
+            members.append(f'graphdot::pk2<{ft.name}> {key};')
+    return f'struct {name} {{' + ' '.join(members) + '};'
+
+
+#: calls a packed evaluation can make (overloaded for pairs in device/fmath.h)
+_PACKED_CALLS = re.compile(
+    r'graphdot::(?:exp|ipow<\d+>|ripow<\d+>)$')
+
+
+def packed_expression(expr):
+    """Does the generated expression only call what device/fmath.h overloads
+    for pairs?"""
+    calls = re.findall(r'([A-Za-z_][\w:]*(?:<[^<>()]*>)?)\s*\(', expr)
+    return all(_PACKED_CALLS.match(c) for c in calls)
+
+
 def widen_theta(dtype, real):
     """theta structs hold float32 hyperparameters in the reference; an fp64
     build stores them as float64."""
@@ -918,16 +979,28 @@ void ${name}(params_t prm) {
         """Full translation unit for the given solver variants."""
         pd = self._params_dtype(node_kernel, edge_kernel, p)
         pfd = self._params_fd_dtype(node_kernel, edge_kernel, p)
+        edge_code = self.gencode_kernel(edge_kernel, 'edge_kernel', self.real)
+        edge2_t = ''
+        # float builds: the edge microkernel on two records at once where the
+        # record and the expression allow it (mgk_oc.h, dense product)
+        if (np.dtype(self.real) == np.float32 and packable(edge_t)
+                and os.environ.get('GD_PACKED_EDGES', '1') != '0'
+                and packed_expression(to_real_expr(
+                    edge_kernel.gen_expr('x1', 'x2')[0], 'float32'))):
+            edge2_t = '\n' + declstruct2(edge_t, 'edge2_t')
+            head = 'struct edge_kernel_t : edge_kernel_theta_t {\n'
+            assert head in edge_code
+            edge_code = edge_code.replace(
+                head, head + '    using packed_edge_t = edge2_t;\n', 1)
         return Template(_TEMPLATE).render(
             real=_real_name(self.real),
             weighted='1' if weighted else '0',
             wpb=WPB1,
             node_t=declstruct(node_t, 'node_t'),
-            edge_t=declstruct(edge_t, 'edge_t'),
+            edge_t=declstruct(edge_t, 'edge_t') + edge2_t,
             node_kernel=self.gencode_kernel(node_kernel, 'node_kernel',
                                             self.real),
-            edge_kernel=self.gencode_kernel(edge_kernel, 'edge_kernel',
-                                            self.real),
+            edge_kernel=edge_code,
             p_start=self.gencode_probability(p, 'p_start', self.real),
             node_size=np.dtype(node_t).itemsize,
             edge_size=max(np.dtype(edge_t).itemsize, 1),

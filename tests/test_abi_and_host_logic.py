@@ -617,3 +617,52 @@ def test_dense_graphs_classify_into_the_on_the_fly_variants():
                 assert dgs[a].n_node * dgs[bb].n_node <= 64 * v.W * v.R
     assert np.array_equal(got[True][0], got[False][0])
     assert np.array_equal(got[True][1], got[False][1])
+
+
+def test_packed_edge_records_are_offered_only_where_they_are_exact():
+    """The dense product evaluates the edge microkernel on two records at once
+    when the backend prints `edge2_t` (_backend_hip.py declstruct2): only for
+    records made of 4-byte numbers without padding, and only for expressions
+    that call nothing but what device/fmath.h overloads for pairs."""
+    from graphdot_amd.kernel.marginalized._backend_hip import (
+        HIPBackend, declstruct2, packable, packed_expression)
+    import cases
+    f4 = np.dtype([('weight', np.float32),
+                   ('label', np.dtype([('length', np.float32),
+                                       ('order', np.int32)], align=True))],
+                  align=True)
+    assert packable(f4)
+    text = declstruct2(f4, 'edge2_t')
+    assert text == ('struct edge2_t {graphdot::pk2<float32> weight; '
+                    'struct edge2_t_label {graphdot::pk2<float32> length; '
+                    'graphdot::pk2<int32> order;} label;};')
+    for bad in (np.dtype([('a', np.float64)]),                    # 8-byte leaf
+                np.dtype([('a', np.float32), ('b', np.int8)], align=True),
+                np.dtype([('a', np.float32, (2,))]),              # array
+                np.dtype([('a', np.bool_)]), np.dtype(np.float32)):
+        assert not packable(bad), bad
+    assert packed_expression(
+        '((x1.weight * x2.weight) * (graphdot::exp(-0.5F*graphdot::ipow<2>('
+        'x1.label.length - x2.label.length)/graphdot::ipow<2>(label.length.'
+        'length_scale))))')
+    assert packed_expression('(x1.a == x2.a ? 1.0f : a.h)')
+    assert not packed_expression('graphdot::pow(x1.a, 2.5f)')
+    assert not packed_expression('dotproduct(x1.a, x2.a)')
+    assert not packed_expression('sqrtf(x1.a * x2.a)')
+    # the rendered translation units: the weighted SquareExponential edge
+    # kernel of the dense molecular set gets the packed record in float, not
+    # in double, and GD_PACKED_EDGES=0 switches it off
+    kn, ke, q = cases.tang2019_kernels()
+    G = cases.tang2019_graphs(3)
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    from graphdot_amd.kernel.marginalized._backend_hip import OCVariant
+    from graphdot_amd.microkernel import TensorProduct, Product
+    for real, want in ((np.float32, True), (np.float64, False)):
+        be = HIPBackend(real=real)
+        k = MarginalizedGraphKernel(kn, ke, q=q, backend=be)
+        dg = [be._register_graph(g) for g in G]
+        ke2 = TensorProduct(weight=Product(), label=ke)
+        src = be.render_source(kn, ke2, k.p, dg[0].node_t, dg[0].edge_t,
+                               [OCVariant(4, 0, 1, 0)], 1, weighted=True)
+        assert ('using packed_edge_t = edge2_t;' in src) is want
+        assert ('struct edge2_t {' in src) is want
