@@ -6,7 +6,10 @@
 // Python -- a dictionary lookup per graph and column, a type check per graph,
 // numpy.concatenate of a thousand small arrays per column -- was 3 ms of the
 // 4.5 ms that packing 1000 molecules took; here it is one pass over the
-// objects through the C API and the buffer protocol.
+// objects through the C APIs of CPython and numpy (the columns are ndarrays:
+// data pointer, size and type descriptor are struct members -- acquiring a
+// buffer with a format string per column and graph, 14 000 of them for a
+// thousand molecules, was most of the pass).
 //
 //   collect(graphs, attr, keys) -> (columns, lengths, formats) | None
 //     graphs: list of Graph; attr: "nodes" / "edges"; keys: tuple of column
@@ -14,12 +17,15 @@
 //     graphs back to back; lengths: bytes of int64[len(graphs)], rows per
 //     graph; formats: tuple of (struct format, itemsize) per column.
 //   None: some graph's table has other columns, another element type, a
-//   non-contiguous or object column -- the caller takes the Python path.
+//   column that is not a one-dimensional contiguous ndarray of numbers -- the
+//   caller takes the Python path.
 //
 // Role in the reference: the per-graph table handling at the top of
 // OctileGraph.__init__ (graphdot/kernel/marginalized/_octilegraph.py:37-105).
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#define NPY_NO_DEPRECATED_API NPY_1_7_API_VERSION
+#include <numpy/arrayobject.h>
 
 #include <cstdint>
 #include <cstring>
@@ -28,11 +34,27 @@
 
 namespace {
 
+// a column as the packer can take it: a one-dimensional C-contiguous ndarray
+// without object references; its type descriptor (borrowed) or nullptr
+PyArray_Descr *plain_column(PyObject *col) {
+    if (!PyArray_Check(col)) return nullptr;
+    PyArrayObject *a = reinterpret_cast<PyArrayObject *>(col);
+    if (PyArray_NDIM(a) != 1 || !PyArray_IS_C_CONTIGUOUS(a)) return nullptr;
+    PyArray_Descr *d = PyArray_DESCR(a);
+    if (PyDataType_REFCHK(d) || PyDataType_ELSIZE(d) <= 0) return nullptr;
+    return d;
+}
+
+bool same_type(PyArray_Descr *a, PyArray_Descr *b) {
+    return a == b || PyArray_EquivTypes(a, b);
+}
+
 PyObject *collect(PyObject *, PyObject *args) {
     PyObject *graphs, *attr, *keys;
     if (!PyArg_ParseTuple(args, "O!UO!", &PyList_Type, &graphs, &attr, &PyTuple_Type, &keys)) return nullptr;
     const Py_ssize_t G = PyList_GET_SIZE(graphs), K = PyTuple_GET_SIZE(keys);
     std::vector<std::vector<char>> cols((size_t)K);
+    std::vector<PyArray_Descr *> descr((size_t)K, nullptr);   // the first graph's (it stays alive: borrowed)
     std::vector<std::string> fmt((size_t)K);
     std::vector<Py_ssize_t> isz((size_t)K, 0);
     std::vector<int64_t> lengths((size_t)G, 0);
@@ -68,33 +90,28 @@ PyObject *collect(PyObject *, PyObject *args) {
                 mismatch = true;
                 break;
             }
-            Py_buffer view;
-            if (PyObject_GetBuffer(col, &view, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS) != 0) {
-                PyErr_Clear();      // not a contiguous buffer: the Python path decides
-                mismatch = true;
-                break;
-            }
-            const char *f = view.format ? view.format : "B";
-            bool ok = view.ndim == 1 && view.itemsize > 0 && std::strchr(f, 'O') == nullptr;
+            PyArray_Descr *d = plain_column(col);      // not one: the Python path decides
+            bool ok = d != nullptr;
             if (ok && g == 0) {
-                fmt[(size_t)k] = f;
-                isz[(size_t)k] = view.itemsize;
+                descr[(size_t)k] = d;
+                fmt[(size_t)k] = std::string(1, d->type);
+                isz[(size_t)k] = (Py_ssize_t)PyDataType_ELSIZE(d);
             } else if (ok) {
-                ok = fmt[(size_t)k] == f && isz[(size_t)k] == view.itemsize;
+                ok = same_type(descr[(size_t)k], d);
             }
-            const int64_t n = ok ? (int64_t)(view.len / view.itemsize) : -1;
+            PyArrayObject *a = reinterpret_cast<PyArrayObject *>(col);
+            const int64_t n = ok ? (int64_t)PyArray_DIM(a, 0) : -1;
             if (ok && rows < 0) rows = n;
             if (!ok || n != rows) {
-                PyBuffer_Release(&view);
                 mismatch = true;
                 break;
             }
+            const size_t len = (size_t)n * (size_t)isz[(size_t)k];
             std::vector<char> &out = cols[(size_t)k];
             // (room for every graph at the size of the first ones: one
             // allocation per column instead of a dozen doublings)
-            if (g == 1) out.reserve((size_t)(out.size() + (size_t)view.len) * (size_t)G / 2 + 64);
-            out.insert(out.end(), (const char *)view.buf, (const char *)view.buf + view.len);
-            PyBuffer_Release(&view);
+            if (g == 1) out.reserve((out.size() + len) * (size_t)G / 2 + 64);
+            out.insert(out.end(), (const char *)PyArray_DATA(a), (const char *)PyArray_DATA(a) + len);
         }
         Py_DECREF(data);
         lengths[(size_t)g] = rows < 0 ? 0 : rows;
@@ -131,7 +148,7 @@ PyObject *collect(PyObject *, PyObject *args) {
 
 // same_tables(graphs, attr) -> True | None.  True: the table `attr` of every
 // graph has the first graph's columns, in its order, each a one-dimensional
-// contiguous buffer of the same element format -- i.e. DataFrame.rowtype() is
+// contiguous array of numbers of the same type -- i.e. DataFrame.rowtype() is
 // the same for all of them (what Graph.has_unified_types establishes with two
 // rowtype() calls per graph, 3-4 ms per 1000 graphs on the first call).  None:
 // anything else -- the caller decides in Python.
@@ -142,8 +159,7 @@ PyObject *same_tables(PyObject *, PyObject *args) {
     PyObject *data_name = PyUnicode_InternFromString("_data");
     if (!data_name) return nullptr;
     std::vector<PyObject *> keys;         // the first graph's column names (owned)
-    std::vector<std::string> fmt;
-    std::vector<Py_ssize_t> isz;
+    std::vector<PyArray_Descr *> descr;   // ... and element types (borrowed: graph 0 stays alive)
     bool same = true, error = false;
     for (Py_ssize_t g = 0; g < G && same && !error; ++g) {
         PyObject *frame = PyObject_GetAttr(PyList_GET_ITEM(graphs, g), attr);
@@ -169,23 +185,15 @@ PyObject *same_tables(PyObject *, PyObject *args) {
                     break;
                 }
             }
-            Py_buffer view;
-            if (PyObject_GetBuffer(col, &view, PyBUF_FORMAT | PyBUF_C_CONTIGUOUS) != 0) {
-                PyErr_Clear();
-                same = false;
-                break;
-            }
-            const char *f = view.format ? view.format : "B";
-            bool ok = view.ndim == 1 && view.itemsize > 0 && std::strchr(f, 'O') == nullptr;
+            PyArray_Descr *d = plain_column(col);
+            bool ok = d != nullptr;
             if (ok && g == 0) {
                 Py_INCREF(key);
                 keys.push_back(key);
-                fmt.emplace_back(f);
-                isz.push_back(view.itemsize);
+                descr.push_back(d);
             } else if (ok) {
-                ok = fmt[(size_t)k] == f && isz[(size_t)k] == view.itemsize;
+                ok = same_type(descr[(size_t)k], d);
             }
-            PyBuffer_Release(&view);
             if (!ok) same = false;
             ++k;
         }
@@ -208,4 +216,7 @@ PyModuleDef module = {PyModuleDef_HEAD_INIT, "_gdcollect", "table gathering for 
 
 }  // namespace
 
-PyMODINIT_FUNC PyInit__gdcollect(void) { return PyModule_Create(&module); }
+PyMODINIT_FUNC PyInit__gdcollect(void) {
+    import_array();      // (returns nullptr with an exception set if numpy cannot be bound)
+    return PyModule_Create(&module);
+}

@@ -292,7 +292,8 @@ def _build_collector():
             tmp = out + f'.{os.getpid()}.tmp'
             r = subprocess.run(
                 [os.environ.get('CXX', 'g++'), '-O2', '-fPIC', '-shared',
-                 '-std=c++17', f'-I{inc}', src, '-o', tmp],
+                 '-std=c++17', f'-I{inc}', f'-I{np.get_include()}', src,
+                 '-o', tmp],
                 capture_output=True, text=True)
             if r.returncode != 0:
                 return False
