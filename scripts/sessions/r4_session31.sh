@@ -1,4 +1,6 @@
 # two-wave static layouts for the pairs of five and more row batches (GD_OC_STATIC2=1)
+# (prototype removed again, DESIGN.md "tried and dropped": OCStatic2 / static2_layouts in _backend_hip.py,
+#  a two-instantiation entry point, W <= 2 static layouts in mgk_oc.h)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 export GD_OC_STATIC2=1
 timeout 1200 python -m pytest tests/test_parity_gpu.py -q -x -k "full_size_gram or self_similarity or cross_similarity or fp64_build" 2>&1 | tail -4
