@@ -69,16 +69,35 @@ def _ptr(a):
 # --------------------------------------------------------------------------
 # graph -> arrays (reference: _octilegraph.py:107-157)
 # --------------------------------------------------------------------------
+def _row64(row):
+    """The row with its numpy scalars as Python numbers: the microkernels are
+    evaluated in float64 whatever type the table stores an attribute in.
+    (The frames keep floats as float32, and numpy -- NEP 50 -- keeps float32
+    arithmetic float32 when the other operand is a Python float: kernel values
+    6e-8 off, which a double build of the solver is held to 1e-9 against;
+    found by scripts/fuzz_parity.py.)"""
+    def wide(v):
+        if isinstance(v, np.floating):
+            return float(v)
+        if isinstance(v, np.integer):
+            return int(v)
+        if isinstance(v, np.ndarray) and v.dtype.kind == 'f':
+            return v.astype(np.float64)
+        return v
+    return type(row)(*[wide(v) for v in tuple(row)])
+
+
 class PairSide:
     """Directed-nonzero view of one graph: both orientations of every edge,
     a self loop once; degree = sum of incident weights (self loop once),
     isolated nodes get degree 1."""
 
-    def __init__(self, g):
+    def __init__(self, g, wide=False):
         self.g = g
         self.n = n = len(g.nodes)
         order = np.argsort(np.asarray(g.nodes['!i']))
-        rows = list(g.nodes.rows())
+        widen = _row64 if wide else (lambda r: r)
+        rows = [widen(r) for r in g.nodes.rows()]
         self.node_rows = [rows[k] for k in order]       # indexed by node id
         self.nodes_sorted = g.nodes[[c for c in g.nodes.columns]]
         ei = np.asarray(g.edges['!i']).astype(np.int64)
@@ -86,7 +105,7 @@ class PairSide:
         self.weighted = '!w' in g.edges
         w = (np.asarray(g.edges['!w']).astype(np.float64) if self.weighted
              else np.ones(len(ei)))
-        erows = list(g.edges.rows())
+        erows = [widen(r) for r in g.edges.rows()]
         di, dj, dw, dr = [], [], [], []
         deg = np.zeros(n)
         for k in range(len(ei)):
@@ -106,11 +125,33 @@ class PairSide:
         self.nnz = len(di)
 
 
+#: evaluate the microkernels on float64 copies of the attributes (`_row64`)?
+#: Off by default: the golden vectors of tests/golden/ were recorded from the
+#: reference's Python solver, which evaluates them in the attributes' storage
+#: type, and the oracle is pinned to them at 1e-11.  On (`with wide_rows():`)
+#: for holding a DOUBLE build of the solver to 1e-9 on attributes that
+#: float32 arithmetic does not evaluate exactly.
+WIDE_ROWS = False
+
+
+class wide_rows:
+    """Context: microkernels evaluated in float64 (see WIDE_ROWS)."""
+
+    def __enter__(self):
+        global WIDE_ROWS
+        self.was, WIDE_ROWS = WIDE_ROWS, True
+
+    def __exit__(self, *exc):
+        global WIDE_ROWS
+        WIDE_ROWS = self.was
+
+
 def _side(g):
+    key = 'oracle_side64' if WIDE_ROWS else 'oracle_side'
     try:
-        return g.cookie['oracle_side']
+        return g.cookie[key]
     except KeyError:
-        s = g.cookie['oracle_side'] = PairSide(g)
+        s = g.cookie[key] = PairSide(g, wide=WIDE_ROWS)
         return s
 
 

@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the HIP path against the dense fp64 oracle: random
+graph families (trees, rings with chords, dense weighted graphs, stars, single
+edges, one-node graphs mixed in), random sizes up to 36 nodes, random kernel
+composites, q, arithmetic and call mode (symmetric / X x Y, nodal, lmin = 1,
+diag, value + gradient) -- every round a fresh small problem, every result
+held to the oracle.  What the fixed cases of tests/ do not enumerate: odd
+sizes next to each other in one job list, degenerate partners, every solver
+family meeting in one launch order.
+
+    python scripts/fuzz_parity.py [rounds] [--seed=N]
+"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'tests'))
+import networkx as nx                                               # noqa: E402
+import numpy as np                                                  # noqa: E402
+from graphdot_amd.graph import Graph                                # noqa: E402
+from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel  # noqa
+from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend  # noqa
+from graphdot_amd.microkernel import (                              # noqa: E402
+    Constant, KroneckerDelta, SquareExponential, TensorProduct)
+from oracle import mgk as oracle                                    # noqa: E402
+
+rounds = int(next((a for a in sys.argv[1:] if not a.startswith('--')), 40))
+seed = int(next((a.split('=')[1] for a in sys.argv[1:]
+                 if a.startswith('--seed=')), 0))
+rng = np.random.default_rng(seed)
+
+
+def random_graph(kind, weighted):
+    r = int(rng.integers(1 << 30))
+    if kind == 'tree':
+        n = int(rng.integers(2, 30))
+        g = nx.random_labeled_tree(n, seed=r) \
+            if hasattr(nx, 'random_labeled_tree') else nx.path_graph(n)
+    elif kind == 'ring':
+        g = nx.newman_watts_strogatz_graph(int(rng.integers(5, 36)),
+                                           int(rng.choice([2, 4])), 0.15, seed=r)
+    elif kind == 'dense':
+        n = int(rng.integers(3, 33))
+        g = nx.gnp_random_graph(n, float(rng.uniform(0.6, 1.0)), seed=r)
+        for u in range(n - 1):
+            g.add_edge(u, u + 1)
+    elif kind == 'star':
+        g = nx.star_graph(int(rng.integers(2, 20)))
+    elif kind == 'edge':
+        g = nx.path_graph(2)
+    else:                                   # one node, one self loop
+        g = nx.Graph()
+        g.add_edge(0, 0)
+    for v in g.nodes:
+        g.nodes[v]['category'] = int(rng.integers(1, 4))
+        g.nodes[v]['radius'] = float(rng.choice([1.0, 1.5, 2.0]))
+    for e in g.edges:
+        g.edges[e]['w'] = float(rng.choice([0.5, 1.0, 2.0])) if weighted else 1.0
+        g.edges[e]['length'] = float(rng.uniform(0.5, 2.5))
+        g.edges[e]['order'] = int(rng.integers(1, 3))
+    return Graph.from_networkx(g, weight='w' if weighted else None)
+
+
+def random_kernels():
+    node = [TensorProduct(category=KroneckerDelta(float(rng.uniform(0.2, 0.8)))),
+            TensorProduct(category=KroneckerDelta(0.5),
+                          radius=SquareExponential(float(rng.uniform(0.5, 2.0)))),
+            ][int(rng.integers(2))]
+    edge = [TensorProduct(length=SquareExponential(float(rng.uniform(0.3, 2.0)))),
+            TensorProduct(order=KroneckerDelta(float(rng.uniform(0.3, 0.9)))),
+            TensorProduct(order=KroneckerDelta(0.6),
+                          length=SquareExponential(1.0)),
+            Constant(1.0)][int(rng.integers(4))]
+    return node, edge
+
+
+def check(name, got, want, rtol, atol=0.0):
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert np.isfinite(got).all(), name
+    err = np.abs(got - want) - (atol + rtol * np.abs(want))
+    if err.max() > 0:
+        at = np.unravel_index(np.argmax(err), err.shape)
+        print('worst entry', at, 'got', got[at], 'want', want[at],
+              'relative', got[at] / want[at] - 1, flush=True)
+        print('entries beyond the tolerance:', int((err > 0).sum()), 'of',
+              err.size, np.argwhere(err > 0)[:12].tolist(), flush=True)
+    assert err.max() <= 0, (name, float(np.abs(got / want - 1).max()))
+
+
+# (double builds are held to 2e-9: the oracle must not evaluate the
+# microkernels in the float32 the frames store the attributes in)
+oracle.WIDE_ROWS = True
+t0 = time.time()
+kinds = ['tree', 'ring', 'dense', 'dense', 'star', 'edge', 'loop']
+stats = {}
+for it in range(rounds):
+    weighted = bool(rng.integers(2))
+    family = rng.choice(['mixed', 'dense', 'sparse'])
+    pool = {'mixed': kinds, 'dense': ['dense', 'dense', 'star'],
+            'sparse': ['tree', 'ring', 'edge']}[family]
+    G = Graph.unify_datatype([random_graph(rng.choice(pool), weighted)
+                              for _ in range(int(rng.integers(3, 9)))])
+    kn, ke = random_kernels()
+    q = float(rng.choice([0.01, 0.05, 0.2, 0.5]))
+    real = [np.float32, np.float64][int(rng.integers(2))]
+    f64 = real is np.float64
+    be = HIPBackend(real=real)
+    k = MarginalizedGraphKernel(kn, ke, q=q, backend=be,
+                                **({'ftol': 1e-13, 'gtol': 1e-12} if f64 else {}))
+    # (double: the device keeps the degrees as float32 sums like the
+    # reference -- exact for the dyadic weights used here)
+    rtol = 2e-9 if f64 else 2e-5
+    mode = rng.choice(['sym', 'xy', 'nodal', 'lmin', 'diag', 'grad'])
+    stats[(family, mode, 'f64' if f64 else 'f32')] = \
+        stats.get((family, mode, 'f64' if f64 else 'f32'), 0) + 1
+    tag = f'round {it} seed {seed}: {family} {mode} {real.__name__} q={q} ' \
+          f'weighted={weighted} sizes={[len(g.nodes) for g in G]} ' \
+          f'{kn!r} {ke!r}'
+    try:
+        if mode == 'sym':
+            check(tag, k(G), oracle.gram(G, kn, ke, q=q), rtol)
+        elif mode == 'xy':
+            h = max(1, len(G) // 2)
+            check(tag, k(G[:h], G[h:]), oracle.gram(G[:h], kn, ke, Y=G[h:], q=q), rtol)
+        elif mode == 'nodal':
+            ref = oracle.gram(G[:4], kn, ke, q=q, nodal=True)
+            check(tag, k(G[:4], nodal=True), ref, rtol, atol=rtol * np.abs(ref).max())
+        elif mode == 'lmin':
+            check(tag, k(G, lmin=1), oracle.gram(G, kn, ke, q=q, lmin=1), 10 * rtol)
+        elif mode == 'diag':
+            check(tag, k.diag(G), np.diag(oracle.gram(G, kn, ke, q=q)), rtol)
+        else:
+            K, dK = k(G, eval_gradient=True)
+            Ko, dKo = oracle.gram(G, kn, ke, q=q, eval_gradient=True)
+            check(tag, K, Ko, rtol)
+            dKo = dKo[:, :, np.asarray(k.active_theta_mask)]
+            scale = np.abs(dKo).max(axis=(0, 1)) + 1e-300
+            dev = (np.abs(dK - dKo).max(axis=(0, 1)) / scale).max()
+            assert np.isfinite(dK).all() and dev < (1e-6 if f64 else 3e-3), \
+                (tag, float(dev))
+    except AssertionError:
+        print('FAILED', tag, flush=True)
+        plan = getattr(be, 'last_plan', None)
+        if plan is not None:
+            print('launches:', [(be.kernel_name(L['variant'], plan.C), L['count'])
+                                for L in plan.launches], flush=True)
+        raise
+print(f'fuzz ok: {rounds} rounds in {time.time() - t0:.0f} s; '
+      f'{len(stats)} (family, mode, arithmetic) combinations')

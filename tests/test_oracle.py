@@ -234,3 +234,43 @@ def test_maximin_restatement_vs_reference_solutions():
          for p in fx['pairs'] if p['i'] != p['j']]
     assert 1e-4 < max(x.max() for x in d) < 1e-2
     assert all(x[0] == 0 for x in d)        # starting probability: same form
+
+
+def test_microkernels_in_float64_on_request():
+    """The frames store float attributes as float32, and the reference's
+    Python solver -- the source of the golden vectors -- evaluates the
+    microkernels in that type (numpy keeps float32 arithmetic float32 next to
+    Python floats).  `oracle.wide_rows()` evaluates them on float64 copies:
+    what a DOUBLE build of the device solver is held to.  The two differ by
+    float32 rounding of the kernel values, and the default stays the pinned
+    one."""
+    import networkx as nx
+    from graphdot_amd.graph import Graph
+    from graphdot_amd.microkernel import (KroneckerDelta, SquareExponential,
+                                          TensorProduct)
+    from oracle import mgk
+    g = nx.cycle_graph(5)
+    for v in g.nodes:
+        g.nodes[v]['radius'] = [1.0, 1.5, 2.0][v % 3]
+    for e in g.edges:
+        g.edges[e]['w'] = 1.0
+        g.edges[e]['length'] = 0.7 + 0.31 * e[0]
+    G = Graph.unify_datatype([Graph.from_networkx(g, weight='w')])
+    assert G[0].nodes._data['radius'].dtype == np.float32
+    kn = TensorProduct(radius=SquareExponential(0.7454643033504345))
+    ke = TensorProduct(length=SquareExponential(0.8810140899648293))
+    assert mgk.WIDE_ROWS is False
+    narrow = mgk.gram(G, kn, ke, q=0.05)
+    with mgk.wide_rows():
+        assert mgk.WIDE_ROWS is True
+        wide = mgk.gram(G, kn, ke, q=0.05)
+    assert mgk.WIDE_ROWS is False
+    again = mgk.gram(G, kn, ke, q=0.05)
+    assert np.array_equal(narrow, again)
+    rel = abs(float(wide[0, 0] / narrow[0, 0]) - 1)
+    assert 1e-10 < rel < 1e-6, rel
+    # float64 evaluation by hand: the same numbers as wide rows
+    r = np.asarray(G[0].nodes._data['radius'], dtype=np.float64)
+    V = np.exp(-0.5 * (r[:, None] - r[None, :])**2 / 0.7454643033504345**2)
+    s = mgk.PairSide(G[0], wide=True)
+    assert np.allclose(mgk.node_table(kn, s, s), V, rtol=1e-15)

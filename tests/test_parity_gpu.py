@@ -900,6 +900,60 @@ def test_mixed_degree_sets_cross_every_solver_family(backend):
                                       2e-3, 2e-5) <= 1.0
 
 
+def test_double_build_on_systems_of_a_few_rows():
+    """Pairs of one- and two-node graphs in the double build against direct
+    dense solves (microkernels evaluated in float64, `oracle.wide_rows`) to
+    1e-12.  With the step lengths of the iteration rounded to float (mgk_oc.h
+    FSCAL) CG does not end after N steps any more: stopped there, the value
+    of two one-node graphs came out as float(4/3) -- 6e-8 off; the double
+    build iterates on (found by scripts/fuzz_parity.py)."""
+    import networkx as nx
+    rng = np.random.default_rng(12)
+    gs = []
+    for kind in ('loop', 'loop', 'edge', 'edge', 'path3', 'ring5', 'star4'):
+        g = nx.Graph()
+        if kind == 'loop':
+            g.add_edge(0, 0)
+        elif kind == 'edge':
+            g.add_edge(0, 1)
+        elif kind == 'path3':
+            g = nx.path_graph(3)
+        elif kind == 'ring5':
+            g = nx.cycle_graph(5)
+        else:
+            g = nx.star_graph(4)
+        for v in g.nodes:
+            g.nodes[v]['category'] = int(rng.integers(1, 3))
+            g.nodes[v]['radius'] = float(rng.choice([1.0, 1.5, 2.0]))
+        for e in g.edges:
+            g.edges[e]['w'] = float(rng.choice([0.5, 1.0, 2.0]))
+            g.edges[e]['length'] = float(rng.uniform(0.5, 2.5))
+        gs.append(Graph.from_networkx(g, weight='w'))
+    G = Graph.unify_datatype(gs)
+    knode = TensorProduct(category=KroneckerDelta(0.5),
+                          radius=SquareExponential(1.0356079415780726))
+    kedge = TensorProduct(length=SquareExponential(0.8810140899648293))
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    for q in (0.5, 0.05, 0.01):
+        k = MarginalizedGraphKernel(knode, kedge, q=q, ftol=1e-13,
+                                    backend=HIPBackend(real=np.float64))
+        with oracle.wide_rows():
+            ref = oracle.gram(G, knode, kedge, q=q)
+            refn = oracle.gram(G, knode, kedge, q=q, nodal=True)
+            ref1 = oracle.gram(G, knode, kedge, q=q, lmin=1)
+        K = k(G)
+        assert np.allclose(K, ref, rtol=1e-12, atol=0), np.abs(K / ref - 1).max()
+        Kn = k(G, nodal=True)
+        assert np.allclose(Kn, refn, rtol=1e-12, atol=1e-13 * np.abs(refn).max())
+        K1 = k(G, lmin=1)
+        assert np.allclose(K1, ref1, rtol=1e-11, atol=1e-13 * np.abs(ref).max())
+        # (the value + gradient solve stops at the reference's fixed
+        # sqrt(rTr) < 1e-10 * 2N, marginalized_kernel.h:769)
+        K2, dK = k(G, eval_gradient=True)
+        assert np.allclose(K2, ref, rtol=1e-8, atol=0), np.abs(K2 / ref - 1).max()
+        assert np.isfinite(dK).all()
+
+
 @pytest.mark.parametrize('sizes', [(5, 8, 28, 29, 30, 31, 32),
                                    (4, 17, 24, 32, 33)])
 def test_dense_product_at_the_row_limit(sizes):
