@@ -21,7 +21,8 @@ from graphdot_amd.graph import Graph                                # noqa: E402
 from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel  # noqa
 from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend  # noqa
 from graphdot_amd.microkernel import (                              # noqa: E402
-    Constant, KroneckerDelta, SquareExponential, TensorProduct)
+    Additive, Constant, KroneckerDelta, RationalQuadratic, SquareExponential,
+    TensorProduct)
 from oracle import mgk as oracle                                    # noqa: E402
 
 rounds = int(next((a for a in sys.argv[1:] if not a.startswith('--')), 40))
@@ -39,6 +40,9 @@ def random_graph(kind, weighted):
     elif kind == 'ring':
         g = nx.newman_watts_strogatz_graph(int(rng.integers(5, 36)),
                                            int(rng.choice([2, 4])), 0.15, seed=r)
+    elif kind == 'bigring':                 # the multi-wave slot variants
+        g = nx.newman_watts_strogatz_graph(int(rng.integers(36, 64)),
+                                           int(rng.choice([4, 6])), 0.1, seed=r)
     elif kind == 'dense':
         n = int(rng.integers(3, 33))
         g = nx.gnp_random_graph(n, float(rng.uniform(0.6, 1.0)), seed=r)
@@ -65,12 +69,20 @@ def random_kernels():
     node = [TensorProduct(category=KroneckerDelta(float(rng.uniform(0.2, 0.8)))),
             TensorProduct(category=KroneckerDelta(0.5),
                           radius=SquareExponential(float(rng.uniform(0.5, 2.0)))),
-            ][int(rng.integers(2))]
+            TensorProduct(category=KroneckerDelta(0.4),
+                          radius=RationalQuadratic(float(rng.uniform(0.5, 2.0)),
+                                                   float(rng.uniform(0.5, 3.0)))),
+            Additive(category=KroneckerDelta(0.3) * 0.5,
+                     radius=SquareExponential(1.2) * 0.5),
+            Constant(1.0),
+            ][int(rng.integers(5))]
     edge = [TensorProduct(length=SquareExponential(float(rng.uniform(0.3, 2.0)))),
             TensorProduct(order=KroneckerDelta(float(rng.uniform(0.3, 0.9)))),
             TensorProduct(order=KroneckerDelta(0.6),
                           length=SquareExponential(1.0)),
-            Constant(1.0)][int(rng.integers(4))]
+            TensorProduct(length=RationalQuadratic(float(rng.uniform(0.5, 2.0)),
+                                                   float(rng.uniform(0.5, 3.0)))),
+            Constant(1.0)][int(rng.integers(5))]
     return node, edge
 
 
@@ -96,9 +108,10 @@ kinds = ['tree', 'ring', 'dense', 'dense', 'star', 'edge', 'loop']
 stats = {}
 for it in range(rounds):
     weighted = bool(rng.integers(2))
-    family = rng.choice(['mixed', 'dense', 'sparse'])
+    family = rng.choice(['mixed', 'dense', 'sparse', 'large'])
     pool = {'mixed': kinds, 'dense': ['dense', 'dense', 'star'],
-            'sparse': ['tree', 'ring', 'edge']}[family]
+            'sparse': ['tree', 'ring', 'edge'],
+            'large': ['bigring', 'bigring', 'ring', 'tree']}[family]
     G = Graph.unify_datatype([random_graph(rng.choice(pool), weighted)
                               for _ in range(int(rng.integers(3, 9)))])
     kn, ke = random_kernels()
@@ -111,7 +124,8 @@ for it in range(rounds):
     # (double: the device keeps the degrees as float32 sums like the
     # reference -- exact for the dyadic weights used here)
     rtol = 2e-9 if f64 else 2e-5
-    mode = rng.choice(['sym', 'xy', 'nodal', 'lmin', 'diag', 'grad'])
+    mode = rng.choice(['sym', 'xy', 'nodal', 'lmin', 'diag', 'diagnodal',
+                       'grad'])
     stats[(family, mode, 'f64' if f64 else 'f32')] = \
         stats.get((family, mode, 'f64' if f64 else 'f32'), 0) + 1
     tag = f'round {it} seed {seed}: {family} {mode} {real.__name__} q={q} ' \
@@ -130,6 +144,10 @@ for it in range(rounds):
             check(tag, k(G, lmin=1), oracle.gram(G, kn, ke, q=q, lmin=1), 10 * rtol)
         elif mode == 'diag':
             check(tag, k.diag(G), np.diag(oracle.gram(G, kn, ke, q=q)), rtol)
+        elif mode == 'diagnodal':
+            ref = oracle.diag(G[:4], kn, ke, q=q, nodal=True)
+            check(tag, k.diag(G[:4], nodal=True), ref, rtol,
+                  atol=rtol * np.abs(ref).max())
         else:
             K, dK = k(G, eval_gradient=True)
             Ko, dKo = oracle.gram(G, kn, ke, q=q, eval_gradient=True)
