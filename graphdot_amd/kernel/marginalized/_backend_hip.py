@@ -1503,6 +1503,8 @@ void ${name}(params_t prm) {
                                 applied[k0] = k2
                         applied[k] = k2
                         break
+        choice = self._fit_launches_into_lds(choice, C, NP, ntask, gbytes,
+                                             gbytes_oc, tab_bytes, oc_only)
         rank_of = np.empty(len(choice), dtype=np.int64)
         by_rank = np.lexsort((-cost, choice))
         # class pairs of equal (variant, cost) share a rank: their jobs stay
@@ -1594,6 +1596,73 @@ void ${name}(params_t prm) {
         out = Partition((jobs, used, order_all, launches))
         out.jobs_sorted, out.merge_map = jobs_sorted, applied
         return out
+
+    #: LDS the kernels declare statically (reduction scratch, rectangle
+    #: tables: mgk_oc.h lds_t, at most ~1.3 KB) -- what the dynamic request of
+    #: a launch must leave free of the 160 KB
+    LDS_STATIC_RESERVE = 2048
+
+    def _launch_lds(self, v, C, NP, ntask, gbytes, gbytes_oc, tab_bytes):
+        """Dynamic LDS of ONE launch of variant `v` over the given class pairs
+        (or jobs): the regions are sized for the largest p and the largest
+        image among them -- two maxima that need not belong to one pair."""
+        rsize = np.dtype(self.real).itemsize
+        if isinstance(v, OCVariant):
+            pcap = int(-(-(NP.max() + 1) // 4) * 4)
+            gcap = int(-(-gbytes_oc.max() // 16) * 16)
+            NR = 64 * v.W * v.R
+            return (pcap + (0 if ((v.L and C != 2) or v.S == 0) else NR)) \
+                * C * rsize + 4 * NR + 2 * gcap + self.lds_slot_bytes(v, C)
+        wpb = WPB1 if v.W == 1 else 1
+        ucap = int(-(-ntask.max() // 64) * 64) + 64
+        gcap = int(-(-gbytes.max() // 16) * 16)
+        return (ucap * C * rsize + 2 * gcap) * wpb + tab_bytes
+
+    def _fit_launches_into_lds(self, choice, C, NP, ntask, gbytes, gbytes_oc,
+                               tab_bytes, oc_only):
+        """Every pair was given a variant whose LDS regions hold IT; a launch
+        sizes its regions for the largest vector and the largest graph image
+        among its pairs, and the two can come from different pairs: the sum
+        went 0.5 KB over the 160 KB of a CU for the 16-wave double variant
+        with LDS-resident slot values on 45...62-node graphs (an invalid
+        launch, scripts/fuzz_parity.py seed 23).  Pairs that hold one of the
+        two maxima of such a launch leave for the general solver until the
+        launch fits."""
+        limit = LDS_LIMIT - self.LDS_STATIC_RESERVE
+        fallback = None
+        for k in sorted(set(choice.tolist())):
+            v = self.variants[k]
+            if k < 0 or v == GENERAL:
+                continue
+            while True:
+                idx = np.flatnonzero(choice == k)
+                if not len(idx) or self._launch_lds(
+                        v, C, NP[idx], ntask[idx], gbytes[idx],
+                        gbytes_oc[idx], tab_bytes) <= limit:
+                    break
+                if fallback is None:
+                    if oc_only or GENERAL not in self.variants:
+                        raise NotOwnerComputes(
+                            f'the pairs of variant {v} do not fit the LDS '
+                            'of a compute unit together and the general '
+                            'solver is not available to this call')
+                    fallback = self.variants.index(GENERAL)
+                big_p = NP[idx] if isinstance(v, OCVariant) else ntask[idx]
+                big_g = gbytes_oc[idx] if isinstance(v, OCVariant) \
+                    else gbytes[idx]
+                # drop whichever maximum frees more bytes per pair dropped
+                cand = []
+                for key in (big_p, big_g):
+                    out = idx[key == key.max()]
+                    keep = np.setdiff1d(idx, out)
+                    after = self._launch_lds(
+                        v, C, NP[keep], ntask[keep], gbytes[keep],
+                        gbytes_oc[keep], tab_bytes) if len(keep) else 0
+                    cand.append((after, len(out), out))
+                after, _, out = min(cand, key=lambda c: (c[0], c[1]))
+                choice = choice.copy()
+                choice[out] = fallback
+        return choice
 
     @staticmethod
     def _code_signature(node_kernel, edge_kernel, p, dgraphs, C, nodal,

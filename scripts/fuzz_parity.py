@@ -8,7 +8,7 @@ held to the oracle.  What the fixed cases of tests/ do not enumerate: odd
 sizes next to each other in one job list, degenerate partners, every solver
 family meeting in one launch order.
 
-    python scripts/fuzz_parity.py [rounds] [--seed=N]
+    python scripts/fuzz_parity.py [rounds] [--seed=N] [--modes=sym,retheta,...]
 """
 import os
 import sys
@@ -28,6 +28,8 @@ from oracle import mgk as oracle                                    # noqa: E402
 rounds = int(next((a for a in sys.argv[1:] if not a.startswith('--')), 40))
 seed = int(next((a.split('=')[1] for a in sys.argv[1:]
                  if a.startswith('--seed=')), 0))
+only_modes = next((a.split('=')[1].split(',') for a in sys.argv[1:]
+                   if a.startswith('--modes=')), None)
 rng = np.random.default_rng(seed)
 
 
@@ -124,8 +126,8 @@ for it in range(rounds):
     # (double: the device keeps the degrees as float32 sums like the
     # reference -- exact for the dyadic weights used here)
     rtol = 2e-9 if f64 else 2e-5
-    mode = rng.choice(['sym', 'xy', 'nodal', 'lmin', 'diag', 'diagnodal',
-                       'grad'])
+    mode = rng.choice(only_modes or ['sym', 'xy', 'nodal', 'lmin', 'diag',
+                                     'diagnodal', 'grad', 'retheta'])
     stats[(family, mode, 'f64' if f64 else 'f32')] = \
         stats.get((family, mode, 'f64' if f64 else 'f32'), 0) + 1
     tag = f'round {it} seed {seed}: {family} {mode} {real.__name__} q={q} ' \
@@ -144,6 +146,22 @@ for it in range(rounds):
             check(tag, k(G, lmin=1), oracle.gram(G, kn, ke, q=q, lmin=1), 10 * rtol)
         elif mode == 'diag':
             check(tag, k.diag(G), np.diag(oracle.gram(G, kn, ke, q=q)), rtol)
+        elif mode == 'retheta':
+            # the training loop: the same graphs again with other
+            # hyperparameters on the same backend (cached layout, new kernel
+            # arguments), through clone_with_theta as an optimiser does it
+            check(tag, k(G), oracle.gram(G, kn, ke, q=q), rtol)
+            for _ in range(3):
+                theta = np.clip(k.theta + rng.normal(scale=0.3, size=len(k.theta)),
+                                k.bounds[:, 0] + 1e-3,
+                                np.minimum(k.bounds[:, 1] - 1e-3, -1e-3))
+                k2 = k.clone_with_theta(theta)
+                want = oracle.gram(G, k2.node_kernel, k2.edge_kernel,
+                                   p=k2.p.p if hasattr(k2.p, 'p') else 1.0, q=k2.q)
+                check(tag + f' theta={theta.tolist()}', k2(G), want, rtol)
+                if rng.integers(2):
+                    K, dK = k2(G, eval_gradient=True)
+                    check(tag + ' (gradient call)', K, want, max(rtol, 1e-7))
         elif mode == 'diagnodal':
             ref = oracle.diag(G[:4], kn, ke, q=q, nodal=True)
             check(tag, k.diag(G[:4], nodal=True), ref, rtol,
