@@ -52,6 +52,16 @@ def random_graph(kind, weighted):
             g.add_edge(u, u + 1)
     elif kind == 'star':
         g = nx.star_graph(int(rng.integers(2, 20)))
+    elif kind == 'iso':                     # isolated nodes next to a ring
+        n = int(rng.integers(4, 20))
+        g = nx.cycle_graph(n)
+        g.add_nodes_from(range(n, n + int(rng.integers(1, 4))))
+    elif kind == 'selfloop':                # self loops inside a tree
+        n = int(rng.integers(3, 20))
+        g = nx.random_labeled_tree(n, seed=r) \
+            if hasattr(nx, 'random_labeled_tree') else nx.path_graph(n)
+        for v in rng.choice(n, size=min(n, 2), replace=False):
+            g.add_edge(int(v), int(v))
     elif kind == 'edge':
         g = nx.path_graph(2)
     else:                                   # one node, one self loop
@@ -106,7 +116,8 @@ def check(name, got, want, rtol, atol=0.0):
 # microkernels in the float32 the frames store the attributes in)
 oracle.WIDE_ROWS = True
 t0 = time.time()
-kinds = ['tree', 'ring', 'dense', 'dense', 'star', 'edge', 'loop']
+kinds = ['tree', 'ring', 'dense', 'dense', 'star', 'edge', 'loop', 'iso',
+         'selfloop']
 stats = {}
 for it in range(rounds):
     weighted = bool(rng.integers(2))
