@@ -138,7 +138,7 @@ for it in range(rounds):
     # reference -- exact for the dyadic weights used here)
     rtol = 2e-9 if f64 else 2e-5
     mode = rng.choice(only_modes or ['sym', 'xy', 'nodal', 'lmin', 'diag',
-                                     'diagnodal', 'grad', 'retheta'])
+                                     'diagnodal', 'grad', 'retheta', 'reuse'])
     stats[(family, mode, 'f64' if f64 else 'f32')] = \
         stats.get((family, mode, 'f64' if f64 else 'f32'), 0) + 1
     tag = f'round {it} seed {seed}: {family} {mode} {real.__name__} q={q} ' \
@@ -173,6 +173,29 @@ for it in range(rounds):
                 if rng.integers(2):
                     K, dK = k2(G, eval_gradient=True)
                     check(tag + ' (gradient call)', K, want, max(rtol, 1e-7))
+        elif mode == 'reuse':
+            # the same Graph objects through a float and a double backend in
+            # turn, whole list and random subsets / blocks: packings are
+            # cached per graph and arithmetic, layouts per list
+            full = oracle.gram(G, kn, ke, q=q)
+            both = {np.float32: k if not f64 else MarginalizedGraphKernel(
+                        kn, ke, q=q, backend=HIPBackend(real=np.float32)),
+                    np.float64: k if f64 else MarginalizedGraphKernel(
+                        kn, ke, q=q, ftol=1e-13, gtol=1e-12,
+                        backend=HIPBackend(real=np.float64))}
+            for _ in range(5):
+                r_ = [np.float32, np.float64][int(rng.integers(2))]
+                tol = 2e-9 if r_ is np.float64 else 2e-5
+                idx = rng.permutation(len(G))[:int(rng.integers(1, len(G) + 1))]
+                sub = [G[i] for i in idx]
+                if rng.integers(2) or len(idx) < 2:
+                    check(tag + f' subset {idx.tolist()} {r_.__name__}',
+                          both[r_](sub), full[np.ix_(idx, idx)], tol)
+                else:
+                    h = len(idx) // 2
+                    check(tag + f' block {idx.tolist()} {r_.__name__}',
+                          both[r_](sub[:h], sub[h:]),
+                          full[np.ix_(idx[:h], idx[h:])], tol)
         elif mode == 'diagnodal':
             ref = oracle.diag(G[:4], kn, ke, q=q, nodal=True)
             check(tag, k.diag(G[:4], nodal=True), ref, rtol,
