@@ -1597,26 +1597,16 @@ void ${name}(params_t prm) {
         out.jobs_sorted, out.merge_map = jobs_sorted, applied
         return out
 
-    #: LDS the kernels declare statically (reduction scratch, rectangle
-    #: tables: mgk_oc.h lds_t, at most ~1.3 KB) -- what the dynamic request of
-    #: a launch must leave free of the 160 KB
-    LDS_STATIC_RESERVE = 2048
-
     def _launch_lds(self, v, C, NP, ntask, gbytes, gbytes_oc, tab_bytes):
-        """Dynamic LDS of ONE launch of variant `v` over the given class pairs
-        (or jobs): the regions are sized for the largest p and the largest
-        image among them -- two maxima that need not belong to one pair."""
-        rsize = np.dtype(self.real).itemsize
+        """LDS of a workgroup -- static and dynamic, `lds_bytes` -- of ONE
+        launch of variant `v` over the given class pairs (or jobs): the
+        regions are sized for the largest vector and the largest image among
+        them -- two maxima that need not belong to one pair."""
         if isinstance(v, OCVariant):
-            pcap = int(-(-(NP.max() + 1) // 4) * 4)
-            gcap = int(-(-gbytes_oc.max() // 16) * 16)
-            NR = 64 * v.W * v.R
-            return (pcap + (0 if ((v.L and C != 2) or v.S == 0) else NR)) \
-                * C * rsize + 4 * NR + 2 * gcap + self.lds_slot_bytes(v, C)
-        wpb = WPB1 if v.W == 1 else 1
-        ucap = int(-(-ntask.max() // 64) * 64) + 64
-        gcap = int(-(-gbytes.max() // 16) * 16)
-        return (ucap * C * rsize + 2 * gcap) * wpb + tab_bytes
+            return int(self.lds_bytes(v, C, int(NP.max()),
+                                      int(gbytes_oc.max())))
+        return int(self.lds_bytes(v, C, int(ntask.max()), int(gbytes.max()),
+                                  tab_bytes))
 
     def _fit_launches_into_lds(self, choice, C, NP, ntask, gbytes, gbytes_oc,
                                tab_bytes, oc_only):
@@ -1624,11 +1614,12 @@ void ${name}(params_t prm) {
         sizes its regions for the largest vector and the largest graph image
         among its pairs, and the two can come from different pairs: the sum
         went 0.5 KB over the 160 KB of a CU for the 16-wave double variant
-        with LDS-resident slot values on 45...62-node graphs (an invalid
-        launch, scripts/fuzz_parity.py seed 23).  Pairs that hold one of the
-        two maxima of such a launch leave for the general solver until the
-        launch fits."""
-        limit = LDS_LIMIT - self.LDS_STATIC_RESERVE
+        with LDS-resident slot values on 45...62-node graphs, and 2.4 KB over
+        for the 16-wave two-stage variant (64 KB of it static) on a list of
+        170 mixed graphs -- invalid launches, scripts/fuzz_parity.py seeds 23
+        and 51.  Pairs that hold one of the two maxima of such a launch leave
+        for the general solver until the launch fits."""
+        limit = LDS_LIMIT
         fallback = None
         for k in sorted(set(choice.tolist())):
             v = self.variants[k]

@@ -673,37 +673,40 @@ def test_a_launch_is_sized_for_two_maxima_and_must_still_fit_the_lds():
     variant sizes its regions for the longest vector AND the largest graph
     image among its pairs, which can be two different pairs: the sum may
     exceed the 160 KB of a compute unit although every pair fits (found by
-    scripts/fuzz_parity.py: an invalid launch of the 16-wave double variant
-    with LDS-resident slot values).  `_fit_launches_into_lds` hands pairs
-    that hold a maximum to the general solver until the launch fits."""
+    scripts/fuzz_parity.py: invalid launches of the 16-wave double variant
+    with LDS-resident slot values and of the 16-wave two-stage variant).
+    `_fit_launches_into_lds` hands pairs that hold a maximum to the general
+    solver until the launch fits."""
     from graphdot_amd.kernel.marginalized._backend_hip import (
-        GENERAL, HIPBackend, LDS_LIMIT, NotOwnerComputes, OCVariant)
+        GENERAL, HIPBackend, LDS_LIMIT, NotOwnerComputes, OCVariant, Variant)
     be = HIPBackend(real=np.float64)
-    v = OCVariant(16, 64, 3, 8)
-    k = be.variants.index(v)
-    C, rsize = 1, 8
-    fixed = 4 * 64 * 16 * 3 + be.lds_slot_bytes(v, C) + (64 * 16 * 3) * C * rsize
-    assert be.lds_slot_bytes(v, C) == 10 * 64 * 16 * 8
-    room = LDS_LIMIT - be.LDS_STATIC_RESERVE - fixed
-    # pair 0: long vector, small images; pair 1: short vector, large images;
-    # pair 2: small in both.  0 and 1 fit alone, not in one launch.
-    NP = np.array([room // rsize - 2600, 1200, 900], dtype=np.int64)
-    gb = np.array([9000, (room - 1204 * rsize) // 2 - 64, 4000], dtype=np.int64)
-
-    def need(idx):
-        return be._launch_lds(v, C, NP[idx], NP[idx], gb[idx], gb[idx], 0)
-    limit = LDS_LIMIT - be.LDS_STATIC_RESERVE
-    assert need([0]) <= limit and need([1]) <= limit and need([2]) <= limit
-    assert need([0, 1, 2]) > limit
-    choice = np.full(3, k, dtype=np.int64)
-    out = be._fit_launches_into_lds(choice, C, NP, NP, gb, gb, 0, False)
     g = be.variants.index(GENERAL)
-    assert sorted(out.tolist()) == sorted([k, k, g])
-    kept = np.flatnonzero(out == k)
-    assert 2 in kept and need(kept) <= limit
-    assert np.array_equal(choice, [k, k, k])            # (input untouched)
-    # nothing to do: the same array comes back
-    assert be._fit_launches_into_lds(out, C, NP, NP, gb, gb, 0, False) is out
-    # calls that only the owner-computes solvers serve cannot fall back
-    with pytest.raises(NotOwnerComputes):
-        be._fit_launches_into_lds(choice, C, NP, NP, gb, gb, 0, True)
+    C, rsize = 1, 8
+    for v in (OCVariant(16, 64, 3, 8), Variant(16, 64, 8)):
+        k = be.variants.index(v)
+        if isinstance(v, OCVariant):
+            assert be.lds_slot_bytes(v, C) == 10 * 64 * 16 * 8
+
+        def need(idx, vec, img):
+            return be._launch_lds(v, C, vec[idx], vec[idx], img[idx], img[idx], 0)
+        room = LDS_LIMIT - int(be.lds_bytes(v, C, 0, 0))      # vector + 2 images
+        # pair 0: long vector, small images; pair 1: short vector, large
+        # images; pair 2: small in both.  0 and 1 fit alone, not together.
+        vec = np.array([(room - 2 * 9000) // rsize - 200, 1200, 900], np.int64)
+        img = np.array([9000, (room - 1300 * rsize) // 2 - 200, 4000], np.int64)
+        assert need([0], vec, img) <= LDS_LIMIT
+        assert need([1], vec, img) <= LDS_LIMIT
+        assert need([2], vec, img) <= LDS_LIMIT
+        assert need([0, 1, 2], vec, img) > LDS_LIMIT
+        choice = np.full(3, k, dtype=np.int64)
+        out = be._fit_launches_into_lds(choice, C, vec, vec, img, img, 0, False)
+        assert sorted(out.tolist()) == sorted([k, k, g])
+        kept = np.flatnonzero(out == k)
+        assert 2 in kept and need(kept, vec, img) <= LDS_LIMIT
+        assert np.array_equal(choice, [k, k, k])            # (input untouched)
+        # nothing to do: the same array comes back
+        assert be._fit_launches_into_lds(out, C, vec, vec, img, img, 0,
+                                         False) is out
+        # calls that only the owner-computes solvers serve cannot fall back
+        with pytest.raises(NotOwnerComputes):
+            be._fit_launches_into_lds(choice, C, vec, vec, img, img, 0, True)
