@@ -142,7 +142,7 @@ for it in range(rounds):
     rtol = 2e-9 if f64 else 2e-5 * max(1.0, 0.05 / q)
     mode = rng.choice(only_modes or ['sym', 'xy', 'nodal', 'lmin', 'diag',
                                      'diagnodal', 'grad', 'retheta', 'reuse',
-                                     'bulk'])
+                                     'bulk', 'bulkgrad', 'huge'])
     stats[(family, mode, 'f64' if f64 else 'f32')] = \
         stats.get((family, mode, 'f64' if f64 else 'f32'), 0) + 1
     tag = f'round {it} seed {seed}: {family} {mode} {real.__name__} q={q} ' \
@@ -200,6 +200,69 @@ for it in range(rounds):
                     check(tag + f' block {idx.tolist()} {r_.__name__}',
                           both[r_](sub[:h], sub[h:]),
                           full[np.ix_(idx[:h], idx[h:])], tol)
+        elif mode == 'huge':
+            # a few graphs of 70-300 nodes among small ones: the 16-wave
+            # variants at their limits, the two-stage and the general solver
+            Gb = []
+            for _ in range(int(rng.integers(4, 9))):
+                n_ = int(rng.integers(70, 300))
+                kind_ = rng.choice(['tree', 'ring', 'ladder'])
+                r_ = int(rng.integers(1 << 30))
+                g = (nx.random_labeled_tree(n_, seed=r_) if kind_ == 'tree'
+                     and hasattr(nx, 'random_labeled_tree')
+                     else nx.newman_watts_strogatz_graph(n_, 4, 0.05, seed=r_)
+                     if kind_ == 'ring' else nx.ladder_graph(n_ // 2))
+                for v in g.nodes:
+                    g.nodes[v]['category'] = int(rng.integers(1, 4))
+                    g.nodes[v]['radius'] = float(rng.choice([1.0, 1.5, 2.0]))
+                for e in g.edges:
+                    g.edges[e]['w'] = float(rng.choice([0.5, 1.0, 2.0])) if weighted else 1.0
+                    g.edges[e]['length'] = float(rng.uniform(0.5, 2.5))
+                    g.edges[e]['order'] = int(rng.integers(1, 3))
+                Gb.append(Graph.from_networkx(g, weight='w' if weighted else None))
+            Gb += [random_graph(rng.choice(kinds), weighted) for _ in range(6)]
+            Gb = Graph.unify_datatype(Gb)
+            knb = TensorProduct(category=KroneckerDelta(float(rng.uniform(0.2, 0.8))))
+            keb = [TensorProduct(length=SquareExponential(float(rng.uniform(0.3, 2.0)))),
+                   Constant(1.0)][int(rng.integers(2))]
+            tag += f' huge: sizes {[len(g.nodes) for g in Gb]} {knb!r} {keb!r}'
+            kb = MarginalizedGraphKernel(
+                knb, keb, q=q, backend=be,
+                **({'ftol': 1e-13, 'gtol': 1e-12} if f64 else {}))
+            K = kb(Gb)
+            assert np.array_equal(K, K.T), tag
+            i_, j_ = np.triu_indices(len(Gb))
+            ref, _ = oracle.TensorProductBatch(Gb, knb, keb).run(
+                i_, j_, q=q, tol=1e-13, real='f64', omp=True)
+            check(tag, K[i_, j_], ref, rtol)
+        elif mode == 'bulkgrad':
+            # value + dK/dtheta of 40-110 graphs in one evaluation, every pair
+            # and plane against the C restatement of compute_duo + derivative
+            Gb = Graph.unify_datatype(
+                [random_graph(rng.choice(kinds + ['bigring']), weighted)
+                 for _ in range(int(rng.integers(40, 110)))])
+            knb = [TensorProduct(category=KroneckerDelta(float(rng.uniform(0.2, 0.8)))),
+                   TensorProduct(category=KroneckerDelta(0.5),
+                                 radius=SquareExponential(float(rng.uniform(0.5, 2.0)))),
+                   ][int(rng.integers(2))]
+            keb = [TensorProduct(length=SquareExponential(float(rng.uniform(0.3, 2.0)))),
+                   TensorProduct(order=KroneckerDelta(float(rng.uniform(0.3, 0.9)))),
+                   ][int(rng.integers(2))]
+            tag += f' bulkgrad: {len(Gb)} graphs {knb!r} {keb!r}'
+            kb = MarginalizedGraphKernel(knb, keb, q=q, backend=be)
+            K, dK = kb(Gb, eval_gradient=True)
+            assert np.isfinite(dK).all() and np.array_equal(K, K.T), tag
+            assert np.array_equal(dK, dK.transpose(1, 0, 2)), tag
+            i_, j_ = np.triu_indices(len(Gb))
+            ref_v, ref_g, _ = oracle.TensorProductBatch(Gb, knb, keb).run_gradient(
+                i_, j_, q=q, real='f64', omp=True)
+            check(tag, K[i_, j_], ref_v, max(rtol, 1e-7))
+            got, want = dK[i_, j_, :], ref_g[:, np.asarray(kb.active_theta_mask)]
+            scale = np.abs(want).max(axis=0, keepdims=True)
+            rt, at = (1e-5, 1e-8) if f64 else (4e-3 * max(1.0, 0.05 / q), 1e-4)
+            bound = rt * np.abs(want) + at * scale + 1e-300
+            worst = float(np.max(np.abs(got - want) / bound))
+            assert worst <= 1.0, (tag, worst)
         elif mode == 'bulk':
             # a list of 60-200 graphs of every family in one matrix: many
             # variants, merged launches, the native job layout at size --
