@@ -142,7 +142,7 @@ for it in range(rounds):
     rtol = 2e-9 if f64 else 2e-5 * max(1.0, 0.05 / q)
     mode = rng.choice(only_modes or ['sym', 'xy', 'nodal', 'lmin', 'diag',
                                      'diagnodal', 'grad', 'retheta', 'reuse',
-                                     'bulk', 'bulkgrad', 'huge'])
+                                     'bulk', 'bulkgrad', 'huge', 'maximin'])
     stats[(family, mode, 'f64' if f64 else 'f32')] = \
         stats.get((family, mode, 'f64' if f64 else 'f32'), 0) + 1
     tag = f'round {it} seed {seed}: {family} {mode} {real.__name__} q={q} ' \
@@ -200,6 +200,23 @@ for it in range(rounds):
                     check(tag + f' block {idx.tolist()} {r_.__name__}',
                           both[r_](sub[:h], sub[h:]),
                           full[np.ix_(idx[:h], idx[h:])], tol)
+        elif mode == 'maximin':
+            # the maximin graph distance fused into the owner-computes
+            # launches against the host composition on full nodal matrices
+            # from the two-stage solvers (float, the metric's arithmetic)
+            from graphdot_amd.metric.maximin import MaxiMin
+            from graphdot_amd.kernel.marginalized._backend_hip import (
+                VARIANTS, GENERAL)
+            fused = MaxiMin(kn, ke, q=q, backend=HIPBackend())
+            host = MaxiMin(kn, ke, q=q,
+                           backend=HIPBackend(variants=VARIANTS + [GENERAL]))
+            Da, Db = fused(G), host(G)
+            assert np.isfinite(Da).all() and np.array_equal(Da, Da.T), tag
+            dev = float(np.abs(Da - Db).max())
+            assert dev <= 5e-4, (tag, dev)
+            if len(G) > 3:
+                dev = float(np.abs(fused(G[:2], G[2:]) - Db[:2, 2:]).max())
+                assert dev <= 5e-4, (tag + ' (block)', dev)
         elif mode == 'huge':
             # a few graphs of 70-300 nodes among small ones: the 16-wave
             # variants at their limits, the two-stage and the general solver
