@@ -142,7 +142,8 @@ for it in range(rounds):
     rtol = 2e-9 if f64 else 2e-5 * max(1.0, 0.05 / q)
     mode = rng.choice(only_modes or ['sym', 'xy', 'nodal', 'lmin', 'diag',
                                      'diagnodal', 'grad', 'retheta', 'reuse',
-                                     'bulk', 'bulkgrad', 'huge', 'maximin'])
+                                     'bulk', 'bulkgrad', 'huge', 'maximin',
+                                     'gradmodes'])
     stats[(family, mode, 'f64' if f64 else 'f32')] = \
         stats.get((family, mode, 'f64' if f64 else 'f32'), 0) + 1
     tag = f'round {it} seed {seed}: {family} {mode} {real.__name__} q={q} ' \
@@ -200,6 +201,32 @@ for it in range(rounds):
                     check(tag + f' block {idx.tolist()} {r_.__name__}',
                           both[r_](sub[:h], sub[h:]),
                           full[np.ix_(idx[:h], idx[h:])], tol)
+        elif mode == 'gradmodes':
+            # the analytic gradient through the other call shapes: X x Y
+            # blocks, lmin = 1, diag
+            mask = np.asarray(k.active_theta_mask)
+
+            def planes(got, want, what):
+                want = np.asarray(want)[..., mask]
+                scale = np.abs(want).reshape(-1, want.shape[-1]).max(axis=0) + 1e-300
+                dev = (np.abs(np.asarray(got) - want).reshape(
+                    -1, want.shape[-1]).max(axis=0) / scale).max()
+                assert np.isfinite(got).all() and dev < (1e-6 if f64 else 4e-3), \
+                    (tag + ' ' + what, float(dev))
+            h = max(1, len(G) // 2)
+            K, dK = k(G[:h], G[h:] or G[:1], eval_gradient=True)
+            Ko, dKo = oracle.gram(G[:h], kn, ke, Y=G[h:] or G[:1], q=q,
+                                  eval_gradient=True)
+            check(tag + ' (block)', K, Ko, max(rtol, 1e-7))
+            planes(dK, dKo, 'block')
+            K, dK = k(G, lmin=1, eval_gradient=True)
+            Ko, dKo = oracle.gram(G, kn, ke, q=q, lmin=1, eval_gradient=True)
+            check(tag + ' (lmin)', K, Ko, 10 * max(rtol, 1e-7))
+            planes(dK, dKo, 'lmin')
+            d, dd = k.diag(G, eval_gradient=True)
+            do, ddo = oracle.diag(G, kn, ke, q=q, eval_gradient=True)
+            check(tag + ' (diag)', d, do, max(rtol, 1e-7))
+            planes(dd, ddo, 'diag')
         elif mode == 'maximin':
             # the maximin graph distance fused into the owner-computes
             # launches against the host composition on full nodal matrices
