@@ -143,7 +143,7 @@ for it in range(rounds):
     mode = rng.choice(only_modes or ['sym', 'xy', 'nodal', 'lmin', 'diag',
                                      'diagnodal', 'grad', 'retheta', 'reuse',
                                      'bulk', 'bulkgrad', 'huge', 'maximin',
-                                     'gradmodes'])
+                                     'gradmodes', 'ringlist'])
     stats[(family, mode, 'f64' if f64 else 'f32')] = \
         stats.get((family, mode, 'f64' if f64 else 'f32'), 0) + 1
     tag = f'round {it} seed {seed}: {family} {mode} {real.__name__} q={q} ' \
@@ -201,6 +201,37 @@ for it in range(rounds):
                     check(tag + f' block {idx.tolist()} {r_.__name__}',
                           both[r_](sub[:h], sub[h:]),
                           full[np.ix_(idx[:h], idx[h:])], tol)
+        elif mode == 'ringlist':
+            # molecules with the variable-length atom attribute of
+            # Graph.from_rdkit and a Convolution microkernel over it: payloads
+            # behind the graph images (frozen_array), no label classes
+            import cases
+            from graphdot_amd.microkernel import Convolution
+            Gm = cases.config3_graphs(int(rng.integers(4, 12)),
+                                      seed=int(rng.integers(1 << 20)),
+                                      ring_list=True)
+            knm = TensorProduct(
+                atomic_number=KroneckerDelta(float(rng.uniform(0.2, 0.8))),
+                ring_list=Convolution(KroneckerDelta(float(rng.uniform(0.3, 0.9)))))
+            kem = [TensorProduct(order=SquareExponential(float(rng.uniform(0.3, 1.5)))),
+                   TensorProduct(order=KroneckerDelta(0.5),
+                                 aromatic=KroneckerDelta(0.7))][int(rng.integers(2))]
+            tag += f' ringlist: sizes {[len(g.nodes) for g in Gm]} {knm!r} {kem!r}'
+            km = MarginalizedGraphKernel(
+                knm, kem, q=q, backend=be,
+                **({'ftol': 1e-13, 'gtol': 1e-12} if f64 else {}))
+            check(tag, km(Gm), oracle.gram(Gm, knm, kem, q=q), rtol)
+            refn = oracle.gram(Gm[:3], knm, kem, q=q, nodal=True)
+            check(tag + ' (nodal)', km(Gm[:3], nodal=True), refn, rtol,
+                  atol=rtol * np.abs(refn).max())
+            K, dK = km(Gm, eval_gradient=True)
+            Ko, dKo = oracle.gram(Gm, knm, kem, q=q, eval_gradient=True)
+            check(tag + ' (gradient call)', K, Ko, max(rtol, 1e-7))
+            dKo = dKo[:, :, np.asarray(km.active_theta_mask)]
+            scale = np.abs(dKo).max(axis=(0, 1)) + 1e-300
+            dev = (np.abs(dK - dKo).max(axis=(0, 1)) / scale).max()
+            assert np.isfinite(dK).all() and dev < (1e-6 if f64 else 4e-3), \
+                (tag, float(dev))
         elif mode == 'gradmodes':
             # the analytic gradient through the other call shapes: X x Y
             # blocks, lmin = 1, diag
