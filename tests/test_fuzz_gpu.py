@@ -1,0 +1,25 @@
+"""A short run of the differential fuzzer (scripts/fuzz_parity.py) inside the
+GPU suite: fixed seeds, every call mode drawn at random -- the long campaigns
+are in scripts/sessions/r4_session4*.sh / r4_session5*.sh."""
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('seed, modes', [
+    (7, None),
+    (23, 'retheta'),           # the round that asked for 163 KB of LDS
+    (51, 'bulk'),              # ... and the two-stage variant's
+    (4, 'sym,lmin,nodal'),     # one- and two-node graphs in double
+])
+def test_fuzzer_rounds(seed, modes):
+    cmd = [sys.executable, os.path.join(ROOT, 'scripts', 'fuzz_parity.py'),
+           '10', f'--seed={seed}'] + ([f'--modes={modes}'] if modes else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500,
+                       cwd=ROOT)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0 and 'fuzz ok' in r.stdout, tail
