@@ -1398,7 +1398,12 @@ struct oc_solver {
                         unsigned fmv[NM];
 #pragma unroll
                         for (int w = 0; w < NM; ++w) {
-                            fmv[w] = fm[w];
+                            // (readfirstlane: where the allocator has parked
+                            // the mask in a vector register -- the nodal-
+                            // gradient kernel of a rational-quadratic composite
+                            // -- the scalar pin below alone is an "illegal VGPR
+                            // to SGPR copy" and the JIT fails at run time)
+                            fmv[w] = (unsigned)__builtin_amdgcn_readfirstlane((int)fm[w]);
                             asm volatile("" : "+s"(fmv[w]));
                         }
 #pragma unroll
@@ -2226,8 +2231,13 @@ struct oc_solver {
         else return y;
     }
     // lane LANE of v = s (s wave-uniform)
+    // (readfirstlane: the "s" constraint alone does not make a value scalar --
+    // where the compiler keeps the count in a vector register, as in the
+    // nodal-gradient kernel of a rational-quadratic composite, it printed
+    // `v_writelane_b32 v21, v39, 39`, which does not assemble: the JIT failed
+    // at run time, scripts/fuzz_parity.py --modes=nodalgrad seed 122)
     template<int LANE> __device__ static __forceinline__ void writelane(int &v, int s) {
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(s), "n"(LANE));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane(s)), "n"(LANE));
     }
     // class tables in the lanes of one register: lane c = first node of degree
     // class c in graph 1, lane 16 + c = nodes of class c in graph 2, lane

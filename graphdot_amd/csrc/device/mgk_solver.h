@@ -246,7 +246,7 @@ template<class real> __device__ __forceinline__ real load_real_at(unsigned addr)
 template<int BYTE_OFFSET> __device__ __forceinline__ void store_lane_contiguous(unsigned base, float v) {
     // (s_nop: one wait state between an SALU write of M0 and the add-TID store)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:%2"
-                 :: "s"(base), "v"(v), "n"(BYTE_OFFSET) : "memory", "m0");
+                 :: "s"(__builtin_amdgcn_readfirstlane((int)base)), "v"(v), "n"(BYTE_OFFSET) : "memory", "m0");
 }
 
 // sum_{j < n, j < deg} t[j] per lane, n <= 4: the entries past a lane's own
@@ -691,7 +691,7 @@ struct pair_solver {
                     unsigned fmv[NM];
 #pragma unroll
                     for (int w = 0; w < NM; ++w) {
-                        fmv[w] = fm[w];
+                        fmv[w] = (unsigned)__builtin_amdgcn_readfirstlane((int)fm[w]);
                         asm volatile("" : "+s"(fmv[w]));
                     }
 #pragma unroll
@@ -770,7 +770,7 @@ struct pair_solver {
                             for (int k = kc; k < kc + RCH && k < R; ++k) {
                                 // (kept as data: hoisted out of the CG loop the test
                                 // would pin an SGPR pair per row)
-                                int plain = plain1[k];   // wave-uniform
+                                int plain = __builtin_amdgcn_readfirstlane(plain1[k]);   // wave-uniform
                                 asm volatile("" : "+s"(plain));
 #pragma unroll
                                 for (int c = 0; c < C; ++c) {
