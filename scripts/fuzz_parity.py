@@ -143,7 +143,8 @@ for it in range(rounds):
     mode = rng.choice(only_modes or ['sym', 'xy', 'nodal', 'lmin', 'diag',
                                      'diagnodal', 'grad', 'retheta', 'reuse',
                                      'bulk', 'bulkgrad', 'huge', 'maximin',
-                                     'gradmodes', 'ringlist', 'nodalgrad'])
+                                     'gradmodes', 'ringlist', 'nodalgrad',
+                                     'startprob'])
     stats[(family, mode, 'f64' if f64 else 'f32')] = \
         stats.get((family, mode, 'f64' if f64 else 'f32'), 0) + 1
     tag = f'round {it} seed {seed}: {family} {mode} {real.__name__} q={q} ' \
@@ -201,6 +202,29 @@ for it in range(rounds):
                     check(tag + f' block {idx.tolist()} {r_.__name__}',
                           both[r_](sub[:h], sub[h:]),
                           full[np.ix_(idx[:h], idx[h:])], tol)
+        elif mode == 'startprob':
+            # starting probabilities other than the uniform 1: a constant, and
+            # an ad-hoc function of the node attributes (Python callable +
+            # device expression), value and gradient
+            for pp in (float(rng.uniform(0.2, 3.0)),
+                       (lambda nodes: np.asarray(nodes['radius'], dtype=float) + 0.5,
+                        'n.radius + 0.5f')):
+                kp = MarginalizedGraphKernel(
+                    kn, ke, q=q, p=pp, backend=be,
+                    **({'ftol': 1e-13, 'gtol': 1e-12} if f64 else {}))
+                what = ' (p = %s)' % (pp if isinstance(pp, float) else pp[1])
+                check(tag + what, kp(G), oracle.gram(G, kn, ke, p=kp.p, q=q), rtol)
+                K, dK = kp(G, eval_gradient=True)
+                Ko, dKo = oracle.gram(G, kn, ke, p=kp.p, q=q, eval_gradient=True)
+                check(tag + what + ' gradient call', K, Ko, max(rtol, 1e-7))
+                dKo = np.asarray(dKo)[:, :, np.asarray(kp.active_theta_mask)] \
+                    if np.asarray(dKo).shape[-1] == len(kp.active_theta_mask) \
+                    else np.asarray(dKo)
+                if dKo.shape == dK.shape:
+                    scale = np.abs(dKo).max(axis=(0, 1)) + 1e-300
+                    dev = (np.abs(dK - dKo).max(axis=(0, 1)) / scale).max()
+                    assert np.isfinite(dK).all() and dev < (1e-6 if f64 else 4e-3), \
+                        (tag + what, float(dev))
         elif mode == 'nodalgrad':
             # the nodal Jacobian (central differences of warm-started
             # re-solves inside the launch, template.cu:226-418) against the
