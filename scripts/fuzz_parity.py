@@ -87,14 +87,19 @@ def random_kernels():
             Additive(category=KroneckerDelta(0.3) * 0.5,
                      radius=SquareExponential(1.2) * 0.5),
             Constant(1.0),
-            ][int(rng.integers(5))]
+            TensorProduct(radius=SquareExponential(float(rng.uniform(0.5, 1.5))),
+                          category=KroneckerDelta(0.5)) ** float(rng.uniform(0.5, 2.5)),
+            ][int(rng.integers(6))]
     edge = [TensorProduct(length=SquareExponential(float(rng.uniform(0.3, 2.0)))),
             TensorProduct(order=KroneckerDelta(float(rng.uniform(0.3, 0.9)))),
             TensorProduct(order=KroneckerDelta(0.6),
                           length=SquareExponential(1.0)),
             TensorProduct(length=RationalQuadratic(float(rng.uniform(0.5, 2.0)),
                                                    float(rng.uniform(0.5, 3.0)))),
-            Constant(1.0)][int(rng.integers(5))]
+            Constant(1.0),
+            (TensorProduct(length=SquareExponential(float(rng.uniform(0.6, 1.8))))
+             * 0.6 + 0.4) ** float(rng.uniform(0.5, 2.5)),
+            ][int(rng.integers(6))]
     return node, edge
 
 

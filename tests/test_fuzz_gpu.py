@@ -10,10 +10,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# (seeds 23 / 51 in these modes are where the invalid launches were first seen;
+# the random stream has changed with the fuzzer's menus since, and the defects
+# have tests of their own: test_abi_and_host_logic.py
+# ::test_a_launch_is_sized_for_two_maxima_and_must_still_fit_the_lds)
 @pytest.mark.parametrize('seed, modes, rounds', [
     (7, None, 10),
-    (23, 'retheta', 8),        # round 7 asked for 163 KB of LDS
-    (51, 'bulk', 10),          # ... and the two-stage variant's launch
+    (23, 'retheta', 8),
+    (51, 'bulk', 10),
     (4, 'sym,lmin,nodal', 4),  # (tiny graphs among the sizes; the float-rounded
     #                            one-row systems have a test of their own)
 ])
