@@ -59,7 +59,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='3',
-                    choices=['2', '3', 'nws48', 'tang2019'])
+                    choices=['2', '3', 'nws48', 'tang2019', 'large'])
     ap.add_argument('--batch', default='1,16,128',
                     help='--config nws48: batch sizes of the reference harness')
     ap.add_argument('--graphs', type=int, default=None,
@@ -188,6 +188,18 @@ def workload(args):
                 'molecules, <= 23 atoms, tent-weighted adjacency within '
                 '3 sqrt(r_i r_j): 88 % dense, degree up to 22; seed 2019, '
                 f'{n * (n + 1) // 2} pairs incl. diagonal), '
+                'Tang2019MolecularKernel: KroneckerDelta(0.2) element x '
+                'SquareExponential(0.05) length, q=0.01')
+        return graphs, knode, kedge, q, name, (2, 6)
+    if args.config == 'large':
+        n = args.graphs or 32
+        graphs = cases.protein_like_graphs(n)
+        knode, kedge, q = cases.tang2019_kernels()
+        name = (f'large spatial graphs ({n} protein-like point clouds of '
+                '150-600 atoms, edges within 2.7 A with tent weights: 6-25 '
+                'neighbours per atom, product graphs of 2e4-3.6e5 rows; seed '
+                f'3000, {n * (n + 1) // 2} pairs incl. diagonal; the regime of '
+                'example/perfbench/protein-time-to-solution.py), '
                 'Tang2019MolecularKernel: KroneckerDelta(0.2) element x '
                 'SquareExponential(0.05) length, q=0.01')
         return graphs, knode, kedge, q, name, (2, 6)
@@ -699,6 +711,8 @@ def main():
         return
     if args.dtype is None:
         args.dtype = 'f64' if args.config == 3 else 'f32'
+    if args.config == 'large' and args.steps == 200:
+        args.steps = 5          # (a step is 528 pairs of ~1e5 rows each)
     sharded = world > 1 or args.sharded
 
     dist = torch = None

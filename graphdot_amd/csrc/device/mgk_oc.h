@@ -705,12 +705,30 @@ struct oc_solver {
                 dE1 = reinterpret_cast<edge_t *>(lG2 + prm.g_capacity);
                 dE2T = reinterpret_cast<edge_t *>(reinterpret_cast<char *>(dE1) + (nn1 * (unsigned)sizeof(edge_t) + 15u) / 16u * 16u);
                 if (dense_pair) {
-                    // (16-byte units: sizeof(edge_t) divides 16 or the pad
-                    // rounds up -- zero-fill by whole records instead)
-                    const edge_t zero{};
+                    // Where a graph has no edge the arrays hold a FILLER: the
+                    // labels of the graph's first edge with weight 0.  The
+                    // microkernel is evaluated on every cell, and on an
+                    // all-zero record a label kernel need not be a number --
+                    // Normalize(DotProduct()) is 0 / sqrt(0) there, Convolution
+                    // divides by the lengths of two empty lists -- and NaN
+                    // times the weight 0 stays NaN.  On the filler it is as
+                    // finite as on any pair of real edges (dense pairs have
+                    // edges: the test above needs n_nz > 0 on both sides).
+                    edge_t fill1 = at32(g1.edge, 0u), fill2 = at32(g2.edge, 0u);
+                    fill1.weight = 0;
+                    fill2.weight = 0;
+                    unsigned fw[EW];
+                    __builtin_memcpy(fw, &fill2, sizeof(edge_t));
                     unsigned *const planes = reinterpret_cast<unsigned *>(dE2T);
-                    for (unsigned k = tid; k < nn1; k += T) dE1[k] = zero;
-                    for (unsigned k = tid; k < nn2; k += T) planes[k] = 0u;
+                    for (unsigned k = tid; k < nn1; k += T) dE1[k] = fill1;
+                    for (unsigned k = tid; k < nn2; k += T) {
+                        // row of the plane array = (j2 / 4) (EW 4) + d 4 + j2 % 4
+                        const unsigned d = ((k / DSTRIDE) >> 2) % EW;
+                        unsigned w = fw[0];
+#pragma unroll
+                        for (unsigned dd = 1; dd < EW; ++dd) w = d == dd ? fw[dd] : w;
+                        planes[k] = w;
+                    }
                     job_sync<W>();
                     for (unsigned e = tid; e < (unsigned)h1.n_nz; e += T) {
                         const nz_t z = at32(g1.nz, e);

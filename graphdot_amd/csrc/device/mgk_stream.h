@@ -1,0 +1,256 @@
+// Streamed solver for LARGE graph pairs on MI355X (gfx950, wave64): product
+// graphs of 1e4 ... 1e6 rows whose CG vectors fit neither registers nor LDS
+// -- the regime of the reference's protein benchmark
+// (example/perfbench/protein-time-to-solution.py:1-58; solver scratch:
+// graphdot/kernel/marginalized/_scratch.py:20-36, marginalized_kernel.h:20-38).
+//
+// Same system, iteration and stopping rules as every other solver here
+// (reference: graphdot/cpp/marginalized_kernel.h:394-461); what differs from
+// `general_solver` (mgk_solver.h), which it replaces for value solves:
+//
+//  * ONE stage instead of two.  The owner of row (iA, iB) sums its whole
+//    Kronecker double sum  sum_{a in adj(iA)} sum_{b in adj(iB)} E[a,b]
+//    p[jA(a), jB(b)]  -- no U[a, iB] array through global memory (written
+//    once and read twice per iteration by general_solver).
+//  * One graph of the pair (B: the smaller image) is staged into LDS once per
+//    pair -- row pointers, column indices and edge records: every per-term
+//    operand of B is a ds_read.  general_solver read them from global memory
+//    in a dependent chain per term.
+//  * The other graph (A) is STREAMED row by row: a workgroup step takes G
+//    rows iA (G groups of LB = ceil64(nB) lanes; lane lb of group g owns row
+//    (iA = base + g, iB = lb)), and for A_ROWS neighbours a of iA at a time
+//    the rows p[jA(a), :] are copied -- coalesced -- from the global vector
+//    into LDS; the gathers p[jA(a), jB(b)] of all lanes then hit that copy.
+//    Graph A's edge record and column are the same for all lanes of a wave:
+//    scalar operands.
+//  * The Jacobi diagonal is evaluated once per pair into the scratch
+//    (general_solver: four evaluations of the node microkernel and four
+//    divisions per row and iteration), A p is kept from the mat-vec for the
+//    update (general_solver re-summed U), and every vector pass is flat and
+//    coalesced.
+//
+// Scratch per workgroup: [x | r | p | Ap | diag], N reals each
+// (prm.u_capacity reals).  Dynamic LDS: [image of B | A_ROWS rows of p per
+// group], sized pair by pair.  The edge microkernel is evaluated per term and iteration, as the
+// reference does (marginalized_kernel.h:299-300,346): nnz_A nnz_B values do
+// not fit anywhere (5e7 per pair), and streaming them from HBM costs what
+// re-evaluating them does.
+#ifndef GRAPHDOT_HIP_MGK_STREAM_H_
+#define GRAPHDOT_HIP_MGK_STREAM_H_
+#include "mgk_solver.h"
+
+namespace graphdot {
+namespace mgk {
+
+template<class real, int TPB, int C, class Graph, class NodeK, class EdgeK, class PStart>
+struct stream_solver {
+    static_assert(C == 1, "value solves; value + gradient pairs of this size take general_solver");
+    using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
+    using node_t = typename Graph::node_t;
+    using edge_t = typename Graph::edge_t;
+    constexpr static int W = TPB / 64;
+#ifndef GD_STREAM_ROWS
+#define GD_STREAM_ROWS 4
+#endif
+    constexpr static int A_ROWS = GD_STREAM_ROWS;     // rows of p staged per pass and group
+
+    struct lds_t {
+        real red[2 * W];
+    };
+
+    // bytes of the contiguous image [degree .. perm] of a graph, in 16-byte units
+    __device__ static __forceinline__ unsigned image_words(graph_header_t const &h) {
+        return (h.perm + 2u * (unsigned)h.n_node - h.degree + 15u) / 16u;
+    }
+
+    template<class V> __device__ static __forceinline__ V pick(bool second, V const &a, V const &b) {
+        return second ? b : a;
+    }
+
+    __device__ static __forceinline__ void run(P const &prm, lds_t &lds, char *dyn, real *scratch_all) {
+        const int tid = threadIdx.x;
+        real *const red = lds.red;
+        real *const scratch = scratch_all + (size_t)blockIdx.x * prm.u_capacity;
+        graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
+        char *const lG = dyn;
+
+        for (unsigned t = blockIdx.x; t < prm.n_launch_jobs; t += gridDim.x) {
+            const job_t job = prm.jobs[t];
+            const graph_header_t h1 = headers[job.i], h2 = headers[job.j];
+            // B, the LDS-resident graph: the smaller image among the graphs of
+            // at most TPB nodes (ties: graph 2); the staged rows of p lie
+            // behind it -- HIPBackend.stream_lds_bytes sizes the launch's
+            // region by the same rule, pair by pair
+            const unsigned w1 = image_words(h1), w2 = image_words(h2);
+            const bool ok1 = h1.n_node <= TPB, ok2 = h2.n_node <= TPB;
+            const bool sw = ok1 && (!ok2 || w1 < w2);     // B = graph 1
+            const graph_header_t hA = sw ? h2 : h1, hB = sw ? h1 : h2;
+            const Graph gA(prm.arena, hA);
+            const Graph gB(lG - hB.degree, hB);
+            real *const stage = reinterpret_cast<real *>(lG + (sw ? w1 : w2) * 16u);
+            const int nA = hA.n_node, nB = hB.n_node, N = nA * nB;
+            const real q = prm.q, q0 = prm.q0;
+            const real inv1q2 = real(1) / ((real(1) - q) * (real(1) - q));
+            const real bscale = q * q / (q0 * q0);
+            real *const X = scratch;
+            real *const Rv = X + (size_t)N;
+            real *const Pv = Rv + (size_t)N;
+            real *const AP = Pv + (size_t)N;
+            real *const DG = AP + (size_t)N;
+
+            __syncthreads();     // the previous pair is done with LDS and scratch
+            {
+                typedef unsigned v4 __attribute__((ext_vector_type(4)));
+                const unsigned wB = sw ? w1 : w2;
+                const v4 *const src = reinterpret_cast<const v4 *>(prm.arena + hB.degree);
+                v4 *const dst = reinterpret_cast<v4 *>(lG);
+                for (unsigned w = tid; w < wB; w += TPB) dst[w] = src[w];
+            }
+            __syncthreads();
+
+            // thread -> (group g, lane lb of the group); G rows of A per step
+            const int LB = (nB + 63) & ~63;
+            const int G = TPB / LB;              // >= 1: nB <= TPB (host)
+            const int g = tid / LB, lb = tid - g * LB;
+            const bool lane_ok = g < G && lb < nB;
+            real *const st = stage + (size_t)g * A_ROWS * nB;
+
+            // ---- diagonal, right-hand side, start vectors ---------------------
+            real rTz = 0;
+            for (int i = tid; i < N; i += TPB) {
+                const int iA = i / nB, iB = i - iA * nB;
+                const real dx = real(gA.degree[iA]) * real(gB.degree[iB]) * inv1q2;
+                const node_t vA = gA.node[iA], vB = gB.node[iB];
+                const real vx = real(prm.node_kernel(pick(sw, vA, vB), pick(sw, vB, vA)));
+                const real b = dx * bscale, mi = vx / dx;
+                DG[i] = dx / vx;
+                X[i] = 0;
+                Rv[i] = b;
+                Pv[i] = b * mi;
+                rTz += b * b * mi;
+            }
+            rTz = block_reduce<real, W>::sum(rTz, red);
+
+            const real tol = prm.ftol * real(N);
+            const real tol2 = tol * tol;
+            unsigned it = 0;
+            for (; it < (unsigned)N && rTz != real(0); ++it) {
+                __syncthreads();     // p of this iteration is in memory
+                real pAp = 0;
+                for (int base = 0; base < nA; base += G) {
+                    const int iA = base + g;
+                    const bool row_ok = g < G && iA < nA;
+                    const int rsA = row_ok ? (int)gA.rowptr[iA] : 0;
+                    const int dA = row_ok ? (int)gA.rowptr[iA + 1] - rsA : 0;
+                    // longest row of the step (workgroup-uniform)
+                    int dmax = 0;
+                    for (int k = 0; k < G && base + k < nA; ++k) {
+                        const int d = (int)gA.rowptr[base + k + 1] - (int)gA.rowptr[base + k];
+                        dmax = d > dmax ? d : dmax;
+                    }
+                    const int b0 = lane_ok ? (int)gB.rowptr[lb] : 0;
+                    const int b1 = lane_ok && row_ok ? (int)gB.rowptr[lb + 1] : b0;
+                    real acc = 0;
+                    for (int a0 = 0; a0 < dmax; a0 += A_ROWS) {
+                        __syncthreads();     // the rows staged before are consumed
+                        const int nv = dA - a0 < A_ROWS ? dA - a0 : A_ROWS;   // (wave-uniform; may be <= 0)
+                        edge_t eA[A_ROWS];
+#pragma unroll
+                        for (int u = 0; u < A_ROWS; ++u) {
+                            if (u < nv) {
+                                eA[u] = gA.edge[rsA + a0 + u];
+                                const unsigned jA = gA.nz[rsA + a0 + u].j;
+                                if (lane_ok) st[u * nB + lb] = Pv[(size_t)jA * nB + lb];
+                            }
+                        }
+                        __syncthreads();
+                        for (int b = b0; b < b1; ++b) {
+                            const edge_t eB = gB.edge[b];
+                            const unsigned col = gB.nz[b].j;
+#pragma unroll
+                            for (int u = 0; u < A_ROWS; ++u) {
+                                if (u < nv) {
+                                    const real e = real(prm.edge_kernel(pick(sw, eA[u], eB), pick(sw, eB, eA[u])));
+                                    acc += e * st[u * nB + col];
+                                }
+                            }
+                        }
+                    }
+                    if (lane_ok && row_ok) {
+                        const size_t i = (size_t)iA * nB + lb;
+                        const real pv = Pv[i];
+                        const real Ap = DG[i] * pv - acc;
+                        AP[i] = Ap;
+                        pAp += pv * Ap;
+                    }
+                }
+                pAp = block_reduce<real, W>::sum(pAp, red);    // (its barriers publish AP)
+                if (pAp == real(0)) break;
+                const real alpha = rTz / pAp;
+                real rTr = 0, rTz_next = 0;
+                for (int i = tid; i < N; i += TPB) {
+                    X[i] += alpha * Pv[i];
+                    const real rv = Rv[i] - alpha * AP[i];
+                    Rv[i] = rv;
+                    rTr += rv * rv;
+                    rTz_next += rv * rv / DG[i];
+                }
+                block_reduce<real, W>::sum2(rTr, rTz_next, red);
+                if (rTr < tol2) {
+                    ++it;
+                    break;
+                }
+                const real beta = rTz_next / rTz;
+                for (int i = tid; i < N; i += TPB) Pv[i] = Rv[i] / DG[i] + beta * Pv[i];
+                rTz = rTz_next;
+            }
+            __syncthreads();
+            if (prm.iters != nullptr && tid == 0) prm.iters[prm.order[t]] = it;
+
+            // ---- output (conventions of pair_solver / template.cu:100-224) ----
+            const unsigned flags = prm.flags;
+            const unsigned I1 = prm.starts[job.i], I2 = prm.starts[job.j];
+            const bool mirror = (flags & F_SYMMETRIC) && job.i != job.j;
+            const int n2 = h2.n_node;
+            real ksum = 0;
+            for (int i = tid; i < N; i += TPB) {
+                const int iA = i / nB, iB = i - iA * nB;
+                const node_t vA = gA.node[iA], vB = gB.node[iB];
+                real xi = X[i];
+                if (flags & F_LMIN1)
+                    xi -= real(prm.node_kernel(pick(sw, vA, vB), pick(sw, vB, vA))) * bscale;
+                const real rv = xi * real(prm.p_start(vA)) * real(prm.p_start(vB));
+                ksum += rv;
+                if (flags & F_NODAL) {
+                    const unsigned oA = gA.perm[iA], oB = gB.perm[iB];
+                    const unsigned o1 = sw ? oB : oA, o2 = sw ? oA : oB;
+                    if (flags & F_BLOCK) {
+                        prm.gramian[I1 + o1 + o2 * n2] = rv;
+                    } else if (flags & F_DIAGONAL) {
+                        if (o1 == o2) prm.gramian[I1 + o1] = rv;
+                    } else {
+                        prm.gramian[(size_t)(I1 + o1) + (size_t)prm.nX * (I2 + o2)] = rv;
+                        if (mirror) prm.gramian[(size_t)(I2 + o2) + (size_t)prm.nX * (I1 + o1)] = rv;
+                    }
+                }
+            }
+            if (!(flags & F_NODAL)) {
+                ksum = block_reduce<real, W>::sum(ksum, red);
+                if (tid == 0) {
+                    if (flags & F_PACKED) {
+                        prm.gramian[prm.order[t]] = ksum;
+                    } else if (flags & F_DIAGONAL) {
+                        prm.gramian[I1] = ksum;
+                    } else {
+                        prm.gramian[(size_t)I1 + (size_t)prm.nX * I2] = ksum;
+                        if (mirror) prm.gramian[(size_t)I2 + (size_t)prm.nX * I1] = ksum;
+                    }
+                }
+            }
+        }
+    }
+};
+
+}  // namespace mgk
+}  // namespace graphdot
+#endif

@@ -101,7 +101,17 @@ GENERAL = Variant(0, 0, 0)
 #: sentinel: the kernel that fills the global microkernel tables
 TABLES = Variant(-1, 0, 0)
 GENERAL_THREADS = 1024
+#: sentinel: the streamed solver for large pairs (csrc/device/mgk_stream.h):
+#: value solves of pairs beyond every register- and LDS-resident variant; one
+#: graph of the pair staged in LDS, the other streamed row by row, CG vectors
+#: in a global scratch.  GD_STREAM=0: those pairs take the general solver.
+STREAM = Variant(-2, 0, 0)
+STREAM_THREADS = 1024
+#: rows of p staged per pass and row group (mgk_stream.h A_ROWS)
+STREAM_ROWS = 4
 LDS_LIMIT = 160 * 1024
+_LARGE_PAIR_SOLVERS = ([STREAM] if os.environ.get('GD_STREAM', '1') != '0'
+                       else []) + [GENERAL]
 #: independent pairs (waves) per workgroup of the one-wave variants;
 #: mgk_solver.h reads the same number from GD_WPB
 WPB1 = int(os.environ.get('GD_WPB', 1))
@@ -466,7 +476,7 @@ class HIPBackend(Backend):
         self.hipcc_extra = list(kwargs.pop('hipcc_extra', [])) + \
             os.environ.get('GD_HIPCC_EXTRA', '').split()
         self.variants = list(kwargs.pop(
-            'variants', OC_VARIANTS + VARIANTS + [GENERAL]))
+            'variants', OC_VARIANTS + VARIANTS + _LARGE_PAIR_SOLVERS))
         if os.environ.get('GD_OC') == '0':        # experiments: two-stage only
             self.variants = [v for v in self.variants
                              if not isinstance(v, OCVariant)]
@@ -480,7 +490,8 @@ class HIPBackend(Backend):
                 f = list(map(int, item.split(':')))
                 return OCVariant(*f) if len(f) == 4 else Variant(*f)
             self.variants = [parse(item) for item in
-                             os.environ['GD_VARIANTS'].split(',')] + [GENERAL]
+                             os.environ['GD_VARIANTS'].split(',')] \
+                + _LARGE_PAIR_SOLVERS
         self.record_iterations = kwargs.pop('record_iterations', False)
         self.occupancy = kwargs.pop('occupancy', None)
         self.concurrent = kwargs.pop('concurrent', True)
@@ -756,6 +767,8 @@ struct ${name}_t : ${name}_theta_t {
             return f'mgk_{f}_general_T{GENERAL_THREADS}_C{C}'
         if v == TABLES:
             return f'mgk_{f}_tables_C{C}'
+        if v == STREAM:
+            return f'mgk_{f}_stream_T{STREAM_THREADS}_C{C}'
         if isinstance(v, OCVariant):
             return f'mgk_{f}_oc{v.D}_W{v.W}_S{v.S}_R{v.R}_C{C}' + \
                 ('_L' + 'x'.join(map(str, v.L)) if v.L else '') + \
@@ -957,6 +970,19 @@ void ${name}(params_t prm) {
     solver::run(prm, lds, prm.scratch);
 }
 ''').render(threads=GENERAL_THREADS, name=self.kernel_name(v, C), C=C)
+        if v == STREAM:
+            return Template(r'''
+extern "C" __global__ __launch_bounds__(${threads})
+void ${name}(params_t prm) {
+    using solver = graphdot::mgk::stream_solver<real_t, ${threads}, ${C},
+        graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
+    static_assert(solver::A_ROWS == ${rows}, "rows of p staged per pass: host and device disagree");
+    __shared__ typename solver::lds_t lds;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    solver::run(prm, lds, dyn_lds, prm.scratch);
+}
+''').render(threads=STREAM_THREADS, name=self.kernel_name(v, C), C=C,
+            rows=STREAM_ROWS)
         threads = 64 * v.W * (WPB1 if v.W == 1 else 1)
         return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
@@ -1030,6 +1056,24 @@ void ${name}(params_t prm) {
         if not 0 < n <= 32 or esize == 0 or esize % 4:
             return 0
         return -(-(n * n * esize) // 16) * 16 + esize * (n + 3) * 32 + 256
+
+    def stream_lds_bytes(self, image1, image2, n1, n2):
+        """Dynamic LDS of a pair in the streamed solver (mgk_stream.h): the
+        image of B -- the smaller image among the graphs of at most
+        STREAM_THREADS nodes, ties: graph 2 -- in 16-byte units, and behind
+        it STREAM_ROWS rows of p for each of the G = STREAM_THREADS //
+        ceil64(nB) row groups of a workgroup step.  A huge number if neither
+        graph qualifies."""
+        image1, image2 = np.asarray(image1), np.asarray(image2)
+        n1, n2 = np.asarray(n1), np.asarray(n2)
+        w1, w2 = -(-image1 // 16), -(-image2 // 16)
+        ok1, ok2 = n1 <= STREAM_THREADS, n2 <= STREAM_THREADS
+        first = ok1 & (~ok2 | (w1 < w2))
+        nB = np.maximum(np.where(first, n1, n2), 1)
+        G = STREAM_THREADS // (-(-nB // 64) * 64).clip(max=STREAM_THREADS)
+        stage = STREAM_ROWS * G * nB * np.dtype(self.real).itemsize
+        out = np.where(first, w1, w2) * 16 + -(-stage // 16) * 16
+        return np.where(ok1 | ok2, out, np.iinfo(np.int64).max // 4)
 
     def lds_slot_bytes(self, v, C):
         """LDS bytes of the slot values a variant keeps in LDS instead of
@@ -1304,7 +1348,8 @@ void ${name}(params_t prm) {
         for k, v in enumerate(self.variants):
             if not len(rem):
                 break
-            if v == GENERAL or (oc_only and not isinstance(v, OCVariant)):
+            if v in (GENERAL, STREAM) or (
+                    oc_only and not isinstance(v, OCVariant)):
                 continue
             if isinstance(v, OCVariant):
                 if tab_bytes or native_oc:  # (table kernels: two-stage only)
@@ -1397,7 +1442,19 @@ void ${name}(params_t prm) {
                     f'{n_nz[jj[bad]]} adjacency nonzeros exceeds the largest '
                     'register-resident solver variant and the general '
                     'solver is disabled')
-            choice[choice < 0] = self.variants.index(GENERAL)
+            left = choice < 0
+            choice[left] = self.variants.index(GENERAL)
+            if C == 1 and STREAM in self.variants:
+                # value solves of large pairs: the streamed solver, if the
+                # image of the smaller graph (of at most STREAM_THREADS nodes:
+                # one lane per node of it) fits the LDS beside the staged
+                # rows of p -- the rule of mgk_stream.h
+                raw = f['image_bytes']
+                sb = self.stream_lds_bytes(raw[ji], raw[jj], n1, n2)
+                fits = left & (sb + 1024 <= LDS_LIMIT)
+                choice[fits] = self.variants.index(STREAM)
+                # (for these pairs `gbytes` is the dynamic LDS of the pair)
+                gbytes = np.where(fits, sb, gbytes)
         return choice, cost, ntask, gbytes, NP, gbytes_oc
 
     # -- the three phases -----------------------------------------------------------
@@ -1547,6 +1604,17 @@ void ${name}(params_t prm) {
                     threads=GENERAL_THREADS, per_wg=per_wg))
                 cursor += count
                 continue
+            if v == STREAM:
+                # one workgroup per pair; scratch [x | r | p | Ap | diag]
+                # (N <= NP reals each); LDS: image of B | staged rows of p
+                per_wg = int(5 * NP[idx].max())
+                dyn = int(-(-gbytes[idx].max() // 16) * 16)
+                launches.append(dict(
+                    variant=v, k=k, offset=cursor, ucap=per_wg, gcap=dyn,
+                    dynamic_lds=dyn, count=count,
+                    grid=None, threads=STREAM_THREADS, per_wg=per_wg))
+                cursor += count
+                continue
             if isinstance(v, OCVariant):
                 # one pair per workgroup; dynamic LDS: p | row sums | row map
                 # | two images (mgk_oc.h)
@@ -1623,7 +1691,7 @@ void ${name}(params_t prm) {
         fallback = None
         for k in sorted(set(choice.tolist())):
             v = self.variants[k]
-            if k < 0 or v == GENERAL:
+            if k < 0 or v in (GENERAL, STREAM):
                 continue
             while True:
                 idx = np.flatnonzero(choice == k)
@@ -1685,7 +1753,7 @@ void ${name}(params_t prm) {
                 self.tables)
         for k, v in todo:
             # (the entry point also carries the variant's occupancy target)
-            waves = None if v in (GENERAL, TABLES) else (
+            waves = None if v in (GENERAL, TABLES, STREAM) else (
                 self._oc_waves(v, C, ngrad) if ngrad and isinstance(
                     v, OCVariant) else self.waves_per_eu(v, C))
             key = (sig, tuple(v), waves, opts)
@@ -1694,7 +1762,7 @@ void ${name}(params_t prm) {
                     node_kernel, edge_kernel, p, dgraphs[0].node_t,
                     dgraphs[0].edge_t, [v], C, nodal,
                     tab=gtab if isinstance(v, OCVariant)
-                    else (tab and v not in (GENERAL, TABLES)),
+                    else (tab and v not in (GENERAL, TABLES, STREAM)),
                     weighted=dgraphs[0].weighted, ngrad=ngrad,
                     maximin=maximin and isinstance(v, OCVariant))
             out[k] = self._source_cache[key]
@@ -1880,15 +1948,15 @@ void ${name}(params_t prm) {
             L['module'] = modules[L['k']]
             L['tab'] = L.get('tab', False) \
                 if isinstance(L['variant'], OCVariant) \
-                else tab and L['variant'] != GENERAL
+                else tab and L['variant'] not in (GENERAL, STREAM)
             L['fn'] = fn = L['module'].function(
                 self.kernel_name(L['variant'], C, nodal, L['tab'], ngrad,
                                  maximin is not None))
-            if L['variant'] == GENERAL:
+            if L['variant'] in (GENERAL, STREAM):
                 L['grid'] = int(min(L['count'],
                                     2 * self.props.compute_units))
                 L['scratch_bytes'] = L['grid'] * L['per_wg'] * rsize
-            elif L['dynamic_lds'] > 64 * 1024:
+            if L['dynamic_lds'] > 64 * 1024:
                 runtime.set_max_dynamic_lds(fn, L['dynamic_lds'])
             launches.append(L)
         plan.launches = launches

@@ -16,6 +16,7 @@
 #include <wave.h>
 #include <mgk_solver.h>
 #include <mgk_oc.h>
+#include <mgk_stream.h>
 
 using namespace graphdot::numpy_type;
 using namespace graphdot::basekernel;

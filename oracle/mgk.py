@@ -341,8 +341,10 @@ def pair_value(g1, g2, knode, kedge, p=1.0, q=0.01, lmin=0, mode='dense',
 
     if nodal is False:
         x, y, _ = solve_pair(s1, s2, V, E, q, mode, tol, rhs_extra=px)
-        jac = derivative(s1, s2, V, dV.reshape(dV.shape[0], -1),
-                         dE.reshape(dE.shape[0], -1), p1, p2, dp1, dp2, q,
+        # (explicit widths: a microkernel without hyperparameters has zero
+        # planes, and numpy cannot infer -1 for an empty array)
+        jac = derivative(s1, s2, V, dV.reshape(dV.shape[0], V.size),
+                         dE.reshape(dE.shape[0], E.size), p1, p2, dp1, dp2, q,
                          x, y)
         return (post(x, V) * px).sum(), jac
 

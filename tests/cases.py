@@ -308,3 +308,91 @@ def tang2019_kernels():
     """Tang2019MolecularKernel's defaults (kernel/molecular.py:36-56)."""
     return (TensorProduct(element=KroneckerDelta(0.2)),
             TensorProduct(length=SquareExponential(0.05)), 0.01)
+
+
+def feature_graphs(seed=12, n_graphs=5, real=np.float32):
+    """Small weighted graphs whose nodes carry a scalar `radius`, a category
+    and a fixed-length non-negative feature vector `fp` (variable-length
+    attribute on the device), edges a `length`.  With real = float64 the float
+    attributes are stored as float64 columns, so that the Python microkernels
+    of the oracle see the numbers the double build computes on (a float32
+    column makes numpy evaluate `x - y` in float32)."""
+    import networkx as nx
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_graphs):
+        n = int(rng.integers(5, 12))
+        g = nx.connected_watts_strogatz_graph(n, 3, 0.3,
+                                              seed=int(rng.integers(1 << 30)))
+        for v in g.nodes:
+            g.nodes[v]['radius'] = float(rng.choice([1.0, 1.5, 2.0, 2.5]))
+            g.nodes[v]['category'] = int(rng.integers(1, 4))
+            g.nodes[v]['fp'] = np.round(rng.uniform(0.2, 1.0, size=4),
+                                        3).astype(real)
+        for e in g.edges:
+            g.edges[e]['w'] = float(rng.choice([0.5, 1.0, 2.0]))
+            g.edges[e]['length'] = float(rng.uniform(0.5, 2.5))
+        out.append(Graph.from_networkx(g, weight='w'))
+    if real is np.float64:
+        for g in out:
+            g.nodes['radius'] = np.asarray(g.nodes['radius'], dtype=real)
+            g.edges['length'] = np.asarray(g.edges['length'], dtype=real)
+            g.edges['!w'] = np.asarray(g.edges['!w'], dtype=real)
+    out = Graph.unify_datatype(out)
+    if real is np.float64:
+        # (unify_datatype stores list-like attributes with the smallest
+        # element type that holds the values: float32)
+        for g in out:
+            g.nodes['fp'] = [np.asarray(a, dtype=real) for a in g.nodes['fp']]
+    return out
+
+
+def protein_like_graphs(n_graphs=32, nmin=150, nmax=600, seed=3000,
+                        cutoff=2.7):
+    """Large spatial graphs in the regime of the reference's protein
+    benchmark (example/perfbench/protein-time-to-solution.py:1-58: 3 kDa
+    crystal structures through `Graph.from_ase`): `n_graphs` point clouds of
+    nmin..nmax atoms (H, C, N, O, S in protein-like proportions) grown as a
+    compact self-avoiding chain -- consecutive atoms 1.1-1.5 A apart, the
+    chain pulled back towards the centre beyond the radius of a globule of
+    protein density -- numbered in chain order like a structure file; every
+    pair of atoms closer than `cutoff` A is an edge of weight 1 - d / cutoff
+    (the tent function of graph/adjacency/atomic.py:80-125) with the
+    attribute `length` = d: 6-25 neighbours per atom (mean 13-17), 1400-4000
+    edges per graph, product graphs of 2e4-3.6e5 rows with up to 6e7 terms.  Far beyond the register- and
+    LDS-resident solvers: the general solver's workload."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_graphs):
+        n = int(rng.integers(nmin, nmax + 1))
+        Z = rng.choice([1, 6, 7, 8, 16], size=n,
+                       p=[0.50, 0.32, 0.085, 0.09, 0.005])
+        R = (n / (4.0 / 3.0 * np.pi * 0.085)) ** (1.0 / 3.0)
+        x = np.zeros((n, 3))
+        for v in range(1, n):
+            step = 1.1 if 1 in (Z[v - 1], Z[v]) else 1.5
+            best, best_d = None, -1.0
+            for attempt in range(30):
+                d = rng.normal(size=3)
+                d /= np.linalg.norm(d)
+                r = np.linalg.norm(x[v - 1])
+                if r > R:                    # pulled back into the globule
+                    d = d - 1.5 * x[v - 1] / r
+                    d /= np.linalg.norm(d)
+                cand = x[v - 1] + step * d
+                dmin = np.min(np.linalg.norm(x[:v] - cand, axis=1))
+                if dmin > best_d:
+                    best, best_d = cand, dmin
+                if dmin > 1.0:
+                    break
+            x[v] = best
+        g = nx.Graph()
+        for v in range(n):
+            g.add_node(v, element=int(Z[v]))
+        D = np.linalg.norm(x[:, None, :] - x[None, :, :], axis=2)
+        ii, jj = np.nonzero(np.triu(D < cutoff, k=1))
+        for i, j in zip(ii.tolist(), jj.tolist()):
+            d = float(np.float32(D[i, j]))
+            g.add_edge(i, j, w=float(np.float32(1.0 - d / cutoff)), length=d)
+        out.append(Graph.from_networkx(g, weight='w'))
+    return Graph.unify_datatype(out)
