@@ -413,6 +413,23 @@ def gpr_step_line(args, world, rank, local_rank):
     # fall back to the numpy kernel protocol?)
     on_device = gpr._device_gramian(gpr._dense(), kernel, graphs,
                                     False) is not None
+    # per rank: kernel part (solvers of the shard + all-gather of the values
+    # + reassembly), dense algebra (replicated factorisation + this rank's
+    # share of the gradient contraction + the all-reduce of n_theta numbers),
+    # and the phases of the sharded kernel step by device events
+    mine = {'kernel_ms': 1e3 * parts['kernel'] / args.steps,
+            'dense_ms': 1e3 * parts['linalg'] / args.steps}
+    step_ = getattr(backend, 'last_step', None)
+    if step_ is not None:
+        ph = step_.phase_ms(steps=3)
+        mine.update(shard_ms=ph['shard_ms'], collective_ms=ph[
+            'all_gather_ms'] + ph['reassembly_ms'], all_gather_ms=ph[
+            'all_gather_ms'], reassembly_ms=ph['reassembly_ms'],
+            gradient_gathered=bool(step_.gather_gradient))
+    per_rank = [mine]
+    if dist is not None and world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if dist is not None and world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device='cpu' if host_collective else 'cuda')
@@ -443,11 +460,15 @@ def gpr_step_line(args, world, rank, local_rank):
                                'on the solver, Cholesky and the gradient '
                                'contractions in float64 torch on the same GPU',
                    'graphs': n, 'pairs': n_pairs,
-                   'parallelism': (f'pair-sharded x{world}, device-resident '
-                                   'reassembly, replicated dense algebra')
+                   'parallelism': (f'pair-sharded x{world}: values '
+                                   'all-gathered and reassembled on the '
+                                   'device, gradient contracted pair shard '
+                                   'by pair shard + one all-reduce of '
+                                   'n_theta numbers, factorisation replicated')
                    if dist is not None else 'single'},
         'kernel_ms': 1e3 * parts['kernel'] / args.steps,
         'dense_algebra_ms': 1e3 * parts['linalg'] / args.steps,
+        'per_rank': {k: [r.get(k) for r in per_rank] for k in per_rank[0]},
         'device_resident_kernel_matrix': bool(on_device),
         'collective': None if dist is None else
         ('gloo/host' if host_collective else 'nccl(RCCL)'),
@@ -824,6 +845,22 @@ def main():
                 isolated_ms[k] += iso_ev[k][0].elapsed_ms(iso_ev[k][1])
         isolated_ms /= args.isolated_steps
     barrier()
+    # the three phases of a sharded step on every rank (device time): what a
+    # first multi-GPU run is read by -- slowest shard + collective + reassembly
+    phases = None
+    if sharded:
+        mine = step.phase_ms(steps=5)
+        if world > 1:
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+        else:
+            every = [mine]
+        phases = {k: [float(e[k]) for e in every] for k in mine}
+        phases['note'] = ('per rank, HIP events on the null stream of 5 '
+                          'synchronised steps: solver launches of the rank\'s '
+                          'shard | all-gather of the packed slabs | device '
+                          'reassembly into the column-major matrix')
+    barrier()
 
     if rank != 0:
         if sharded:
@@ -1142,7 +1179,8 @@ def main():
         'roofline': roofline, 'compute': compute, 'lds': lds,
         'step_aggregate': step_aggregate, 'kernels': per_kernel,
         'cpu_baseline': cpu, 'api_inclusive': api,
-        'sharded_check': sharded_check, 'other_arithmetic': other,
+        'sharded_check': sharded_check, 'phases_per_rank': phases,
+        'other_arithmetic': other,
         # host time to issue one step (launches, events, collective)
         'host_enqueue_ms': host_enqueue_ms,
     }

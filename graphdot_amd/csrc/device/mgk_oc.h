@@ -281,8 +281,8 @@ struct oc_solver {
     // ~9 issue slots per term against ~23, for (n1 n2) / (d1 d2) ~ 1.3 times
     // the terms.  Decided per pair (wave-uniform) from the four counts in the
     // graph headers.
-    // Measured on the dense molecular set (scripts/sessions/r4_session10.sh,
-    // r4_session12.sh): float values 4.98 -> 6.31 M pairs/s, float value +
+    // Measured on the dense molecular set (profiles/sessions.md r4_session10,
+    // r4_session12): float values 4.98 -> 6.31 M pairs/s, float value +
     // gradient 3.55 -> 3.93 M; 8 vector instructions per term against 19 for
     // 1.3 x the terms, bank conflicts 59 % -> 2 % of the LDS cycles, and the
     // vector pipe saturated (VALU busy 101-107 %): what is left per term is
@@ -351,7 +351,7 @@ struct oc_solver {
     // capped at 128 registers -- a slot is 2 + 1/2 registers instead of 3:
     // configuration 2's (16,40,2) 1.85 -> 1.18 ms, (16,64,3) 1.02 -> 0.88;
     // the 4- and 8-wave variants have the registers and only pay the unpack
-    // (+6 ... 9 %, scripts/sessions/r4_session8.sh).  GD_OC_PACK=3: double out.
+    // (+6 ... 9 %, profiles/sessions.md r4_session8).  GD_OC_PACK=3: double out.
     constexpr static bool PACK = GD_OC_PACK != 0 && C == 1 && !NODAL && !STATIC && !FLY &&
                                  ((sizeof(real) == 4 ? (S >= 64 && W >= 8)
                                                      : (GD_OC_PACK != 3 && W >= 16)) || GD_OC_PACK == 2);
@@ -367,7 +367,7 @@ struct oc_solver {
     // to spare beside p, the row sums, the row map and the images.  The table
     // is mirrored by HIPBackend.lds_slot_bytes (LDS sizing and the LDS limit
     // of the classification); -DGD_OC_SL=0 turns it off, =n sets n slots.
-    // Configuration 2 in double (scripts/sessions/r4_session17.sh), 10 slots
+    // Configuration 2 in double (profiles/sessions.md r4_session17), 10 slots
     // (80 KB of a 1024-lane workgroup; 12 overflow the 160 KB with (16,64,3)):
     // (16,40,2) 1.19 -> 0.97 ms, (16,64,3) 0.87 -> 0.74 ms, the step 4.95 ->
     // 4.64 ms; 4 / 6 / 8 slots: 4.76 / 4.72 / 4.67 ms.
@@ -416,7 +416,7 @@ struct oc_solver {
     // gather addresses from scratch inside the iteration.  It then runs no
     // faster at three waves (3.08 ms) than with x in registers at two (2.98):
     // the extra LDS operations cost what the third wave hides; at two waves
-    // the LDS form loses 9 % (scripts/sessions/r4_session4.sh).
+    // the LDS form loses 9 % (profiles/sessions.md r4_session4).
     constexpr static bool SEQ_XLDS = SEQ && GD_OC_SEQ_XLDS != 0;
     constexpr static bool LEAN = STATIC && C == 2 && !NODAL && !SEQ;
 #ifndef GD_OC_FSCAL
@@ -449,7 +449,7 @@ struct oc_solver {
     // r -= A d with the double matrix (one pass over the slots); the last
     // round stops at the caller's sqrt(rTr) < ftol N.  The reference's rule
     // (marginalized_kernel.h:449) then holds for the TRUE residual.
-    // MEASURED AND LEFT OFF (scripts/sessions/r4_session14.sh, 1000 QM7-like
+    // MEASURED AND LEFT OFF (profiles/sessions.md r4_session14, 1000 QM7-like
     // graphs, ftol 1e-8): 18.1 float iterations per pair in two rounds, K
     // within 5.7e-8 of the converged oracle -- and 147 M pairs/s against the
     // 153 M of the double iteration with float scalars (FSCAL): the float
@@ -1178,7 +1178,7 @@ struct oc_solver {
                             // unrolled to the 32-node limit behind uniform
                             // branches -- the kernels fell from five waves per
                             // SIMD to three and lost: 7.9 against 9.8 M pairs/s,
-                            // scripts/sessions/r4_session25.sh.  The loop is bound
+                            // profiles/sessions.md r4_session25.  The loop is bound
                             // by the vector pipe -- four v_exp_f32 at quarter rate
                             // are half of a trip -- not by these reads.)
                             for (unsigned j2 = 0; j2 < (unsigned)n2; j2 += 4) {
@@ -1348,6 +1348,11 @@ struct oc_solver {
                 // SEQ: the stacked rule rTr_0 + rTr_1 < tol^2 -- half the budget
                 // for the first system, what it left for the second
                 sreal tol2 = (sreal)(tol * tol);
+                // (FSCAL compares float sums: a tolerance whose square is under
+                // float's normal range -- ftol below ~1e-19 / N -- must not
+                // round to 0, or no residual ever passes and every pair runs to
+                // the iteration cap)
+                if constexpr (FSCAL) tol2 = tol2 < sreal(1.17549435e-38f) ? sreal(1.17549435e-38f) : tol2;
                 if constexpr (SEQ) tol2 = sys == 0 ? tol2 * sreal(0.5) : tol2 - rTr_first;
                 [[maybe_unused]] bool last_round = false;
                 if constexpr (MIXED) {

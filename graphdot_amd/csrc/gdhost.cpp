@@ -13,6 +13,8 @@
 #include <cstring>
 #include <numeric>
 #include <atomic>
+#include <exception>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -67,25 +69,51 @@ inline int host_threads(int64_t n, int64_t min_items) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(configured, by_size));
 }
 
-// fn(begin, end, thread index) over [0, n) cut into T contiguous ranges
+// fn(begin, end, thread index) over [0, n) cut into T contiguous ranges.
+// Every range runs exactly once: a range whose thread cannot be created
+// (std::system_error under a pid / thread limit -- containers, eight ranks per
+// node) runs on the calling thread; an exception inside a worker is carried to
+// the caller (a std::thread that lets one escape calls std::terminate) and
+// re-thrown there, where the entry points' function-try-blocks turn it into
+// an error code.
 template<class F> inline void parallel_ranges(int64_t n, int T, F &&fn) {
     if (T <= 1) {
         fn((int64_t)0, n, 0);
         return;
     }
     std::vector<std::thread> pool;
-    pool.reserve((size_t)T - 1);
+    std::vector<char> started((size_t)T, 0);
+    std::exception_ptr failure;
+    std::mutex failure_lock;
+    auto guarded = [&](int k) {
+        try {
+            fn(n * k / T, n * (k + 1) / T, k);
+        } catch (...) {
+            std::lock_guard<std::mutex> hold(failure_lock);
+            if (!failure) failure = std::current_exception();
+        }
+    };
+    try {
+        pool.reserve((size_t)T - 1);
+        for (int k = 1; k < T; ++k) {
+            pool.emplace_back(guarded, k);
+            started[(size_t)k] = 1;
+        }
+    } catch (...) {
+        // no more threads to be had: the remaining ranges run here
+    }
+    guarded(0);
     for (int k = 1; k < T; ++k)
-        pool.emplace_back([&, k] { fn(n * k / T, n * (k + 1) / T, k); });
-    fn((int64_t)0, n / T, 0);
+        if (!started[(size_t)k]) guarded(k);
     for (auto &th : pool) th.join();
+    if (failure) std::rethrow_exception(failure);
 }
 
 }  // namespace
 
 extern "C" {
 
-const char *gdh_version(void) { return "gdhost 4.0 (round 4)"; }
+const char *gdh_version(void) { return "gdhost 5.0 (round 5)"; }
 
 int gdh_pack_graphs(int32_t G, const int64_t *node_off, const int64_t *edge_off,
                     const int64_t *node_id, const int64_t *ei, const int64_t *ej,
@@ -96,7 +124,7 @@ int gdh_pack_graphs(int32_t G, const int64_t *node_off, const int64_t *edge_off,
                     int64_t *sec_off, int64_t *nnz, uint16_t *perm, int64_t *rank,
                     float *degree, int64_t *count, uint16_t *rowptr, uint16_t *nz,
                     int64_t *eid, int64_t nz_capacity, int64_t *nz_off,
-                    int64_t *maxdeg) {
+                    int64_t *maxdeg) try {
     if (G < 0 || node_size < 0 || label_size < 0 || edge_size < 0) return -1;
     if (weight_bytes != 0 && weight_bytes != 4 && weight_bytes != 8) return -1;
     struct entry_t {
@@ -257,12 +285,12 @@ int gdh_pack_graphs(int32_t G, const int64_t *node_off, const int64_t *edge_off,
         }
     });
     return 0;
-}
+} catch (...) { return -3; }   // (bad_alloc, system_error: never across the C ABI)
 
 int gdh_number_records(const uint8_t *rec, int64_t n, int32_t itemsize,
                        const int32_t *part_off, const int32_t *part_len,
                        int32_t n_parts, int32_t *cls, int64_t *first,
-                       int64_t *n_classes) {
+                       int64_t *n_classes) try {
     if (n < 0 || itemsize < 0 || n_parts < 0) return -1;
     int64_t klen = 0;
     for (int32_t p = 0; p < n_parts; ++p) {
@@ -346,7 +374,7 @@ int gdh_number_records(const uint8_t *rec, int64_t n, int32_t itemsize,
     for (int64_t i = 0; i < n; ++i) cls[i] = number[(size_t)tmp[(size_t)i]];
     *n_classes = nc;
     return 0;
-}
+} catch (...) { return -3; }   // (bad_alloc, system_error: never across the C ABI)
 
 int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
                     const int32_t *n_node, const int32_t *n_nz,
@@ -355,7 +383,7 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
                     const int32_t *S, const int32_t *R, const int32_t *D,
                     const int32_t *n_L, const int32_t *L, int32_t C,
                     int32_t real_size, int64_t lds_limit, int32_t fly_min_degree,
-                    const int64_t *extra_lds, int32_t *choice, int64_t *NP) {
+                    const int64_t *extra_lds, int32_t *choice, int64_t *NP) try {
     if (n_pairs < 0 || n_var < 0 || (C != 1 && C != 2)) return -1;
     (void)n_nz;
     constexpr int MAXL = 12;
@@ -448,10 +476,10 @@ int gdh_classify_oc(int64_t n_pairs, const int32_t *ca, const int32_t *cb,
     }
     });
     return 0;
-}
+} catch (...) { return -3; }   // (bad_alloc, system_error: never across the C ABI)
 
 int gdh_pair_keys(const uint32_t *jobs, int64_t n_jobs, const int32_t *cid,
-                  int32_t n_graphs, int32_t nc, int32_t *pk, int64_t *count) {
+                  int32_t n_graphs, int32_t nc, int32_t *pk, int64_t *count) try {
     if (n_jobs < 0 || nc <= 0) return -1;
     const size_t nk = (size_t)nc * (size_t)nc;
     const int T = host_threads(n_jobs, 65536);
@@ -479,11 +507,11 @@ int gdh_pair_keys(const uint32_t *jobs, int64_t n_jobs, const int32_t *cid,
         count[key] = c;
     }
     return 0;
-}
+} catch (...) { return -3; }   // (bad_alloc, system_error: never across the C ABI)
 
 int gdh_order_jobs(const int32_t *pk, int64_t n_jobs, const int32_t *rank_of_key,
                    int64_t n_keys, int64_t n_ranks, uint32_t *order,
-                   const uint32_t *jobs, uint32_t *jobs_sorted) {
+                   const uint32_t *jobs, uint32_t *jobs_sorted) try {
     if (n_jobs < 0 || n_keys < 0 || n_ranks < 0) return -1;
     if (n_jobs > 0xFFFFFFFFll) return -1;
     // Stable counting sort by rank, the job list cut into contiguous ranges
@@ -539,11 +567,11 @@ int gdh_order_jobs(const int32_t *pk, int64_t n_jobs, const int32_t *rank_of_key
         }
     });
     return 0;
-}
+} catch (...) { return -3; }   // (bad_alloc, system_error: never across the C ABI)
 
 int gdh_gather_section(const uint8_t *blob, const int64_t *blob_off, const int64_t *sec_off,
                        int32_t col, const int64_t *count, int64_t G, int32_t itemsize,
-                       uint8_t *out, int64_t out_bytes) {
+                       uint8_t *out, int64_t out_bytes) try {
     if (G < 0 || col < 0 || col >= 6 || itemsize < 0) return -1;
     int64_t at = 0;
     for (int64_t g = 0; g < G; ++g) {
@@ -553,12 +581,12 @@ int gdh_gather_section(const uint8_t *blob, const int64_t *blob_off, const int64
         at += nb;
     }
     return 0;
-}
+} catch (...) { return -3; }   // (bad_alloc, system_error: never across the C ABI)
 
 int gdh_assemble_arena(int64_t G, const uint8_t *blob, const int64_t *blob_off,
                        const int64_t *starts, const int64_t *cbytes, const int64_t *n_node,
                        const int64_t *n_nz, const uint8_t *ncls, const uint8_t *ecls,
-                       uint8_t *host, int64_t host_bytes) {
+                       uint8_t *host, int64_t host_bytes) try {
     if (G < 0) return -1;
     int64_t vn = 0, ve = 0;
     for (int64_t g = 0; g < G; ++g) {
@@ -576,9 +604,9 @@ int gdh_assemble_arena(int64_t G, const uint8_t *blob, const int64_t *blob_off,
         ve += n_nz[g];
     }
     return 0;
-}
+} catch (...) { return -3; }   // (bad_alloc, system_error: never across the C ABI)
 
-int gdh_pairwise_jobs(int64_t nx, int64_t ny, uint32_t *jobs) {
+int gdh_pairwise_jobs(int64_t nx, int64_t ny, uint32_t *jobs) try {
     if (nx < 0 || ny < -1 || nx + (ny > 0 ? ny : 0) > 0xFFFFFFFFll) return -1;
     int64_t t = 0;
     if (ny < 0) {          // symmetric: the upper triangle with the diagonal
@@ -595,6 +623,6 @@ int gdh_pairwise_jobs(int64_t nx, int64_t ny, uint32_t *jobs) {
             }
     }
     return 0;
-}
+} catch (...) { return -3; }   // (bad_alloc, system_error: never across the C ABI)
 
 }  // extern "C"

@@ -81,7 +81,8 @@ def _p(a):
 def _check(rc, what):
     if rc != 0:
         raise HostLibError(f'{what} failed with code {rc} '
-                           '(-1: bad argument, -2: capacity)')
+                           '(-1: bad argument, -2: capacity, -3: exception inside '
+                           'the library, e.g. out of memory)')
 
 
 def _c(a, dtype):

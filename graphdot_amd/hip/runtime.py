@@ -203,10 +203,17 @@ PINNED_MIN_BYTES = 256 << 10
 PINNED_MAX_BYTES = 96 << 20
 #: pinned bytes the pool may hold idle (what is lent out is not counted)
 PINNED_POOL_BYTES = 256 << 20
+#: pinned bytes that may be LENT OUT at a time (GD_PINNED_LIMIT_MB): a caller
+#: who keeps many result arrays -- a hyperparameter sweep storing every Gram
+#: matrix -- would otherwise pin gigabytes of host memory that cannot be
+#: swapped; past the limit results are ordinary pageable arrays (they take
+#: the staging copy, 0.7 ms per 8 MB)
+PINNED_LIMIT_BYTES = int(os.environ.get('GD_PINNED_LIMIT_MB', 1024)) << 20
 _pinned_lock = threading.Lock()
 _pinned_free = {}        # capacity -> [pointer, ...]
 _pinned_idle = 0
 _pinned_live = {}        # pointer -> capacity (lent out)
+_pinned_lent = 0         # sum of the capacities lent out
 
 
 class _PinnedBlock:
@@ -215,16 +222,19 @@ class _PinnedBlock:
     gone the block goes back to the pool."""
 
     def __init__(self, ptr, cap, nbytes):
-        self.ptr, self.cap = ptr, cap
+        self.ptr, self.cap, self.pid = ptr, cap, os.getpid()
         self.__array_interface__ = dict(
             shape=(nbytes,), typestr='|u1', data=(ptr, False), version=3)
 
     def __del__(self):
-        global _pinned_idle
-        if _lib is None:
+        global _pinned_idle, _pinned_lent
+        # (a forked child inherits the arrays, not the HIP context that pinned
+        # them: the block is the parent's to free or to pool)
+        if _lib is None or self.pid != os.getpid():
             return
         with _pinned_lock:
-            _pinned_live.pop(self.ptr, None)
+            if _pinned_live.pop(self.ptr, None) is not None:
+                _pinned_lent -= self.cap
             if _pinned_idle + self.cap <= PINNED_POOL_BYTES:
                 _pinned_free.setdefault(self.cap, []).append(self.ptr)
                 _pinned_idle += self.cap
@@ -246,7 +256,7 @@ def pinned_empty(size, dtype):
     the array and all its views are gone; pinning costs 0.2 ms per MB, which
     is why they are kept.  Small and very large arrays stay pageable."""
     import numpy as np
-    global _pinned_idle
+    global _pinned_idle, _pinned_lent
     dtype = np.dtype(dtype)
     nbytes = int(size) * dtype.itemsize
     if not (PINNED_MIN_BYTES <= nbytes <= PINNED_MAX_BYTES) \
@@ -257,6 +267,9 @@ def pinned_empty(size, dtype):
         else -(-nbytes // (8 << 20)) * (8 << 20)
     ptr = None
     with _pinned_lock:
+        if _pinned_lent + cap > PINNED_LIMIT_BYTES:
+            return np.empty(int(size), dtype)
+        _pinned_lent += cap          # (reserved; given back on failure)
         free = _pinned_free.get(cap)
         if free:
             ptr = free.pop()
@@ -269,6 +282,8 @@ def pinned_empty(size, dtype):
         except HIPError:
             # (no device, or no pinnable memory left: a pageable array; the
             # evaluation that follows reports a missing device itself)
+            with _pinned_lock:
+                _pinned_lent -= cap
             return np.empty(int(size), dtype)
         ptr = p.value
     with _pinned_lock:
@@ -279,6 +294,8 @@ def pinned_empty(size, dtype):
 
 def is_pinned(array):
     """Does `array` lie in a block of the pinned pool?"""
+    if not _pinned_live:
+        return False
     a = array.ctypes.data
     with _pinned_lock:
         for ptr, cap in _pinned_live.items():

@@ -10,7 +10,6 @@ menu of register-resident solver variants (see ``csrc/device/mgk_solver.h``).
 There is no CPU path: a missing ``libgdhip.so`` / hipcc / device raises.
 """
 import copy
-import gc
 import os
 import re
 import uuid
@@ -18,6 +17,7 @@ import zlib
 from collections import OrderedDict, namedtuple
 import numpy as np
 from ...codegen import Template
+from ...util import gcpause
 from ...util.cookie import IdentityCache
 from ...codegen.sympy_printer import to_real_expr
 from ...codegen.typetool import _dtype_util
@@ -872,7 +872,7 @@ struct ${name}_t : ${name}_theta_t {
                      (1, 20, 4, 4): 2, (1, 24, 4, 4): 3, (1, 28, 5, 4): 3,
                      (1, 28, 6, 4): 2, (1, 32, 7, 4): 2, (1, 36, 9, 4): 2},
         # (static layouts: the sequential solves of mgk_oc.h SEQ, round 4 --
-        # scripts/sessions/r4_session2.sh / r4_session4.sh: three waves only
+        # profiles/sessions.md r4_session2 / r4_session4: three waves only
         # where the loop stays free of scratch reloads, the three-batch kernel)
         (True, 2): {('L', 16): 2, ('L', 16, 4): 2, ('L', 16, 4, 1): 3, ('L', 16, 4, 4): 2,
                     ('L', 16, 4, 4, 1): 2, ('L', 16, 4, 4, 1, 1): 2,
@@ -1075,11 +1075,14 @@ void ${name}(params_t prm) {
         out = np.where(first, w1, w2) * 16 + -(-stage // 16) * 16
         return np.where(ok1 | ok2, out, np.iinfo(np.int64).max // 4)
 
-    def lds_slot_bytes(self, v, C):
+    def lds_slot_bytes(self, v, C, nodal=False):
         """LDS bytes of the slot values a variant keeps in LDS instead of
-        registers (mgk_oc.h SL: the 16-wave double value solvers, 10 slots per
-        lane)."""
+        registers (mgk_oc.h SL, `lds_slot_count`: the 16-wave double
+        graph-level value solvers, 10 slots per lane; nodal outputs -- and
+        with them the nodal-gradient and maximin launches -- keep every slot
+        in registers)."""
         if (isinstance(v, OCVariant) and not v.L and C == 1 and v.W == 16
+                and not nodal
                 and v.S in (40, 64) and np.dtype(self.real) == np.float64):
             n = 10
             for f in self.hipcc_extra:           # (-DGD_OC_SL=n: experiments)
@@ -1089,7 +1092,7 @@ void ${name}(params_t prm) {
             return n * 64 * v.W * 8
         return 0
 
-    def lds_bytes(self, v, C, ntask=0, gbytes=0, tab_bytes=0):
+    def lds_bytes(self, v, C, ntask=0, gbytes=0, tab_bytes=0, nodal=False):
         """LDS bytes of one workgroup: static p + scratch, dynamic U, the two
         staged graph images per pair slot and the microkernel tables."""
         if isinstance(v, OCVariant):
@@ -1103,7 +1106,7 @@ void ${name}(params_t prm) {
             NR_y = 0 if ((v.L and C != 2) or v.S == 0) else NR
             return (pcap + NR_y) * C * rs + 4 * NR + 2 * np.asarray(gbytes) \
                 + 4 * v.W * rs + 4 * (128 if v.D > 6 else 64) + 256 + 16 \
-                + self.lds_slot_bytes(v, C)
+                + self.lds_slot_bytes(v, C, nodal)
         wpb = WPB1 if v.W == 1 else 1
         T = 64 * v.W
         ucap = -(-np.asarray(ntask) // 64) * 64 + 64
@@ -1196,7 +1199,7 @@ void ${name}(params_t prm) {
         return worst
 
     def classify(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
-                 oc_only=False):
+                 oc_only=False, nodal=False):
         """Assign every job the cheapest solver variant it fits.  Returns
         (variant index, cost, stage-1 tasks, image bytes, padded rows, image
         bytes incl. class ids) per job.
@@ -1208,11 +1211,11 @@ void ${name}(params_t prm) {
         QM7-like molecules): large job lists are classified once per pair of
         graph classes and looked up."""
         sel, out = self._classify_classes(ji, jj, dgraphs, C, tab_bytes, gtab,
-                                          oc_only)
+                                          oc_only, nodal=nodal)
         return out if sel is None else tuple(a[sel.sel] for a in out)
 
     def _classify_classes(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
-                          oc_only=False, jobs=None):
+                          oc_only=False, jobs=None, nodal=False):
         """(sel, per-class-pair results): job t has the results of class pair
         sel.sel[t] (`ClassPairs`: class-pair key per job, jobs per key); sel is
         None for short job lists (results are per job).  `jobs`: the job list
@@ -1224,7 +1227,7 @@ void ${name}(params_t prm) {
             ji = np.asarray(ji, dtype=np.int64)
             jj = np.asarray(jj, dtype=np.int64)
             return None, self._classify_pairs(ji, jj, dgraphs, C, tab_bytes,
-                                              gtab, oc_only)
+                                              gtab, oc_only, nodal)
         # graphs of one degree histogram and image size are classified alike
         f = graph_features(dgraphs)
         if int(f['max_degree'].max()) < HIST_BINS - 1:
@@ -1261,7 +1264,7 @@ void ${name}(params_t prm) {
             count = np.bincount(pk, minlength=nc * nc)
         upk = np.flatnonzero(count)
         out = self._classify_pairs(rep[upk // nc], rep[upk % nc], dgraphs, C,
-                                   tab_bytes, gtab, oc_only)
+                                   tab_bytes, gtab, oc_only, nodal)
         return ClassPairs(pk, upk, count, nc), out
 
     #: row batches the trip tables cover (static layouts have at most this many)
@@ -1293,7 +1296,7 @@ void ${name}(params_t prm) {
         return tr, row
 
     def _classify_pairs(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
-                        oc_only=False):
+                        oc_only=False, nodal=False):
         f = graph_features(dgraphs)
         n_node, n_nz = f['n_node'], f['n_nz']
         deg_sorted = None      # (the two-stage variants' walk: made on demand)
@@ -1340,7 +1343,7 @@ void ${name}(params_t prm) {
                 ji, jj, n_node, n_nz, image_oc, maxdeg, hist,
                 [(v.W, v.S, v.R, v.D, v.L) for _, v in menu], C,
                 np.dtype(self.real).itemsize, LDS_LIMIT, FLY_MIN_DEGREE,
-                [self.lds_slot_bytes(v, C) for _, v in menu])
+                [self.lds_slot_bytes(v, C, nodal) for _, v in menu])
             idx = np.array([k for k, _ in menu], dtype=np.int64)
             hit = ch >= 0
             choice[hit] = idx[ch[hit]]
@@ -1365,8 +1368,8 @@ void ${name}(params_t prm) {
                         continue
                     fits = (N[rem] <= 64 * v.W * v.R) & (NP[rem] < 0x3FFF) \
                         & (pair_maxdeg[rem] > FLY_MIN_DEGREE)
-                    fits &= self.lds_bytes(v, C, NP[rem], gbytes_oc[rem]) \
-                        <= LDS_LIMIT
+                    fits &= self.lds_bytes(v, C, NP[rem], gbytes_oc[rem],
+                                           nodal=nodal) <= LDS_LIMIT
                     choice[rem[fits]] = k
                     rem = rem[~fits]
                     continue
@@ -1374,8 +1377,8 @@ void ${name}(params_t prm) {
                         & (NP[rem] < 0xFFFF))
                 if not fits.any():
                     continue
-                fits &= self.lds_bytes(v, C, NP[rem], gbytes_oc[rem]) \
-                    <= LDS_LIMIT
+                fits &= self.lds_bytes(v, C, NP[rem], gbytes_oc[rem],
+                                       nodal=nodal) <= LDS_LIMIT
                 if v.L:
                     # static layout: the trip count of every batch under its
                     # segment (looked up per pair of distinct histograms)
@@ -1503,14 +1506,14 @@ void ${name}(params_t prm) {
         return dgraphs, edge_kernel, C, fields
 
     def _partition(self, dgraphs, jobs, C, tab_bytes=0, gtab=False,
-                   oc_only=False, merge_map=None):
+                   oc_only=False, merge_map=None, nodal=False):
         """Host half of a layout: solver variant per job, launch order (by
         variant, then descending cost) and launch geometry.  No device."""
         jobs = np.ascontiguousarray(jobs)
         jobs_sorted = None             # (set by the native ordering)
         sel, (choice, cost, ntask, gbytes, NP, gbytes_oc) = \
             self._classify_classes(None, None, dgraphs, C, tab_bytes, gtab,
-                                   oc_only, jobs=jobs)
+                                   oc_only, jobs=jobs, nodal=nodal)
         # Launch order: by variant, then descending cost, then job index.
         # `choice` ... `gbytes_oc` are per class pair (or per job when sel is
         # None); the jobs are ordered by the rank of their class pair with one
@@ -1561,7 +1564,8 @@ void ${name}(params_t prm) {
                         applied[k] = k2
                         break
         choice = self._fit_launches_into_lds(choice, C, NP, ntask, gbytes,
-                                             gbytes_oc, tab_bytes, oc_only)
+                                             gbytes_oc, tab_bytes, oc_only,
+                                             nodal)
         rank_of = np.empty(len(choice), dtype=np.int64)
         by_rank = np.lexsort((-cost, choice))
         # class pairs of equal (variant, cost) share a rank: their jobs stay
@@ -1623,7 +1627,7 @@ void ${name}(params_t prm) {
                 NR = 64 * v.W * v.R
                 dyn = (pcap + (0 if ((v.L and C != 2) or v.S == 0)
                                else NR)) * C * rsize + 4 * NR + 2 * gcap
-                dyn += self.lds_slot_bytes(v, C)
+                dyn += self.lds_slot_bytes(v, C, nodal)
                 dense = False
                 if v.S == 0:
                     # on-the-fly variants: the dense n x n edge-record arrays
@@ -1665,19 +1669,20 @@ void ${name}(params_t prm) {
         out.jobs_sorted, out.merge_map = jobs_sorted, applied
         return out
 
-    def _launch_lds(self, v, C, NP, ntask, gbytes, gbytes_oc, tab_bytes):
+    def _launch_lds(self, v, C, NP, ntask, gbytes, gbytes_oc, tab_bytes,
+                    nodal=False):
         """LDS of a workgroup -- static and dynamic, `lds_bytes` -- of ONE
         launch of variant `v` over the given class pairs (or jobs): the
         regions are sized for the largest vector and the largest image among
         them -- two maxima that need not belong to one pair."""
         if isinstance(v, OCVariant):
             return int(self.lds_bytes(v, C, int(NP.max()),
-                                      int(gbytes_oc.max())))
+                                      int(gbytes_oc.max()), nodal=nodal))
         return int(self.lds_bytes(v, C, int(ntask.max()), int(gbytes.max()),
                                   tab_bytes))
 
     def _fit_launches_into_lds(self, choice, C, NP, ntask, gbytes, gbytes_oc,
-                               tab_bytes, oc_only):
+                               tab_bytes, oc_only, nodal=False):
         """Every pair was given a variant whose LDS regions hold IT; a launch
         sizes its regions for the largest vector and the largest graph image
         among its pairs, and the two can come from different pairs: the sum
@@ -1697,7 +1702,7 @@ void ${name}(params_t prm) {
                 idx = np.flatnonzero(choice == k)
                 if not len(idx) or self._launch_lds(
                         v, C, NP[idx], ntask[idx], gbytes[idx],
-                        gbytes_oc[idx], tab_bytes) <= limit:
+                        gbytes_oc[idx], tab_bytes, nodal) <= limit:
                     break
                 if fallback is None:
                     if oc_only or GENERAL not in self.variants:
@@ -1716,7 +1721,7 @@ void ${name}(params_t prm) {
                     keep = np.setdiff1d(idx, out)
                     after = self._launch_lds(
                         v, C, NP[keep], ntask[keep], gbytes[keep],
-                        gbytes_oc[keep], tab_bytes) if len(keep) else 0
+                        gbytes_oc[keep], tab_bytes, nodal) if len(keep) else 0
                     cand.append((after, len(out), out))
                 after, _, out = min(cand, key=lambda c: (c[0], c[1]))
                 choice = choice.copy()
@@ -1778,8 +1783,9 @@ void ${name}(params_t prm) {
         arena = self._host_arena(dgraphs, fields)
         tab_bytes = self._table_bytes(arena)
         gtab = self._global_tables(arena)
-        jobs, used, order_all, launches = self._partition(dgraphs, jobs, C,
-                                                          tab_bytes, gtab)
+        jobs, used, order_all, launches = self._partition(
+            dgraphs, jobs, C, tab_bytes, gtab,
+            nodal=traits.nodal is not False)
         sources = self._sources(used, node_kernel, edge_kernel, p, dgraphs, C,
                                 traits.nodal is not False, tab_bytes > 0,
                                 gtab)
@@ -1794,7 +1800,8 @@ void ${name}(params_t prm) {
         return jit.compile_many(list(sources.values()), self.hipcc_extra)
 
     def _layout(self, dgraphs, jobs, starts, C, fields=(None, None),
-                timer=None, ngrad=False, maximin=False, merge_map=None):
+                timer=None, ngrad=False, maximin=False, merge_map=None,
+                nodal=False):
         """Everything of a plan that depends only on WHICH pairs of WHICH
         graphs are evaluated: variant per job, launch order and geometry, and
         the device copies of the job list, the order and `starts`.  Cached
@@ -1810,7 +1817,7 @@ void ${name}(params_t prm) {
             ('crc', zlib.crc32(jobs.view(np.uint8)))
         key = (_ids(dgraphs), len(jobs), jobs_id,
                zlib.crc32(starts.view(np.uint8)), C, fields, self.tables,
-               ngrad, maximin,
+               ngrad, maximin, bool(nodal),
                None if merge_map is None else tuple(sorted(merge_map.items())))
         hit = self._layouts.get(key)
         if hit is not None:
@@ -1832,7 +1839,8 @@ void ${name}(params_t prm) {
             lay.tab_bytes = 0
         tic('  solver variants and launch order')
         part = self._partition(dgraphs, jobs, C, lay.tab_bytes, lay.gtab,
-                               oc_only=ngrad or maximin, merge_map=merge_map)
+                               oc_only=ngrad or maximin, merge_map=merge_map,
+                               nodal=nodal)
         jobs, lay.used, lay.order_host, lay.launches = part
         toc('  solver variants and launch order')
         tic('  job list to the device')
@@ -1879,7 +1887,8 @@ void ${name}(params_t prm) {
         dgraphs, edge_kernel, C, fields = self._graphs_and_kernels(
             graphs, node_kernel, edge_kernel, traits, timer, ngrad)
         lay = self._layout(dgraphs, jobs, starts, C, fields, timer, ngrad,
-                           maximin is not None, merge_map)
+                           maximin is not None, merge_map,
+                           nodal=traits.nodal is not False)
         tab = lay.tab_bytes > 0
 
         tic('code generation')
@@ -2310,9 +2319,8 @@ void ${name}(params_t prm) {
         # packed-graph handles, cookies -- none of them part of a cycle: the
         # cyclic collector, which would walk the caller's whole heap of graphs
         # for ~8 ms if its threshold fell inside, waits until the call is over)
-        gc_was_on = gc.isenabled()
-        gc.disable()
-        try:
+        # (counted and thread-safe, GD_PAUSE_GC=0 turns it off: util/gcpause.py)
+        with gcpause.paused():
             plan = self.prepare(graphs, node_kernel, edge_kernel, p, q, eps,
                                 ftol, gtol, jobs, starts, nX, nY, nJ, traits,
                                 timer)
@@ -2321,6 +2329,3 @@ void ${name}(params_t prm) {
             runtime.synchronize()
             timer.toc('GPU kernel execution')
             self.collect(plan, gramian, gradient)
-        finally:
-            if gc_was_on:
-                gc.enable()

@@ -523,10 +523,8 @@ def pack_many(graphs, real=np.float32, native=True):
     # (a thousand small objects in a row: keep the cyclic collector from
     # walking the caller's heap in the middle of it -- nothing here can be
     # part of a cycle)
-    import gc
-    gc_was_on = gc.isenabled()
-    gc.disable()
-    try:
+    from ...util import gcpause
+    with gcpause.paused():
         new = _BatchMember.__new__
         ibytes = r['features']['image_bytes'].tolist()
         for b_, k in enumerate(batch):
@@ -539,9 +537,6 @@ def pack_many(graphs, real=np.float32, native=True):
                 'weighted': weighted, 'node_t': node_t, 'edge_t': edge_t,
                 'signature': signature, 'image_bytes': ibytes[b_],
                 '_max_degree': maxdeg[b_]}
-    finally:
-        if gc_was_on:
-            gc.enable()
     return out
 
 

@@ -33,6 +33,15 @@ def _type_error(pred, hint):
         f'types. {hint}\nFirst graph: {first}\nSecond graph: {second}\n')
 
 
+class LocalGradient:
+    """One rank's share of a pair-sharded symmetric gradient: `dK[p, :]` (a
+    device tensor, all `n_dims` columns) belongs to the pair `(i[p], j[p])`,
+    i <= j; the ranks of `group` hold every unordered pair exactly once."""
+
+    def __init__(self, dK, i, j, group=None):
+        self.dK, self.i, self.j, self.group = dK, i, j, group
+
+
 class MarginalizedGraphKernel:
     """Random-walk graph kernel of Kashima, Tsuda & Inokuchi (ICML 2003) in
     the linear-system form of Tang & de Jong (J. Chem. Phys. 150, 044107).
@@ -249,7 +258,8 @@ class MarginalizedGraphKernel:
                     gradient.astype(self.element_dtype, copy=False))
         return gramian.astype(self.element_dtype, copy=False)
 
-    def device_gram(self, X, eval_gradient=False, lmin=0):
+    def device_gram(self, X, eval_gradient=False, lmin=0,
+                    local_gradient=False):
         """The symmetric Gram matrix of `X` (and its gradient) left in device
         memory: the HIP backend's output buffers as zero-copy views
         (`graphdot_amd.hip.runtime.DeviceArray`; ``torch.as_tensor(view,
@@ -259,7 +269,16 @@ class MarginalizedGraphKernel:
         valid until the next evaluation on this backend.  For consumers that
         continue on the GPU (model.gaussian_process): saves the download, the
         float64 conversion on the host and the upload of ``n^2 (1 + n_dims)``
-        numbers per call."""
+        numbers per call.
+
+        `local_gradient=True` (with `eval_gradient`): under a backend that
+        shards the pairs over ranks the gradient is NOT all-gathered; the
+        second return value is then a `LocalGradient` -- the gradient entries
+        of this rank's pairs, ``dK[p, :]`` for pair ``(i[p], j[p])``, every
+        unordered pair of the symmetric matrix on exactly one rank -- for a
+        consumer that reduces over pairs and all-reduces the result
+        (model.gaussian_process: ``sum_ij W_ij dK_ij``).  Any other backend
+        returns the full planes as before."""
         from ...hip.runtime import DeviceArray
         backend = self.backend
         if not hasattr(backend, 'prepare'):
@@ -282,11 +301,15 @@ class MarginalizedGraphKernel:
                 X, self.node_kernel, self.edge_kernel, self.p, self.q,
                 self.eps, self.ftol, self.gtol, self._pairwise_jobs(nx),
                 np.arange(nx + 1, dtype=np.uint32), nx, nx, self.n_dims,
-                traits)
+                traits, gather_gradient=not (eval_gradient
+                                             and local_gradient))
             base = step.result.data_ptr()
             K = DeviceArray.fortran(base, (nx, nx), real, owner=step)
             if not eval_gradient:
                 return K
+            if local_gradient:
+                i, j = step.local_index
+                return K, LocalGradient(step.local_gradient, i, j, step.group)
             dK = DeviceArray.fortran(base + nx * nx * real.itemsize,
                                      (nx, nx, self.n_dims), real, owner=step)
             return K, dK

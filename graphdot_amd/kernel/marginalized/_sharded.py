@@ -445,7 +445,13 @@ class ShardedStep:
     def __init__(self, backend, graphs, node_kernel, edge_kernel, p, q, eps,
                  ftol, gtol, jobs, starts, nX, nY, nJ, traits, group=None,
                  timer=None, shard_plan=None, collective='torch',
-                 pipeline=False):
+                 pipeline=False, gather_gradient=True):
+        """`gather_gradient=False` (value + gradient steps): only the VALUES
+        are all-gathered and reassembled; the gradient entries of this rank's
+        pairs stay in its slab (`local_gradient`, rows in the order of
+        `local_index`) for a consumer that reduces over pairs -- the Gaussian
+        process contracts them with K^-1 - a a^T and all-reduces n_theta
+        numbers instead of moving n_theta planes (gpr.py:287-298)."""
         import torch
         import torch.distributed as dist
         from ...hip import runtime
@@ -469,6 +475,10 @@ class ShardedStep:
         self.nX, self.nY = int(nX), int(nY)
         self.n_grad = int(nJ) if traits.eval_gradient is True else 0
         n_cols = self.n_cols = 1 + self.n_grad
+        self.gather_gradient = bool(gather_gradient) or self.n_grad == 0
+        # columns that travel: the collective and the reassembly see the
+        # first `g_cols` * capacity entries of a slab
+        g_cols = self.g_cols = n_cols if self.gather_gradient else 1
         jobs = np.ascontiguousarray(jobs)
         if shard_plan is None:
             shard_plan = measured_shard_plan(
@@ -491,15 +501,16 @@ class ShardedStep:
                                            dtype=self.tdtype,
                                            device=self.device)
                                for _ in range(self.depth)]
-            self.gathereds = [torch.empty(self.world * max(cap * n_cols, 1),
+            self.gathereds = [torch.empty(self.world * max(cap * g_cols, 1),
                                           dtype=self.tdtype,
                                           device=self.device)
                               for _ in range(self.depth)]
             self.local_out, self.gathered = self.local_outs[0], \
                 self.gathereds[0]
-            self.result = torch.zeros(n_cols * self.nX * self.nY,
+            self.result = torch.zeros(g_cols * self.nX * self.nY,
                                       dtype=self.tdtype, device=self.device)
-            src, dst = sp.reassembly_index(self.n_grad)
+            src, dst = sp.reassembly_index(self.n_grad if self.gather_gradient
+                                           else 0)
             self.t_src = torch.from_numpy(src).to(self.device)
             self.t_dst = torch.from_numpy(dst).to(self.device)
             # every element of the result has a source (the usual case: the
@@ -535,21 +546,29 @@ class ShardedStep:
             for out in self.local_outs]
         self.plan = self.plans[0]
 
-    def enqueue(self, events=None, serial=False):
+    def enqueue(self, events=None, serial=False, phases=None):
         """One step: solver launches, all-gather, reassembly -- all
         asynchronous (`LaunchSet` orders the solver streams against the null
         stream, on which torch runs the collective and the reassembly).
         `events[k] = (start, stop)` are recorded around launch k on the
-        stream it runs on (bench.py's per-kernel timing)."""
+        stream it runs on (bench.py's per-kernel timing).  `phases`: four
+        events recorded on the null stream -- step start, solvers done,
+        all-gather done, reassembly done (`phase_ms`)."""
         import torch
         import torch.distributed as dist
         b = self._count % self.depth
         self._count += 1
         local_out, gathered = self.local_outs[b], self.gathereds[b]
         self.local_out, self.gathered = local_out, gathered   # (the latest)
+        if phases is not None:
+            phases[0].record()
         self.launch_set.enqueue(self.plans[b], events, serial,
                                 front=self.front,
                                 after=(self.buffer_free[b],))
+        if phases is not None:
+            phases[1].record()        # (the null stream waits for the solvers)
+        if not self.gather_gradient:
+            local_out = local_out[:max(self.capacity, 1)]     # values only
         with torch.cuda.device(self.device):
             if self.comm is not None:
                 # null stream: behind the solvers (LaunchSet) and in front of
@@ -565,12 +584,49 @@ class ShardedStep:
                 g = torch.empty(self.world * h.numel(), dtype=h.dtype)
                 dist.all_gather_into_tensor(g, h, group=self.group)
                 gathered.copy_(g)
+            if phases is not None:
+                phases[2].record()
             if self.t_perm is not None:
                 torch.index_select(gathered, 0, self.t_perm, out=self.result)
             else:
                 self.result.index_copy_(
                     0, self.t_dst, gathered.index_select(0, self.t_src))
+        if phases is not None:
+            phases[3].record()
         self.buffer_free[b].record()       # (null stream: slabs are consumed)
+
+    def phase_ms(self, steps=5):
+        """Device time of the three phases of a step on this rank, averaged
+        over `steps` steps: {'shard_ms': this rank's solver launches,
+        'all_gather_ms': the collective (for a gloo group: the copies through
+        host memory included), 'reassembly_ms': slabs -> matrix}.  What makes
+        a multi-GPU run diagnosable: the slowest shard, the collective and the
+        reassembly add up to the step."""
+        from ...hip import runtime
+        ev = [[runtime.Event() for _ in range(4)] for _ in range(steps)]
+        self.enqueue()
+        self.synchronize()
+        for k in range(steps):
+            self.enqueue(phases=ev[k])
+            self.synchronize()      # (phases of different steps do not overlap)
+        out = {}
+        for name, a in (('shard_ms', 0), ('all_gather_ms', 1),
+                        ('reassembly_ms', 2)):
+            out[name] = float(np.mean([e[a].elapsed_ms(e[a + 1]) for e in ev]))
+        return out
+
+    @property
+    def local_index(self):
+        """(i, j) of this rank's pairs, in the order of its slab."""
+        return (self.local_jobs['i'].astype(np.int64),
+                self.local_jobs['j'].astype(np.int64))
+
+    @property
+    def local_gradient(self):
+        """(pairs of this rank, n_grad) device view of the gradient entries
+        in this rank's slab (row p: pair `local_index[p]`)."""
+        n, cap = len(self.local_jobs), self.capacity
+        return self.local_out[cap:cap + n * self.n_grad].view(n, self.n_grad)
 
     def synchronize(self):
         import torch
@@ -600,6 +656,9 @@ class ShardedStep:
     @property
     def gradient(self):
         """(nX, nY, n_grad) device view of the gradient planes."""
+        if not self.gather_gradient:
+            raise RuntimeError('this step keeps the gradient in the ranks\' '
+                               'slabs (gather_gradient=False): local_gradient')
         n = self.nX * self.nY
         return self.result[n:].view(self.n_grad, self.nY, self.nX).permute(
             2, 1, 0)
@@ -691,13 +750,14 @@ def distributed_backend(**kwargs):
 
         def sharded_step(self, graphs, node_kernel, edge_kernel, p, q, eps,
                          ftol, gtol, jobs, starts, nX, nY, nJ, traits,
-                         timer=None):
+                         timer=None, gather_gradient=True):
             """Evaluate the graph-level job list over the ranks and leave the
             reassembled result on this rank's device: returns the
             `ShardedStep` (`.values` / `.gradient` / `.result`), enqueued and
             synchronised.  Steps are cached per (graphs, jobs, traits): a
             repeated evaluation with new hyperparameters only re-binds the
-            kernel arguments."""
+            kernel arguments.  `gather_gradient=False`: the gradient stays
+            in the ranks' slabs (`ShardedStep.local_gradient`)."""
             import torch.distributed as dist
             rank, world = dist.get_rank(), dist.get_world_size()
             jobs = np.ascontiguousarray(jobs) if not isinstance(
@@ -708,7 +768,8 @@ def distributed_backend(**kwargs):
             plan_key, (sp, _, kept) = self._shard_plan(
                 graphs, dgraphs, node_kernel, edge_kernel, jobs, int(nX),
                 int(nY), traits, rank, world)
-            key = (id(sp), int(nJ), traits)
+            gather_gradient = bool(gather_gradient)
+            key = (id(sp), int(nJ), traits, gather_gradient)
             step = self._steps.get(key)
             if step is None:
                 if len(self._steps) > 4:
@@ -719,7 +780,8 @@ def distributed_backend(**kwargs):
                         self, graphs, node_kernel, edge_kernel, p, q, eps,
                         ftol, gtol, jobs, starts, nX, nY, nJ, traits,
                         timer=timer, shard_plan=plan,
-                        collective=self.collective, pipeline=self.pipeline)
+                        collective=self.collective, pipeline=self.pipeline,
+                        gather_gradient=gather_gradient)
                 step = build(sp)
                 if (world > 1 and self.rebalance > 0
                         and len(jobs) >= self.rebalance_min_jobs * world):
@@ -730,7 +792,7 @@ def distributed_backend(**kwargs):
                     # is one cached object shared by every set of n graphs
                     # and by value and value + gradient evaluations
                     self._shard_plans[plan_key] = (sp, jobs, kept)
-                    key = (id(sp), int(nJ), traits)
+                    key = (id(sp), int(nJ), traits, gather_gradient)
                 self._steps[key] = step
             else:
                 step.bind(node_kernel, edge_kernel, p, q, eps, ftol, gtol,

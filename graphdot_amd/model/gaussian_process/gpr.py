@@ -54,6 +54,40 @@ def _contract_planes(W, dK):
     return (W.unsqueeze(-1) * dK).sum((0, 1))
 
 
+def _contract_local(W, lg, keep=None):
+    """The same contraction from ONE RANK'S share of a pair-sharded
+    symmetric gradient (`LocalGradient` of the marginalized kernel: the rows
+    `dK[p, :]` of the pairs `(i[p], j[p])`, i <= j, every unordered pair on
+    exactly one rank): ``sum_p m_p W[i_p, j_p] dK[p, :]`` with m = 2 off the
+    diagonal, then ONE all-reduce of n_theta numbers over the ranks -- instead
+    of an all-gather and a reassembly of n_theta planes of n^2 numbers
+    followed by the same contraction on every rank.  `keep`: indices of the
+    rows / columns of the full matrix that W covers (masked targets)."""
+    torch = _torch()
+    import torch.distributed as dist
+    i = torch.as_tensor(lg.i, device=W.device)
+    j = torch.as_tensor(lg.j, device=W.device)
+    if keep is not None:
+        # W lives on the kept rows: scatter it into the full index space
+        n = int(max(int(i.max()) if len(i) else 0,
+                    int(j.max()) if len(j) else 0, int(keep.max())) + 1)
+        full = torch.zeros((n, n), dtype=W.dtype, device=W.device)
+        full[keep[:, None], keep[None, :]] = W
+        W = full
+    w = W[i, j] * torch.where(i == j, 1.0, 2.0).to(W.dtype)
+    d = w @ lg.dK.to(W.dtype)
+    if dist.is_available() and dist.is_initialized() \
+            and dist.get_world_size(lg.group) > 1:
+        from ...kernel.marginalized._sharded import cuda_collective
+        if cuda_collective(lg.group):
+            dist.all_reduce(d, group=lg.group)
+        else:
+            h = d.cpu()
+            dist.all_reduce(h, group=lg.group)
+            d = h.to(W.device)
+    return d
+
+
 class _Dense:
     """float64 dense algebra on one device."""
 
@@ -320,7 +354,8 @@ class GaussianProcessRegressor:
         return ymean
 
     # -- objectives ----------------------------------------------------------------
-    def _objective_inputs(self, theta, X, y, eval_gradient, clone_kernel):
+    def _objective_inputs(self, theta, X, y, eval_gradient, clone_kernel,
+                          local_gradient=False):
         theta = np.array(theta if theta is not None else self.kernel.theta,
                          dtype=float)
         X = X if X is not None else self._X
@@ -335,7 +370,8 @@ class GaussianProcessRegressor:
             kernel.theta = theta
         t = time.perf_counter()
         la = self._dense()
-        on_device = self._device_gramian(la, kernel, X, eval_gradient)
+        on_device = self._device_gramian(la, kernel, X, eval_gradient,
+                                         local_gradient)
         if on_device is not None:
             Kt, dKt = on_device
         elif eval_gradient is True:
@@ -345,26 +381,32 @@ class GaussianProcessRegressor:
             Kt, dKt = la.tensor(self._gramian(self.alpha, X, kernel=kernel)), \
                 None
         t_kernel = time.perf_counter() - t
+        self._keep = None
         if not y_mask.all():
             keep = _torch().as_tensor(np.flatnonzero(y_mask),
                                       device=la.device)
             Kt = Kt.index_select(0, keep).index_select(1, keep)
-            if dKt is not None:
+            if dKt is not None and not hasattr(dKt, 'dK'):
                 dKt = dKt.index_select(0, keep).index_select(1, keep)
+            self._keep = keep          # (a LocalGradient is indexed in full)
         return theta, la, Kt, dKt, la.tensor(y), t_kernel
 
-    def _device_gramian(self, la, kernel, X, jac):
+    def _device_gramian(self, la, kernel, X, jac, local_gradient=False):
         """Regularised float64 kernel matrix (and gradient over the active
         hyperparameters) as device tensors, straight from the kernel's device
         buffers -- if the kernel offers them (`device_gram` of the HIP
         marginalized graph kernel), the algebra runs on that GPU and no
-        kernel options are in the way; None otherwise."""
+        kernel options are in the way; None otherwise.  `local_gradient`:
+        accept this rank's share of a pair-sharded gradient
+        (`LocalGradient`) in place of the planes."""
         if la.device.type != 'cuda' or self.kernel_options \
                 or not hasattr(kernel, 'device_gram'):
             return None
         torch = _torch()
         try:
-            out = kernel.device_gram(X, eval_gradient=jac)
+            out = kernel.device_gram(X, eval_gradient=jac,
+                                     **({'local_gradient': True}
+                                        if jac and local_gradient else {}))
         except TypeError:            # not the HIP backend
             return None
         Kd, dKd = out if jac else (out, None)
@@ -372,7 +414,16 @@ class GaussianProcessRegressor:
         diag = torch.diagonal(K)
         diag.copy_(self._regularize(diag, self.alpha))
         dK = None
-        if dKd is not None:
+        if hasattr(dKd, 'dK'):
+            # this rank's pairs only: (pairs, n_dims) rows, masked below
+            mask = np.asarray(kernel.active_theta_mask)
+            rows = dKd.dK
+            if rows.shape[1] == len(mask) and not mask.all():
+                rows = rows.index_select(1, torch.as_tensor(
+                    np.flatnonzero(mask), device=la.device))
+            dKd.dK = rows
+            dK = dKd
+        elif dKd is not None:
             dK = torch.as_tensor(dKd, device=la.device)
             # a graph kernel hands over all its columns; transformers
             # (kernel/fix.py) already work on what the kernel protocol returns
@@ -389,7 +440,7 @@ class GaussianProcessRegressor:
         """``y^T K^-1 y + log|K|`` at the log-scale hyperparameters `theta`
         (and its gradient w.r.t. `theta`)."""
         theta, la, K, dK, y, t_kernel = self._objective_inputs(
-            theta, X, y, eval_gradient, clone_kernel)
+            theta, X, y, eval_gradient, clone_kernel, local_gradient=True)
         torch = _torch()
         t = time.perf_counter()
         Kinv, logdet = la.factor(K, self.beta)
@@ -400,7 +451,12 @@ class GaussianProcessRegressor:
         if eval_gradient is True:
             # tr(K^-1 dK_k) - (K^-1 y)^T dK_k (K^-1 y) = sum_ij W_ij dK_ijk
             # with the symmetric W = K^-1 - (K^-1 y)(K^-1 y)^T: one pass over dK
-            d = _contract_planes(Kinv - torch.outer(Ky, Ky), dK)
+            W = Kinv - torch.outer(Ky, Ky)
+            if hasattr(dK, 'dK'):
+                # pair-sharded kernel: this rank's pairs, then one all-reduce
+                d = _contract_local(W, dK, self._keep)
+            else:
+                d = _contract_planes(W, dK)
             grad = d.cpu().numpy() * np.exp(theta)
         t_linalg = time.perf_counter() - t
         if verbose:

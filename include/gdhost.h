@@ -19,7 +19,10 @@
  *                         cost-ordered job list per variant)
  *
  * Every function returns 0 on success, a negative code on bad arguments
- * (-1) or a capacity that is too small (-2).  The numpy implementations in
+ * (-1), a capacity that is too small (-2), or an exception inside the library
+ * (-3: out of memory, no worker thread to be had and the like -- nothing is
+ * thrown across this boundary).  Worker threads that cannot be created cost
+ * nothing but time: their ranges run on the calling thread.  The numpy implementations in
  * graphdot_amd/kernel/marginalized/_devicegraph.py and _backend_hip.py stay
  * as the specification: the tests hold the native results to them byte for
  * byte.

@@ -1,7 +1,7 @@
-"""The distributed backend (`_sharded.distributed_backend`): two ranks (one
-process each, sharing the single GPU of the test box through gloo) evaluate
-the kernel through the ordinary API; every rank must end up with the full
-matrix and gradient, equal to the single-process result."""
+"""The distributed backend (`_sharded.distributed_backend`): two and EIGHT
+ranks (one process each, sharing the single GPU of the test box through gloo)
+evaluate the kernel through the ordinary API; every rank must end up with the
+full matrix and gradient, equal to the single-process result."""
 import os
 import sys
 import numpy as np
@@ -39,18 +39,39 @@ def _worker(rank, world, port, tmp):
         and on_device[1].is_cuda
     assert on_device[1].shape == (len(G), len(G), len(k.theta))
     lml, glml = gpr.log_marginal_likelihood(eval_gradient=True)
+    # the likelihood's gradient came from this rank's pairs and one
+    # all-reduce: the gradient planes were never gathered
+    step = k.backend.last_step
+    assert step.n_grad == len(k.theta) and not step.gather_gradient
+    assert len(step.local_jobs) < len(G) * (len(G) + 1) // 2
     loo, gloo = gpr.squared_loocv_error(eval_gradient=True)
+    assert k.backend.last_step.gather_gradient      # (needs whole planes)
+    # masked targets: W covers the kept rows, the pairs are indexed in full
+    y2 = [None if i % 7 == 3 else float(np.cos(i)) for i in range(len(G))]
+    gpr2 = GaussianProcessRegressor(k, alpha=float(0.1 * d.mean()))
+    gpr2.X, gpr2.y = G, y2
+    lml2, glml2 = gpr2.log_marginal_likelihood(eval_gradient=True)
+    phases = step.phase_ms(steps=2)
+    assert set(phases) == {'shard_ms', 'all_gather_ms', 'reassembly_ms'}
+    assert all(v > 0 for v in phases.values())
     np.savez(os.path.join(tmp, f'rank{rank}.npz'), K=K, K2=K2, dK=dK,
-             Kxy=Kxy, d=d, lml=lml, glml=glml, loo=loo, gloo=gloo)
+             Kxy=Kxy, d=d, lml=lml, glml=glml, loo=loo, gloo=gloo,
+             lml2=lml2, glml2=glml2)
     dist.destroy_process_group()
 
 
-def test_two_ranks_through_the_kernel_api(tmp_path):
+@pytest.mark.parametrize('world', [2, 8])
+def test_ranks_through_the_kernel_api(tmp_path, world):
+    """Values, value + gradient, an X x Y block, `diag` and the Gaussian
+    process step end to end on `world` ranks (eight: the rank count of the
+    node BASELINE.json's configurations 4 and 5 name), every rank a process of
+    its own, against one rank."""
     import torch.multiprocessing as mp
     import cases
     from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
-    port = 29700 + os.getpid() % 200
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29700 + (os.getpid() + 11 * world) % 200
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world,
+             join=True)
     G = cases.config3_graphs(30, seed=6)
     knode, kedge, q = cases.config3_kernels()
     # (bit for bit: the same solver variant per pair -- launch merging is
@@ -61,7 +82,7 @@ def test_two_ranks_through_the_kernel_api(tmp_path):
     K2, dK = k(G, eval_gradient=True)
     Kxy = k(G[:12], G[12:])
     d = k.diag(G)
-    for rank in range(2):
+    for rank in range(world):
         r = np.load(tmp_path / f'rank{rank}.npz')
         assert np.array_equal(r['K'], K)
         assert np.array_equal(r['K2'], K2) and np.array_equal(r['dK'], dK)
@@ -77,11 +98,24 @@ def test_two_ranks_through_the_kernel_api(tmp_path):
     assert gpr._device_gramian(gpr._dense(), k, G, True) is not None
     lml, glml = gpr.log_marginal_likelihood(eval_gradient=True)
     loo, gloo = gpr.squared_loocv_error(eval_gradient=True)
-    r0, r1 = (np.load(tmp_path / f'rank{r}.npz') for r in range(2))
-    assert float(r0['lml']) == float(r1['lml']) == lml
-    assert np.array_equal(r0['glml'], glml) and np.array_equal(r1['glml'], glml)
-    assert float(r0['loo']) == float(r1['loo']) == loo
-    assert np.array_equal(r0['gloo'], gloo)
+    y2 = [None if i % 7 == 3 else float(np.cos(i)) for i in range(len(G))]
+    gpr2 = GaussianProcessRegressor(k, alpha=float(0.1 * d.mean()))
+    gpr2.X, gpr2.y = G, y2
+    lml2, glml2 = gpr2.log_marginal_likelihood(eval_gradient=True)
+    r0 = np.load(tmp_path / 'rank0.npz')
+    for rank in range(world):
+        r = np.load(tmp_path / f'rank{rank}.npz')
+        # the same matrix bit for bit, hence the same factor and objective
+        assert float(r['lml']) == lml and float(r['lml2']) == lml2
+        assert float(r['loo']) == loo
+        assert np.array_equal(r['gloo'], gloo)
+        # the likelihood's gradient is summed pair shard by pair shard and
+        # all-reduced: equal on every rank, round-off away from the
+        # contraction of whole planes on one rank
+        assert np.array_equal(r['glml'], r0['glml'])
+        assert np.array_equal(r['glml2'], r0['glml2'])
+        assert np.allclose(r['glml'], glml, rtol=1e-10, atol=1e-12 * np.abs(glml).max())
+        assert np.allclose(r['glml2'], glml2, rtol=1e-10, atol=1e-12 * np.abs(glml2).max())
     # ... and against the numpy kernel protocol (host arrays, float64
     # conversion on the host) to round-off
     slow = GaussianProcessRegressor(k, alpha=float(0.1 * d.mean()),

@@ -1,6 +1,6 @@
 """A short run of the differential fuzzer (scripts/fuzz_parity.py) inside the
 GPU suite: fixed seeds, every call mode drawn at random -- the long campaigns
-are in scripts/sessions/r4_session4*.sh / r4_session5*.sh."""
+are recorded in profiles/sessions.md (r4_session4x / r4_session5x)."""
 import os
 import subprocess
 import sys

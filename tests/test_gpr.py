@@ -4,6 +4,7 @@ reference), with a small vector kernel that implements the kernel protocol --
 no GPU needed.  The marginalized graph kernel is plugged in by the GPU test
 at the end."""
 import copy
+import os
 import numpy as np
 import pytest
 from graphdot_amd.model.gaussian_process import GaussianProcessRegressor
@@ -587,3 +588,72 @@ def test_native_blocked_cholesky():
     (v1, g1), (v0, g0) = results
     assert v1 == pytest.approx(v0, rel=1e-10)
     assert np.allclose(g1, g0, rtol=1e-8)
+
+
+def _sharded_contraction_case(seed=3, n=23, nt=5):
+    rng = np.random.default_rng(seed)
+    A = rng.normal(size=(n, n))
+    W = A + A.T
+    dK = rng.normal(size=(n, n, nt))
+    dK = dK + dK.transpose(1, 0, 2)
+    i, j = np.triu_indices(n)
+    return W, dK, i, j
+
+
+def test_gradient_contraction_from_pair_shards():
+    """`_contract_local`: the likelihood gradient's contraction
+    sum_ij W_ij dK_ijk (reference gpr.py:287-298) taken over the pairs one
+    rank holds -- i <= j, off-diagonal pairs twice -- and summed over the
+    ranks equals the contraction over the full planes; with masked targets
+    (W on the kept rows only) too."""
+    import torch
+    from graphdot_amd.kernel.marginalized._kernel import LocalGradient
+    from graphdot_amd.model.gaussian_process.gpr import (
+        _contract_local, _contract_planes)
+    W, dK, i, j = _sharded_contraction_case()
+    Wt, dKt = torch.from_numpy(W), torch.from_numpy(dK)
+    want = _contract_planes(Wt, dKt).numpy()
+    parts = np.array_split(np.random.default_rng(0).permutation(len(i)), 3)
+    got = sum(_contract_local(Wt, LocalGradient(
+        torch.from_numpy(dK[i[p], j[p], :]), i[p], j[p])).numpy()
+        for p in parts)
+    assert np.allclose(got, want, rtol=1e-12)
+    keep = np.array([k for k in range(len(W)) if k % 4 != 1])
+    Wk = torch.from_numpy(W[np.ix_(keep, keep)])
+    want = _contract_planes(Wk, torch.from_numpy(
+        dK[np.ix_(keep, keep)])).numpy()
+    got = sum(_contract_local(Wk, LocalGradient(
+        torch.from_numpy(dK[i[p], j[p], :]), i[p], j[p]),
+        torch.from_numpy(keep)).numpy() for p in parts)
+    assert np.allclose(got, want, rtol=1e-12)
+
+
+def _contraction_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from graphdot_amd.kernel.marginalized._kernel import LocalGradient
+    from graphdot_amd.model.gaussian_process.gpr import _contract_local
+    W, dK, i, j = _sharded_contraction_case()
+    p = np.arange(len(i))[rank::world]
+    d = _contract_local(torch.from_numpy(W), LocalGradient(
+        torch.from_numpy(dK[i[p], j[p], :]), i[p], j[p]))
+    np.save(os.path.join(tmp, f'd{rank}.npy'), d.numpy())
+    dist.destroy_process_group()
+
+
+def test_gradient_contraction_all_reduced_over_gloo_ranks(tmp_path):
+    """The same over a world-size-2 gloo group: every rank contracts its
+    pairs and ends up, after one all-reduce of n_theta numbers, with the
+    contraction over the full planes."""
+    import torch
+    import torch.multiprocessing as mp
+    from graphdot_amd.model.gaussian_process.gpr import _contract_planes
+    port = 29400 + os.getpid() % 500
+    mp.spawn(_contraction_worker, args=(2, port, str(tmp_path)), nprocs=2,
+             join=True)
+    W, dK, i, j = _sharded_contraction_case()
+    want = _contract_planes(torch.from_numpy(W), torch.from_numpy(dK)).numpy()
+    for r in range(2):
+        assert np.allclose(np.load(tmp_path / f'd{r}.npy'), want, rtol=1e-12)
