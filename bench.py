@@ -1038,11 +1038,14 @@ def main():
             v, _ = batch.run(i[sel], j[sel], q=q, real=args.dtype, omp=omp)
             return v, None
 
-        probe = rng.choice(n_pairs, size=min(500, n_pairs), replace=False)
+        # (pairs of the large-graph configuration take ~0.1 s each on one
+        # core: a probe of 500 would be a minute)
+        n_probe = 16 if args.config == 'large' else 500
+        probe = rng.choice(n_pairs, size=min(n_probe, n_pairs), replace=False)
         t1 = time.perf_counter()
         run(probe)
         rate = len(probe) / (time.perf_counter() - t1)
-        size = int(min(n_pairs, max(500, rate * args.cpu_seconds)))
+        size = int(min(n_pairs, max(n_probe, rate * args.cpu_seconds)))
         sample = rng.choice(n_pairs, size=size, replace=False)
         t1 = time.perf_counter()
         ref, gref = run(sample)
@@ -1068,7 +1071,8 @@ def main():
             # a sample of >= 5 s: the pair list repeated if it is too short
             # (the short probe under-estimates the steady rate: grow until
             # the timed call is long enough)
-            size_all, dt_all = int(max(2000, rate_all * 6.0)), 0.0
+            size_all, dt_all = int(max(2000 if args.config != 'large' else
+                                       4 * ncore, rate_all * 6.0)), 0.0
             for _ in range(4):
                 sample_all = rng.choice(n_pairs, size=min(size_all, n_pairs),
                                         replace=False)

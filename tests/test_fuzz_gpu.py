@@ -20,6 +20,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (51, 'bulk', 10),
     (4, 'sym,lmin,nodal', 4),  # (tiny graphs among the sizes; the float-rounded
     #                            one-row systems have a test of their own)
+    # round 5: the pair-list API; Normalize(DotProduct()) / Convolution on
+    # nodes and edges of sparse and dense graphs; spatial graphs of 65-300
+    # nodes (16-wave on-the-fly, streamed and general solvers); two ranks
+    # through the pair-sharded path
+    (11, 'pairlist', 6),
+    (12, 'features', 6),
+    (13, 'spatial', 2),
+    (14, 'sharded', 2),
 ])
 def test_fuzzer_rounds(seed, modes, rounds):
     cmd = [sys.executable, os.path.join(ROOT, 'scripts', 'fuzz_parity.py'),
