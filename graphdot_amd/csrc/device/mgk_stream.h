@@ -31,7 +31,7 @@
 //
 // Scratch per workgroup: [x | r | p | Ap | diag], N reals each
 // (prm.u_capacity reals).  Dynamic LDS: [image of B | A_ROWS rows of p per
-// group], sized pair by pair.  The edge microkernel is evaluated per term and iteration, as the
+// group | one partial sum per lane], sized pair by pair.  The edge microkernel is evaluated per term and iteration, as the
 // reference does (marginalized_kernel.h:299-300,346): nnz_A nnz_B values do
 // not fit anywhere (5e7 per pair), and streaming them from HBM costs what
 // re-evaluating them does.
@@ -54,8 +54,15 @@ struct stream_solver {
 #endif
     constexpr static int A_ROWS = GD_STREAM_ROWS;     // rows of p staged per pass and group
 
+#ifndef GD_STREAM_CAP
+#define GD_STREAM_CAP 16
+#endif
+    constexpr static int SEG_CAP = GD_STREAM_CAP;     // neighbours of B per lane segment (doubled until the segments fit)
+    constexpr static int MAX_LAYERS = 64;             // nB <= TPB = 1024 = 64 * 16
+
     struct lds_t {
         real red[2 * W];
+        int lay_off[MAX_LAYERS + 1];
     };
 
     // bytes of the contiguous image [degree .. perm] of a graph, in 16-byte units
@@ -70,6 +77,7 @@ struct stream_solver {
     __device__ static __forceinline__ void run(P const &prm, lds_t &lds, char *dyn, real *scratch_all) {
         const int tid = threadIdx.x;
         real *const red = lds.red;
+        int *const lay_off = lds.lay_off;
         real *const scratch = scratch_all + (size_t)blockIdx.x * prm.u_capacity;
         graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
         char *const lG = dyn;
@@ -108,12 +116,62 @@ struct stream_solver {
             }
             __syncthreads();
 
-            // thread -> (group g, lane lb of the group); G rows of A per step
-            const int LB = (nB + 63) & ~63;
-            const int G = TPB / LB;              // >= 1: nB <= TPB (host)
+            // ---- virtual rows of B ----------------------------------------------
+            // A lane that owned a whole node of B would walk its d_B neighbours
+            // for every neighbour a of iA, and the workgroup moves in lockstep
+            // (the staged rows of p are shared): with 3 ... 35 neighbours per
+            // node every wave waits for the one that holds the hubs -- the
+            // step takes max(d_B) where the mean is a third of it.  So a node
+            // is cut into SEGMENTS of at most CAP neighbours and a lane owns a
+            // segment.  Nodes are stored by descending degree, so layer l --
+            // the (l + 1)-th segments of the nodes with more than l CAP
+            // neighbours -- is a prefix 0 .. c_l - 1 of the node list: segment
+            // s of layer l belongs to node s - off_l, no table.  Layers are
+            // laid out one after the other (each sorted by length); the
+            // partial sums meet in LDS, the lane of a node's first segment
+            // adds them up in layer order (deterministic).  CAP: 16, doubled
+            // until the segments fit the workgroup's lanes.
+            int cap = SEG_CAP, nV = 0, nlay = 0;
+            for (;; cap *= 2) {
+                // c_l by binary search in the degree-sorted node list (every
+                // thread the same numbers: wave-uniform control flow)
+                nV = 0;
+                nlay = 0;
+                for (int l = 0; l < MAX_LAYERS; ++l) {
+                    int c = nB;
+                    if (l > 0) {
+                        int lo = 0, hi = nB;       // first node with degree <= l cap
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            const int d = (int)gB.rowptr[mid + 1] - (int)gB.rowptr[mid];
+                            if (d > l * cap) lo = mid + 1;
+                            else hi = mid;
+                        }
+                        c = lo;
+                    }
+                    if (c == 0) break;
+                    if (tid == 0) lay_off[l] = nV;
+                    nV += c;
+                    nlay = l + 1;
+                }
+                if (nV <= TPB) break;
+            }
+            if (tid == 0) lay_off[nlay] = nV;
+            __syncthreads();
+            // thread -> (group g, virtual row lb of the group); G rows of A per step
+            const int LB = (nV + 63) & ~63;
+            const int G = TPB / LB;              // >= 1: nV <= TPB
             const int g = tid / LB, lb = tid - g * LB;
-            const bool lane_ok = g < G && lb < nB;
+            const bool seg_ok = g < G && lb < nV;          // owns a segment
+            const bool lane_ok = g < G && lb < nB;         // owns a node (its first segment)
+            int lay = 0;
+            for (int l = 1; l < nlay; ++l) lay += lb >= lay_off[l] ? 1 : 0;
+            const int iBs = seg_ok ? lb - lay_off[lay] : 0;  // node of this lane's segment
+            const int seg_b0 = seg_ok ? (int)gB.rowptr[iBs] + lay * cap : 0;
+            const int seg_end = seg_ok ? (int)gB.rowptr[iBs + 1] : 0;
+            const int seg_b1 = seg_b0 + cap < seg_end ? seg_b0 + cap : seg_end;
             real *const st = stage + (size_t)g * A_ROWS * nB;
+            real *const ys = stage + (size_t)G * A_ROWS * nB + (size_t)g * LB;
 
             // ---- diagonal, right-hand side, start vectors ---------------------
             real rTz = 0;
@@ -148,9 +206,10 @@ struct stream_solver {
                         const int d = (int)gA.rowptr[base + k + 1] - (int)gA.rowptr[base + k];
                         dmax = d > dmax ? d : dmax;
                     }
-                    const int b0 = lane_ok ? (int)gB.rowptr[lb] : 0;
-                    const int b1 = lane_ok && row_ok ? (int)gB.rowptr[lb + 1] : b0;
+                    const int b0 = seg_b0;
+                    const int b1 = row_ok ? seg_b1 : b0;
                     real acc = 0;
+                    __syncthreads();     // the partial sums of the step before are read
                     for (int a0 = 0; a0 < dmax; a0 += A_ROWS) {
                         __syncthreads();     // the rows staged before are consumed
                         const int nv = dA - a0 < A_ROWS ? dA - a0 : A_ROWS;   // (wave-uniform; may be <= 0)
@@ -176,7 +235,12 @@ struct stream_solver {
                             }
                         }
                     }
+                    // partial sums of the segments -> their nodes
+                    if (seg_ok) ys[lb] = acc;
+                    __syncthreads();
                     if (lane_ok && row_ok) {
+                        for (int l = 1; l < nlay; ++l)
+                            if (lb < lay_off[l + 1] - lay_off[l]) acc += ys[lay_off[l] + lb];
                         const size_t i = (size_t)iA * nB + lb;
                         const real pv = Pv[i];
                         const real Ap = DG[i] * pv - acc;
@@ -185,7 +249,9 @@ struct stream_solver {
                     }
                 }
                 pAp = block_reduce<real, W>::sum(pAp, red);    // (its barriers publish AP)
-                if (pAp == real(0)) break;
+                // (pAp != pAp: a NaN must end the solve, not run it for N
+                // iterations -- the reference's rules do not stop on one)
+                if (pAp == real(0) || pAp != pAp) break;
                 const real alpha = rTz / pAp;
                 real rTr = 0, rTz_next = 0;
                 for (int i = tid; i < N; i += TPB) {

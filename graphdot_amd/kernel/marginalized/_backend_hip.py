@@ -109,6 +109,8 @@ STREAM = Variant(-2, 0, 0)
 STREAM_THREADS = 1024
 #: rows of p staged per pass and row group (mgk_stream.h A_ROWS)
 STREAM_ROWS = 4
+#: neighbours per lane segment of the LDS-resident graph (mgk_stream.h SEG_CAP)
+STREAM_CAP = 16
 LDS_LIMIT = 160 * 1024
 _LARGE_PAIR_SOLVERS = ([STREAM] if os.environ.get('GD_STREAM', '1') != '0'
                        else []) + [GENERAL]
@@ -354,12 +356,17 @@ class LaunchSet:
         self._n_last = 0
         self.max_streams = int(os.environ.get('GD_MAX_STREAMS', '3'))
 
-    def enqueue(self, plan, events=None, serial=False, front=None, after=()):
+    def enqueue(self, plan, events=None, serial=False, front=None, after=(),
+                detached=False):
         """`front`: a stream that takes the place of the null stream for the
         table kernel and the start event (pipelined steps: the null stream
         may still be busy with the previous step's collective).  It first
         waits for the events in `after` and for the solver launches of the
-        previous `enqueue` (they read the table buffer this step rewrites)."""
+        previous `enqueue` (they read the table buffer this step rewrites).
+        `detached`: the null stream does NOT wait for the solver streams --
+        what the caller enqueues there next (the Gaussian process factors the
+        kernel matrix while the gradient solves run) overlaps the solvers;
+        `join()` makes it wait later."""
         fh = None
         if front is not None and not serial:
             fh = front.h
@@ -412,8 +419,17 @@ class LaunchSet:
                 events[k][1].record(s.h)
         for slot in range(ns):
             self.done[slot].record(self.streams[slot].h)
-            runtime.null_stream_wait_event(self.done[slot])
+            if not detached:
+                runtime.null_stream_wait_event(self.done[slot])
         self._n_last = ns
+        self._detached = ns if detached else 0
+
+    def join(self):
+        """The null stream waits for the solver launches of a detached
+        `enqueue` (device-side)."""
+        for slot in range(getattr(self, '_detached', 0)):
+            runtime.null_stream_wait_event(self.done[slot])
+        self._detached = 0
 
 
 class HIPBackend(Backend):
@@ -976,13 +992,13 @@ extern "C" __global__ __launch_bounds__(${threads})
 void ${name}(params_t prm) {
     using solver = graphdot::mgk::stream_solver<real_t, ${threads}, ${C},
         graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
-    static_assert(solver::A_ROWS == ${rows}, "rows of p staged per pass: host and device disagree");
+    static_assert(solver::A_ROWS == ${rows} && solver::SEG_CAP == ${cap}, "rows of p staged per pass, neighbours per segment: host and device disagree");
     __shared__ typename solver::lds_t lds;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     solver::run(prm, lds, dyn_lds, prm.scratch);
 }
 ''').render(threads=STREAM_THREADS, name=self.kernel_name(v, C), C=C,
-            rows=STREAM_ROWS)
+            rows=STREAM_ROWS, cap=STREAM_CAP)
         threads = 64 * v.W * (WPB1 if v.W == 1 else 1)
         return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
@@ -1057,21 +1073,39 @@ void ${name}(params_t prm) {
             return 0
         return -(-(n * n * esize) // 16) * 16 + esize * (n + 3) * 32 + 256
 
-    def stream_lds_bytes(self, image1, image2, n1, n2):
+    @staticmethod
+    def stream_virtual_rows(adjacency_count):
+        """Lanes the streamed solver deals a graph's nodes onto when it is
+        the LDS-resident one (mgk_stream.h, "virtual rows"): a node is cut
+        into segments of at most CAP neighbours, CAP = 16 doubled until the
+        segments fit the STREAM_THREADS lanes of a workgroup; every node has
+        a first segment."""
+        d = np.asarray(adjacency_count, dtype=np.int64)
+        cap = STREAM_CAP
+        while True:
+            nv = len(d) + sum(int((d > l * cap).sum())
+                              for l in range(1, int(d.max(initial=0)) // cap + 1))
+            if nv <= STREAM_THREADS or cap > (1 << 20):
+                return nv
+            cap *= 2
+
+    def stream_lds_bytes(self, image1, image2, n1, n2, nv1, nv2):
         """Dynamic LDS of a pair in the streamed solver (mgk_stream.h): the
         image of B -- the smaller image among the graphs of at most
         STREAM_THREADS nodes, ties: graph 2 -- in 16-byte units, and behind
-        it STREAM_ROWS rows of p for each of the G = STREAM_THREADS //
-        ceil64(nB) row groups of a workgroup step.  A huge number if neither
-        graph qualifies."""
+        it, for each of the G = STREAM_THREADS // ceil64(nV) row groups of a
+        workgroup step (nV: B's virtual rows), STREAM_ROWS rows of p and one
+        partial sum per lane.  A huge number if neither graph qualifies."""
         image1, image2 = np.asarray(image1), np.asarray(image2)
         n1, n2 = np.asarray(n1), np.asarray(n2)
         w1, w2 = -(-image1 // 16), -(-image2 // 16)
         ok1, ok2 = n1 <= STREAM_THREADS, n2 <= STREAM_THREADS
         first = ok1 & (~ok2 | (w1 < w2))
         nB = np.maximum(np.where(first, n1, n2), 1)
-        G = STREAM_THREADS // (-(-nB // 64) * 64).clip(max=STREAM_THREADS)
-        stage = STREAM_ROWS * G * nB * np.dtype(self.real).itemsize
+        nV = np.maximum(np.where(first, nv1, nv2), 1)
+        LB = (-(-nV // 64) * 64).clip(max=STREAM_THREADS)
+        G = STREAM_THREADS // LB
+        stage = (STREAM_ROWS * G * nB + G * LB) * np.dtype(self.real).itemsize
         out = np.where(first, w1, w2) * 16 + -(-stage // 16) * 16
         return np.where(ok1 | ok2, out, np.iinfo(np.int64).max // 4)
 
@@ -1453,7 +1487,15 @@ void ${name}(params_t prm) {
                 # one lane per node of it) fits the LDS beside the staged
                 # rows of p -- the rule of mgk_stream.h
                 raw = f['image_bytes']
-                sb = self.stream_lds_bytes(raw[ji], raw[jj], n1, n2)
+                # (virtual rows of the graphs these pairs touch: a pass over
+                # their degree lists, only when there are such pairs)
+                nv = np.zeros(len(dgraphs), dtype=np.int64)
+                for g_ in np.unique(np.concatenate((ji[left], jj[left]))):
+                    nv[g_] = self.stream_virtual_rows(
+                        dgraphs[g_].adjacency_count) \
+                        if n_node[g_] <= STREAM_THREADS else 0
+                sb = self.stream_lds_bytes(raw[ji], raw[jj], n1, n2,
+                                           nv[ji], nv[jj])
                 fits = left & (sb + 1024 <= LDS_LIMIT)
                 choice[fits] = self.variants.index(STREAM)
                 # (for these pairs `gbytes` is the dynamic LDS of the pair)
@@ -1976,8 +2018,13 @@ void ${name}(params_t prm) {
             if plan.n_grad else None
         b_iters = self._buffer('iters', 4 * lay.n_jobs) \
             if self.record_iterations else None
-        scratch_bytes = max([L.get('scratch_bytes', 0) for L in launches]
-                            + [0])
+        # (launches run concurrently on several streams: every launch that
+        # keeps CG vectors in global memory gets a region of its own)
+        scratch_bytes = 0
+        for L in launches:
+            if L.get('scratch_bytes', 0):
+                L['scratch_offset'] = scratch_bytes
+                scratch_bytes += -(-L['scratch_bytes'] // 256) * 256
         b_scratch = self._buffer('scratch', scratch_bytes) \
             if scratch_bytes else None
         # global microkernel tables of this evaluation: values (and, for the
@@ -2056,6 +2103,8 @@ void ${name}(params_t prm) {
             a['n_launch_jobs'] = L['count']
             a['order_offset'] = L['offset']
             a['u_capacity'] = L['ucap']
+            if L.get('scratch_bytes', 0):
+                a['scratch'] = b_scratch.ptr + L['scratch_offset']
             if L.get('dense'):
                 a['flags'] |= F_DENSE
             if fd is not None:

@@ -40,6 +40,24 @@ class LocalGradient:
 
     def __init__(self, dK, i, j, group=None):
         self.dK, self.i, self.j, self.group = dK, i, j, group
+        #: indices of the columns the consumer wants (None: all)
+        self.columns = None
+
+
+class PendingLocalGradient(LocalGradient):
+    """A `LocalGradient` whose solvers may still be running on their own
+    streams (`device_gram(..., local_gradient='overlapped')`): what the caller
+    enqueues on the null stream meanwhile overlaps them; reading `dK` first
+    orders the null stream behind the solvers."""
+
+    def __init__(self, step, i, j, group=None):
+        self._step, self.i, self.j, self.group = step, i, j, group
+        self.columns = None
+
+    @property
+    def dK(self):
+        self._step.join()
+        return self._step.local_gradient
 
 
 class MarginalizedGraphKernel:
@@ -278,7 +296,13 @@ class MarginalizedGraphKernel:
         unordered pair of the symmetric matrix on exactly one rank -- for a
         consumer that reduces over pairs and all-reduces the result
         (model.gaussian_process: ``sum_ij W_ij dK_ij``).  Any other backend
-        returns the full planes as before."""
+        returns the full planes as before.  `local_gradient='overlapped'`:
+        where the backend finds it worthwhile (`overlaps_dense_algebra`: from
+        four ranks up) the matrix comes from a value step of its own and the
+        value + gradient solvers are then enqueued DETACHED -- the second
+        return value is a `PendingLocalGradient`, and whatever the caller
+        enqueues on the null stream before reading its `dK` (a Cholesky
+        factorisation) runs beside the gradient solves."""
         from ...hip.runtime import DeviceArray
         backend = self.backend
         if not hasattr(backend, 'prepare'):
@@ -297,12 +321,23 @@ class MarginalizedGraphKernel:
             # matrix (and gradient planes) of `ShardedStep` stay on this
             # rank's device -- every rank holds the full result, like the
             # single-GPU path, and nothing goes through host memory
+            args = (X, self.node_kernel, self.edge_kernel, self.p, self.q,
+                    self.eps, self.ftol, self.gtol, self._pairwise_jobs(nx),
+                    np.arange(nx + 1, dtype=np.uint32), nx, nx, self.n_dims)
+            if eval_gradient and local_gradient == 'overlapped' \
+                    and backend.overlaps_dense_algebra():
+                vstep = backend.sharded_step(*args, traits._replace(
+                    eval_gradient=False))
+                K = DeviceArray.fortran(vstep.result.data_ptr(), (nx, nx),
+                                        real, owner=vstep)
+                gstep = backend.sharded_step(*args, traits,
+                                             gather_gradient=False,
+                                             solvers_only=True)
+                i, j = gstep.local_index
+                return K, PendingLocalGradient(gstep, i, j, gstep.group)
             step = backend.sharded_step(
-                X, self.node_kernel, self.edge_kernel, self.p, self.q,
-                self.eps, self.ftol, self.gtol, self._pairwise_jobs(nx),
-                np.arange(nx + 1, dtype=np.uint32), nx, nx, self.n_dims,
-                traits, gather_gradient=not (eval_gradient
-                                             and local_gradient))
+                *args, traits, gather_gradient=not (eval_gradient
+                                                    and local_gradient))
             base = step.result.data_ptr()
             K = DeviceArray.fortran(base, (nx, nx), real, owner=step)
             if not eval_gradient:

@@ -595,6 +595,21 @@ class ShardedStep:
             phases[3].record()
         self.buffer_free[b].record()       # (null stream: slabs are consumed)
 
+    def enqueue_solvers(self):
+        """The solver launches of this rank's shard alone, DETACHED: no
+        collective, no reassembly, and the null stream does not wait for them
+        -- work enqueued there next runs beside the solvers.  `join()` orders
+        the null stream behind them; the slab (`local_gradient`) is complete
+        after it."""
+        b = self._count % self.depth
+        self._count += 1
+        self.local_out, self.gathered = self.local_outs[b], self.gathereds[b]
+        self.launch_set.enqueue(self.plans[b], front=self.front,
+                                after=(self.buffer_free[b],), detached=True)
+
+    def join(self):
+        self.launch_set.join()
+
     def phase_ms(self, steps=5):
         """Device time of the three phases of a step on this rank, averaged
         over `steps` steps: {'shard_ms': this rank's solver launches,
@@ -721,8 +736,24 @@ def distributed_backend(**kwargs):
             #: job lists shorter than this per rank are not re-balanced
             self.rebalance_min_jobs = int(os.environ.get(
                 'GD_SHARD_REBALANCE_MIN_JOBS', 4096))
+            #: consumers that factor the kernel matrix (model.gaussian_process)
+            #: may overlap the factorisation with the gradient solves: values
+            #: first (their own sharded step), then the value + gradient
+            #: solvers detached beside the dense algebra.  Pays when a rank's
+            #: value step is shorter than the (replicated, latency-bound)
+            #: factorisation -- from four ranks up; GD_GPR_OVERLAP=0 / 1
+            #: forces it off / on.
+            self.overlap_min_ranks = 4
             self._shard_plans = {}
             self._steps = {}      # (shard plan, nJ, traits) -> ShardedStep
+
+        def overlaps_dense_algebra(self):
+            import torch.distributed as dist
+            flag = os.environ.get('GD_GPR_OVERLAP')
+            if flag is not None:
+                return flag != '0' and self.shards_over_ranks()
+            return (self.shards_over_ranks()
+                    and dist.get_world_size() >= self.overlap_min_ranks)
 
         def shards_over_ranks(self):
             """True when a process group with more than one rank is up."""
@@ -750,14 +781,18 @@ def distributed_backend(**kwargs):
 
         def sharded_step(self, graphs, node_kernel, edge_kernel, p, q, eps,
                          ftol, gtol, jobs, starts, nX, nY, nJ, traits,
-                         timer=None, gather_gradient=True):
+                         timer=None, gather_gradient=True, solvers_only=False):
             """Evaluate the graph-level job list over the ranks and leave the
             reassembled result on this rank's device: returns the
             `ShardedStep` (`.values` / `.gradient` / `.result`), enqueued and
             synchronised.  Steps are cached per (graphs, jobs, traits): a
             repeated evaluation with new hyperparameters only re-binds the
             kernel arguments.  `gather_gradient=False`: the gradient stays
-            in the ranks' slabs (`ShardedStep.local_gradient`)."""
+            in the ranks' slabs (`ShardedStep.local_gradient`).
+            `solvers_only`: the step is enqueued DETACHED and without its
+            collective (`ShardedStep.enqueue_solvers`) and not synchronised:
+            the caller goes on enqueueing on the null stream and calls
+            `step.join()` before it reads `local_gradient`."""
             import torch.distributed as dist
             rank, world = dist.get_rank(), dist.get_world_size()
             jobs = np.ascontiguousarray(jobs) if not isinstance(
@@ -797,6 +832,10 @@ def distributed_backend(**kwargs):
             else:
                 step.bind(node_kernel, edge_kernel, p, q, eps, ftol, gtol,
                           timer)
+            if solvers_only:
+                step.enqueue_solvers()
+                self.last_step = step
+                return step
             if timer is not None:
                 timer.tic('GPU kernel execution')
             step.enqueue()

@@ -75,7 +75,11 @@ def _contract_local(W, lg, keep=None):
         full[keep[:, None], keep[None, :]] = W
         W = full
     w = W[i, j] * torch.where(i == j, 1.0, 2.0).to(W.dtype)
-    d = w @ lg.dK.to(W.dtype)
+    rows = lg.dK          # (a pending gradient: the null stream joins the solvers)
+    if lg.columns is not None:
+        rows = rows.index_select(1, torch.as_tensor(lg.columns,
+                                                    device=W.device))
+    d = w @ rows.to(W.dtype)
     if dist.is_available() and dist.is_initialized() \
             and dist.get_world_size(lg.group) > 1:
         from ...kernel.marginalized._sharded import cuda_collective
@@ -386,7 +390,7 @@ class GaussianProcessRegressor:
             keep = _torch().as_tensor(np.flatnonzero(y_mask),
                                       device=la.device)
             Kt = Kt.index_select(0, keep).index_select(1, keep)
-            if dKt is not None and not hasattr(dKt, 'dK'):
+            if dKt is not None and not hasattr(dKt, 'columns'):
                 dKt = dKt.index_select(0, keep).index_select(1, keep)
             self._keep = keep          # (a LocalGradient is indexed in full)
         return theta, la, Kt, dKt, la.tensor(y), t_kernel
@@ -405,7 +409,7 @@ class GaussianProcessRegressor:
         torch = _torch()
         try:
             out = kernel.device_gram(X, eval_gradient=jac,
-                                     **({'local_gradient': True}
+                                     **({'local_gradient': 'overlapped'}
                                         if jac and local_gradient else {}))
         except TypeError:            # not the HIP backend
             return None
@@ -414,14 +418,13 @@ class GaussianProcessRegressor:
         diag = torch.diagonal(K)
         diag.copy_(self._regularize(diag, self.alpha))
         dK = None
-        if hasattr(dKd, 'dK'):
-            # this rank's pairs only: (pairs, n_dims) rows, masked below
+        if hasattr(dKd, 'columns'):
+            # this rank's pairs only: (pairs, n_dims) rows; the active
+            # columns are picked where the rows are read (a pending gradient
+            # must not be touched before the factorisation is enqueued)
             mask = np.asarray(kernel.active_theta_mask)
-            rows = dKd.dK
-            if rows.shape[1] == len(mask) and not mask.all():
-                rows = rows.index_select(1, torch.as_tensor(
-                    np.flatnonzero(mask), device=la.device))
-            dKd.dK = rows
+            if not mask.all():
+                dKd.columns = np.flatnonzero(mask)
             dK = dKd
         elif dKd is not None:
             dK = torch.as_tensor(dKd, device=la.device)
@@ -452,7 +455,7 @@ class GaussianProcessRegressor:
             # tr(K^-1 dK_k) - (K^-1 y)^T dK_k (K^-1 y) = sum_ij W_ij dK_ijk
             # with the symmetric W = K^-1 - (K^-1 y)(K^-1 y)^T: one pass over dK
             W = Kinv - torch.outer(Ky, Ky)
-            if hasattr(dK, 'dK'):
+            if hasattr(dK, 'columns'):
                 # pair-sharded kernel: this rank's pairs, then one all-reduce
                 d = _contract_local(W, dK, self._keep)
             else:
