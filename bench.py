@@ -409,6 +409,8 @@ def gpr_step_line(args, world, rank, local_rank):
             parts[k] += gpr.last_timing[k]
     barrier()
     elapsed = time.perf_counter() - t0
+    # (the sharded step the likelihood's gradient came from)
+    step_ = getattr(backend, 'last_step', None)
     # (was the regressor handed device tensors -- device_gram -- or did it
     # fall back to the numpy kernel protocol?)
     on_device = gpr._device_gramian(gpr._dense(), kernel, graphs,
@@ -419,13 +421,14 @@ def gpr_step_line(args, world, rank, local_rank):
     # and the phases of the sharded kernel step by device events
     mine = {'kernel_ms': 1e3 * parts['kernel'] / args.steps,
             'dense_ms': 1e3 * parts['linalg'] / args.steps}
-    step_ = getattr(backend, 'last_step', None)
     if step_ is not None:
         ph = step_.phase_ms(steps=3)
         mine.update(shard_ms=ph['shard_ms'], collective_ms=ph[
             'all_gather_ms'] + ph['reassembly_ms'], all_gather_ms=ph[
             'all_gather_ms'], reassembly_ms=ph['reassembly_ms'],
-            gradient_gathered=bool(step_.gather_gradient))
+            gradient_gathered=bool(step_.gather_gradient),
+            factorisation_overlaps_gradient_solves=bool(
+                backend.overlaps_dense_algebra()))
     per_rank = [mine]
     if dist is not None and world > 1:
         per_rank = [None] * world

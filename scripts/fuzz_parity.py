@@ -146,7 +146,10 @@ def _sharded_worker(rank, world, port, path):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from graphdot_amd.kernel.marginalized._sharded import distributed_backend
     with open(path, 'rb') as f:
-        G, kn, ke, q, real, kw = pickle.load(f)
+        G, kseed, q, real, kw = pickle.load(f)
+    # (the microkernel classes are made by a decorator and do not pickle:
+    # both sides draw the kernels of this mode from the same sub-seed)
+    kn, ke = random_kernels(np.random.default_rng(kseed))
     be = distributed_backend(device=0, real=real)
     be.rebalance_min_jobs = 1
     k = MarginalizedGraphKernel(kn, ke, q=q, backend=be, **kw)
@@ -158,7 +161,7 @@ def _sharded_worker(rank, world, port, path):
     dist.destroy_process_group()
 
 
-def random_kernels():
+def random_kernels(rng=rng):
     node = [TensorProduct(category=KroneckerDelta(float(rng.uniform(0.2, 0.8)))),
             TensorProduct(category=KroneckerDelta(0.5),
                           radius=SquareExponential(float(rng.uniform(0.5, 2.0)))),
@@ -370,6 +373,11 @@ def main():
                 i_, j_ = np.triu_indices(len(Gs))
                 batch = oracle.TensorProductBatch(Gs, kns, kes)
                 ref, _ = batch.run(i_, j_, q=q, tol=1e-13, real='f64', omp=True)
+                # (double: the device keeps the degrees as float32 sums of the
+                # float32 weights like the reference, _octilegraph.py:109-139,
+                # the restatement sums them in double -- exact for the dyadic
+                # weights of the other modes, 1e-8 of K on tent weights)
+                rtol = max(rtol, 1e-7)
                 check(tag, K[i_, j_], ref, rtol)
                 h = len(Gs) // 2
                 check(tag + ' (block)', ks(Gs[h:], Gs[:h]), K[h:, :h],
@@ -391,13 +399,17 @@ def main():
                 import tempfile
                 import torch.multiprocessing as mp
                 kw = {'ftol': 1e-13, 'gtol': 1e-12} if f64 else {}
+                kseed = int(rng.integers(1 << 30))
+                kn, ke = random_kernels(np.random.default_rng(kseed))
+                tag += f' sharded: {kn!r} {ke!r}'
+                k = MarginalizedGraphKernel(kn, ke, q=q, backend=be, **kw)
                 want = (k(G),) + k(G, eval_gradient=True)
                 h = max(1, len(G) // 2)
                 want_xy = k(G[:h], G[h:] or G[:1])
                 with tempfile.TemporaryDirectory() as tmp:
                     path = os.path.join(tmp, 'problem.pkl')
                     with open(path, 'wb') as f:
-                        pickle.dump((G, kn, ke, q, real, kw), f)
+                        pickle.dump((G, kseed, q, real, kw), f)
                     port = 29600 + (os.getpid() + it) % 300
                     mp.spawn(_sharded_worker, args=(2, port, path), nprocs=2,
                              join=True)
