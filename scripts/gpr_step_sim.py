@@ -107,7 +107,8 @@ for world in worlds:
         rows_g = slab[len(jg):].view(len(jg), nJ)
 
         def contraction(W):
-            return (W[ti, tj] * mult) @ rows_g.to(torch.float64)
+            return (rows_g.to(torch.float64)
+                    * (W[ti, tj] * mult).unsqueeze(1)).sum(dim=0)
 
         def serial():
             ls_g.enqueue(pg)                 # (the null stream waits for it)

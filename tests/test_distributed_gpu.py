@@ -42,7 +42,7 @@ def _worker(rank, world, port, tmp):
     # the likelihood's gradient came from this rank's pairs and one
     # all-reduce: the gradient planes were never gathered
     step = k.backend.last_step
-    assert step.n_grad == len(k.theta) and not step.gather_gradient
+    assert step.n_grad == k.n_dims and not step.gather_gradient
     assert len(step.local_jobs) < len(G) * (len(G) + 1) // 2
     loo, gloo = gpr.squared_loocv_error(eval_gradient=True)
     assert k.backend.last_step.gather_gradient      # (needs whole planes)
