@@ -213,6 +213,15 @@ int gd_stream_create(gd_stream_t *out) {
     *out = reinterpret_cast<gd_stream_t>(s);
     return 0;
 }
+int gd_stream_create_low_priority(gd_stream_t *out) {
+    if (!out) return fail("gd_stream_create_low_priority: null argument");
+    int least = 0, greatest = 0;      // (numerically: least >= greatest)
+    GD_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t s;
+    GD_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, least));
+    *out = reinterpret_cast<gd_stream_t>(s);
+    return 0;
+}
 int gd_stream_destroy(gd_stream_t s) {
     if (s) GD_TRY(hipStreamDestroy(S(s)));
     return 0;

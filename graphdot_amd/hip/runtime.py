@@ -59,6 +59,7 @@ SIGNATURES = {
     'gd_function_set_max_dynamic_lds': [_vp, ctypes.c_int],
     'gd_launch': [_vp, _u32, _u32, _u32, _vp, _vp, _sz],
     'gd_stream_create': [_P(_vp)],
+    'gd_stream_create_low_priority': [_P(_vp)],
     'gd_stream_destroy': [_vp],
     'gd_stream_sync': [_vp],
     'gd_event_create': [_P(_vp)],
@@ -445,10 +446,12 @@ class Event:
 class Stream:
     """A non-blocking HIP stream."""
 
-    def __init__(self):
+    def __init__(self, low_priority=False):
         ensure_device()
         p = ctypes.c_void_p()
-        check(lib().gd_stream_create(ctypes.byref(p)))
+        create = lib().gd_stream_create_low_priority if low_priority \
+            else lib().gd_stream_create
+        check(create(ctypes.byref(p)))
         self.h = p.value
 
     def sync(self):

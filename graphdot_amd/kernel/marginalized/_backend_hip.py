@@ -327,6 +327,7 @@ _SOURCES = {}
 #: HIP streams / events are expensive to create (milliseconds each): every
 #: LaunchSet draws from this process-wide pool, in order
 _STREAM_POOL, _EVENT_POOL = [], []
+_LOW_STREAM_POOL, _LOW_EVENT_POOL = [], []     # streams of the lowest priority
 
 
 class _DeviceGraphList(list):
@@ -352,6 +353,13 @@ class LaunchSet:
 
     def __init__(self):
         self.streams, self.done = [], []
+        # detached launches (`enqueue(detached=True)`) run on streams of the
+        # lowest priority: what overlaps them on the null stream -- a chain of
+        # small dependent launches, the Cholesky factorisation -- gets compute
+        # units as soon as it has a workgroup to dispatch instead of queueing
+        # behind the solver grids (GD_DETACHED_PRIORITY=0: normal streams)
+        self.low_streams, self.low_done = [], []
+        self._last_done = self.done
         self.start = runtime.Event()
         self._n_last = 0
         self.max_streams = int(os.environ.get('GD_MAX_STREAMS', '3'))
@@ -373,7 +381,7 @@ class LaunchSet:
             for e in after:
                 front.wait_event(e)
             for slot in range(self._n_last):
-                front.wait_event(self.done[slot])
+                front.wait_event(self._last_done[slot])
         for L in plan.pre_launches:
             runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
                            stream=fh, dynamic_lds=L['dynamic_lds'])
@@ -396,21 +404,26 @@ class LaunchSet:
                 for k in range(n)]
         order = sorted(range(n), key=lambda k: -cost[k])
         ns = max(1, min(n, self.max_streams or n))
-        while len(self.streams) < ns:
-            k = len(self.streams)
-            if len(_STREAM_POOL) <= k:
-                _STREAM_POOL.append(runtime.Stream())
-                _EVENT_POOL.append(runtime.Event())
-            self.streams.append(_STREAM_POOL[k])
-            self.done.append(_EVENT_POOL[k])
+        low = detached and os.environ.get('GD_DETACHED_PRIORITY', '1') != '0'
+        streams, done, spool, epool = (
+            (self.low_streams, self.low_done, _LOW_STREAM_POOL,
+             _LOW_EVENT_POOL) if low else
+            (self.streams, self.done, _STREAM_POOL, _EVENT_POOL))
+        while len(streams) < ns:
+            k = len(streams)
+            if len(spool) <= k:
+                spool.append(runtime.Stream(low_priority=low))
+                epool.append(runtime.Event())
+            streams.append(spool[k])
+            done.append(epool[k])
         self.start.record(fh)
         load = [0] * ns
         for slot in range(ns):
-            self.streams[slot].wait_event(self.start)
+            streams[slot].wait_event(self.start)
         for k in order:
             slot = load.index(min(load))
             load[slot] += cost[k]
-            L, s = plan.launches[k], self.streams[slot]
+            L, s = plan.launches[k], streams[slot]
             if events is not None:
                 events[k][0].record(s.h)
             runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
@@ -418,17 +431,17 @@ class LaunchSet:
             if events is not None:
                 events[k][1].record(s.h)
         for slot in range(ns):
-            self.done[slot].record(self.streams[slot].h)
+            done[slot].record(streams[slot].h)
             if not detached:
-                runtime.null_stream_wait_event(self.done[slot])
-        self._n_last = ns
+                runtime.null_stream_wait_event(done[slot])
+        self._n_last, self._last_done = ns, done
         self._detached = ns if detached else 0
 
     def join(self):
         """The null stream waits for the solver launches of a detached
         `enqueue` (device-side)."""
         for slot in range(getattr(self, '_detached', 0)):
-            runtime.null_stream_wait_event(self.done[slot])
+            runtime.null_stream_wait_event(self._last_done[slot])
         self._detached = 0
 
 

@@ -739,20 +739,41 @@ def distributed_backend(**kwargs):
             #: consumers that factor the kernel matrix (model.gaussian_process)
             #: may overlap the factorisation with the gradient solves: values
             #: first (their own sharded step), then the value + gradient
-            #: solvers detached beside the dense algebra.  Pays when a rank's
-            #: value step is shorter than the (replicated, latency-bound)
-            #: factorisation -- from four ranks up; GD_GPR_OVERLAP=0 / 1
-            #: forces it off / on.
-            self.overlap_min_ranks = 4
+            #: solvers detached beside the dense algebra.  OFF by default
+            #: (None): measured on one GPU with the shards of a world of
+            #: eight (scripts/gpr_step_sim.py, profiles/r05_gpr_step_sim_*),
+            #: the overlapped step takes 2.96 ms against 2.51 ms one after
+            #: the other -- the factorisation's chain of ~50 small dependent
+            #: launches does not run beside the solver grids, it queues
+            #: behind them (low-priority solver streams: no difference), and
+            #: the value step is paid on top.  GD_GPR_OVERLAP=1 or
+            #: `overlap_min_ranks = n` turn it on for a measurement on real
+            #: ranks.
+            self.overlap_min_ranks = None
             self._shard_plans = {}
             self._steps = {}      # (shard plan, nJ, traits) -> ShardedStep
+            # (clones of a kernel -- clone_with_theta, every objective
+            # evaluation of the regressor -- hold shallow copies of the
+            # backend: what the copies must see of each other lives here)
+            self._shared = {}
+
+        @property
+        def last_step(self):
+            """The `ShardedStep` of the latest sharded evaluation on this
+            backend or any of its copies."""
+            return self._shared.get('last_step')
+
+        @last_step.setter
+        def last_step(self, step):
+            self._shared['last_step'] = step
 
         def overlaps_dense_algebra(self):
             import torch.distributed as dist
             flag = os.environ.get('GD_GPR_OVERLAP')
             if flag is not None:
                 return flag != '0' and self.shards_over_ranks()
-            return (self.shards_over_ranks()
+            return (self.overlap_min_ranks is not None
+                    and self.shards_over_ranks()
                     and dist.get_world_size() >= self.overlap_min_ranks)
 
         def shards_over_ranks(self):

@@ -90,6 +90,13 @@ int gd_launch(gd_function_t f, uint32_t grid_x, uint32_t block_x,
 
 /* ---- streams & events (timing of the launched kernels on their own stream) */
 int gd_stream_create(gd_stream_t *out);
+/* A non-blocking stream of the LOWEST priority the device offers
+ * (hipStreamCreateWithPriority): work enqueued there yields compute units to
+ * streams of normal priority whenever both have workgroups to dispatch.  New
+ * (no PyCUDA counterpart): the Gaussian process factors the kernel matrix on
+ * the null stream while the gradient solves of the same step run on such
+ * streams (ShardedStep.enqueue_solvers). */
+int gd_stream_create_low_priority(gd_stream_t *out);
 int gd_stream_destroy(gd_stream_t s);
 int gd_stream_sync(gd_stream_t s);
 int gd_event_create(gd_event_t *out);

@@ -43,7 +43,7 @@ def _worker(rank, world, port, tmp):
     # all-reduce: the gradient planes were never gathered
     step = k.backend.last_step
     assert step.n_grad == k.n_dims and not step.gather_gradient
-    assert len(step.local_jobs) < len(G) * (len(G) + 1) // 2
+    n_local = len(step.local_jobs)      # (the ranks' shares add up: parent)
     loo, gloo = gpr.squared_loocv_error(eval_gradient=True)
     assert k.backend.last_step.gather_gradient      # (needs whole planes)
     # masked targets: W covers the kept rows, the pairs are indexed in full
@@ -56,7 +56,7 @@ def _worker(rank, world, port, tmp):
     assert all(v > 0 for v in phases.values())
     np.savez(os.path.join(tmp, f'rank{rank}.npz'), K=K, K2=K2, dK=dK,
              Kxy=Kxy, d=d, lml=lml, glml=glml, loo=loo, gloo=gloo,
-             lml2=lml2, glml2=glml2)
+             lml2=lml2, glml2=glml2, n_local=n_local)
     dist.destroy_process_group()
 
 
@@ -103,6 +103,9 @@ def test_ranks_through_the_kernel_api(tmp_path, world):
     gpr2.X, gpr2.y = G, y2
     lml2, glml2 = gpr2.log_marginal_likelihood(eval_gradient=True)
     r0 = np.load(tmp_path / 'rank0.npz')
+    # every unordered pair on exactly one rank
+    assert sum(int(np.load(tmp_path / f'rank{r}.npz')['n_local'])
+               for r in range(world)) == len(G) * (len(G) + 1) // 2
     for rank in range(world):
         r = np.load(tmp_path / f'rank{rank}.npz')
         # the same matrix bit for bit, hence the same factor and objective
