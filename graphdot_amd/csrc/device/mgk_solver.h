@@ -75,7 +75,8 @@ template<class real, class Graph, class NodeK, class EdgeK, class PStart> struct
     real *gramian;
     real *gradient;
     std::uint32_t *iters;        // optional per-job CG iteration counts
-    real *scratch;               // general solver only: per-workgroup CG scratch
+    real *scratch;               // general / streamed solver: CG vectors in global memory
+    unsigned *sync;              // streamed solver, several workgroups per pair: barrier cells and partial sums (mgk_stream.h)
     real *tables;                // microkernel values over label-class pairs (mgk_oc.h)
     // maximin distance (mgk_oc.h, MAXIMIN): nodal self-similarities of every
     // graph [node_starts[g] + node], their Jacobian (column-major, leading
@@ -91,6 +92,7 @@ template<class real, class Graph, class NodeK, class EdgeK, class PStart> struct
     std::uint32_t order_offset;  // slot of order[0] in the packed output
     std::uint32_t u_capacity;    // tasks per pair slot in the dynamic LDS region
     std::uint32_t g_capacity;    // bytes per staged graph image in dynamic LDS
+    std::uint32_t parts;         // streamed solver: workgroups per pair (1: none of the grid-wide machinery)
     // label classes (GraphArena): counts and arena offsets of the class
     // representatives node_t[n_vclass], edge_t[n_eclass]
     std::uint32_t n_vclass, n_eclass, vrep, erep;

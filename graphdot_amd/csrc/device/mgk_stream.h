@@ -74,15 +74,101 @@ struct stream_solver {
         return second ? b : a;
     }
 
+    // ---- several workgroups per pair ---------------------------------------
+    // A launch of few pairs (one protein against itself: the reference's
+    // protein-time-to-solution.py) would leave all but a few compute units
+    // idle: M = prm.parts workgroups then share a pair.  Part m owns the rows
+    // iA in [nA m / M, nA (m + 1) / M): their share of the mat-vec, of every
+    // vector pass and of the scalar products; p is read by all.  Three
+    // grid-wide barriers per iteration (p complete | pAp | rTr, rTz), through
+    // device memory: the launch is COOPERATIVE (gd_launch_cooperative: every
+    // workgroup resident, and the device runs one such kernel at a time), the
+    // barrier a counter and a generation number per pair slot -- the last
+    // part to arrive resets the counter and bumps the generation, so the
+    // cells are clean when the kernel ends and need no host-side reset.
+    // Scalar products: every part publishes its partial sums, all parts add
+    // the M partials up in part order -- the same numbers, hence the same
+    // control flow, in every part.  M = 1: none of this is executed.
+    constexpr static unsigned SYNC_HEAD = 16;        // words: [count, generation, pad]
+    __device__ static __forceinline__ unsigned sync_words(unsigned M) {
+        return SYNC_HEAD + 2u * M * 4u * (unsigned)(sizeof(real) / 4u);
+    }
+    struct group_t {
+        unsigned M, part;
+        unsigned *cells;          // [count, generation]
+        real *partial;            // [2][M][4]
+        unsigned gen, epoch;
+        __device__ __forceinline__ void barrier() {
+            if (M == 1) {
+                __syncthreads();
+                return;
+            }
+            __syncthreads();      // (this workgroup's stores are issued)
+            if (threadIdx.x == 0) {
+                __threadfence();  // release: they are visible device-wide
+                const unsigned arrived = atomicAdd(&cells[0], 1u);
+                if (arrived == M - 1) {
+                    atomicExch(&cells[0], 0u);
+                    __threadfence();
+                    atomicAdd(&cells[1], 1u);
+                } else {
+                    while (__hip_atomic_load(&cells[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen)
+                        __builtin_amdgcn_s_sleep(2);
+                }
+                __threadfence();  // acquire: the other parts' stores are read afresh
+            }
+            ++gen;
+            __syncthreads();
+        }
+        // v[k], k < NV: block-level sums (the same in every thread) -> sums over the parts
+        template<int NV> __device__ __forceinline__ void sum(real (&v)[NV], real *red) {
+            if (M == 1) return;
+            real *const mine = partial + ((size_t)(epoch & 1u) * M + part) * 4u;
+            if (threadIdx.x == 0)
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+                    __hip_atomic_store(&mine[k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            barrier();
+            if (threadIdx.x < 64) {
+                real const *const all = partial + (size_t)(epoch & 1u) * M * 4u;
+                real a[NV];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) a[k] = 0;
+                for (unsigned m = threadIdx.x; m < M; m += 64)
+#pragma unroll
+                    for (int k = 0; k < NV; ++k)
+                        a[k] += __hip_atomic_load(&all[(size_t)m * 4u + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < NV; ++k) a[k] = wave::sum(a[k]);
+                if (threadIdx.x == 0)
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) red[k] = a[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = red[k];
+            __syncthreads();
+            ++epoch;
+        }
+    };
+
     __device__ static __forceinline__ void run(P const &prm, lds_t &lds, char *dyn, real *scratch_all) {
         const int tid = threadIdx.x;
         real *const red = lds.red;
         int *const lay_off = lds.lay_off;
-        real *const scratch = scratch_all + (size_t)blockIdx.x * prm.u_capacity;
+        group_t grp;
+        grp.M = prm.parts > 1u ? prm.parts : 1u;
+        const unsigned slot = blockIdx.x / grp.M, n_slots = gridDim.x / grp.M;
+        grp.part = blockIdx.x - slot * grp.M;
+        grp.cells = prm.sync + (size_t)slot * sync_words(grp.M);
+        grp.partial = reinterpret_cast<real *>(grp.cells + SYNC_HEAD);
+        grp.epoch = 0;
+        grp.gen = grp.M > 1u ? __hip_atomic_load(&grp.cells[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        real *const scratch = scratch_all + (size_t)slot * prm.u_capacity;
         graph_header_t const *const headers = reinterpret_cast<graph_header_t const *>(prm.arena);
         char *const lG = dyn;
 
-        for (unsigned t = blockIdx.x; t < prm.n_launch_jobs; t += gridDim.x) {
+        for (unsigned t = slot; t < prm.n_launch_jobs; t += n_slots) {
             const job_t job = prm.jobs[t];
             const graph_header_t h1 = headers[job.i], h2 = headers[job.j];
             // B, the LDS-resident graph: the smaller image among the graphs of
@@ -106,7 +192,10 @@ struct stream_solver {
             real *const AP = Pv + (size_t)N;
             real *const DG = AP + (size_t)N;
 
-            __syncthreads();     // the previous pair is done with LDS and scratch
+            grp.barrier();       // the previous pair is done with LDS and scratch
+            // this part's rows of A (and of every vector)
+            const int rlo = (int)((long)nA * grp.part / grp.M), rhi = (int)((long)nA * (grp.part + 1u) / grp.M);
+            const int ilo = rlo * nB, ihi = rhi * nB;
             {
                 typedef unsigned v4 __attribute__((ext_vector_type(4)));
                 const unsigned wB = sw ? w1 : w2;
@@ -175,7 +264,7 @@ struct stream_solver {
 
             // ---- diagonal, right-hand side, start vectors ---------------------
             real rTz = 0;
-            for (int i = tid; i < N; i += TPB) {
+            for (int i = ilo + tid; i < ihi; i += TPB) {
                 const int iA = i / nB, iB = i - iA * nB;
                 const real dx = real(gA.degree[iA]) * real(gB.degree[iB]) * inv1q2;
                 const node_t vA = gA.node[iA], vB = gB.node[iB];
@@ -188,21 +277,26 @@ struct stream_solver {
                 rTz += b * b * mi;
             }
             rTz = block_reduce<real, W>::sum(rTz, red);
+            {
+                real v[1] = {rTz};
+                grp.sum(v, red);
+                rTz = v[0];
+            }
 
             const real tol = prm.ftol * real(N);
             const real tol2 = tol * tol;
             unsigned it = 0;
             for (; it < (unsigned)N && rTz != real(0); ++it) {
-                __syncthreads();     // p of this iteration is in memory
+                grp.barrier();       // p of this iteration is in memory, every part's rows of it
                 real pAp = 0;
-                for (int base = 0; base < nA; base += G) {
+                for (int base = rlo; base < rhi; base += G) {
                     const int iA = base + g;
-                    const bool row_ok = g < G && iA < nA;
+                    const bool row_ok = g < G && iA < rhi;
                     const int rsA = row_ok ? (int)gA.rowptr[iA] : 0;
                     const int dA = row_ok ? (int)gA.rowptr[iA + 1] - rsA : 0;
                     // longest row of the step (workgroup-uniform)
                     int dmax = 0;
-                    for (int k = 0; k < G && base + k < nA; ++k) {
+                    for (int k = 0; k < G && base + k < rhi; ++k) {
                         const int d = (int)gA.rowptr[base + k + 1] - (int)gA.rowptr[base + k];
                         dmax = d > dmax ? d : dmax;
                     }
@@ -249,12 +343,17 @@ struct stream_solver {
                     }
                 }
                 pAp = block_reduce<real, W>::sum(pAp, red);    // (its barriers publish AP)
+                {
+                    real v[1] = {pAp};
+                    grp.sum(v, red);
+                    pAp = v[0];
+                }
                 // (pAp != pAp: a NaN must end the solve, not run it for N
                 // iterations -- the reference's rules do not stop on one)
                 if (pAp == real(0) || pAp != pAp) break;
                 const real alpha = rTz / pAp;
                 real rTr = 0, rTz_next = 0;
-                for (int i = tid; i < N; i += TPB) {
+                for (int i = ilo + tid; i < ihi; i += TPB) {
                     X[i] += alpha * Pv[i];
                     const real rv = Rv[i] - alpha * AP[i];
                     Rv[i] = rv;
@@ -262,16 +361,22 @@ struct stream_solver {
                     rTz_next += rv * rv / DG[i];
                 }
                 block_reduce<real, W>::sum2(rTr, rTz_next, red);
+                {
+                    real v[2] = {rTr, rTz_next};
+                    grp.sum(v, red);
+                    rTr = v[0];
+                    rTz_next = v[1];
+                }
                 if (rTr < tol2) {
                     ++it;
                     break;
                 }
                 const real beta = rTz_next / rTz;
-                for (int i = tid; i < N; i += TPB) Pv[i] = Rv[i] / DG[i] + beta * Pv[i];
+                for (int i = ilo + tid; i < ihi; i += TPB) Pv[i] = Rv[i] / DG[i] + beta * Pv[i];
                 rTz = rTz_next;
             }
             __syncthreads();
-            if (prm.iters != nullptr && tid == 0) prm.iters[prm.order[t]] = it;
+            if (prm.iters != nullptr && tid == 0 && grp.part == 0) prm.iters[prm.order[t]] = it;
 
             // ---- output (conventions of pair_solver / template.cu:100-224) ----
             const unsigned flags = prm.flags;
@@ -279,7 +384,7 @@ struct stream_solver {
             const bool mirror = (flags & F_SYMMETRIC) && job.i != job.j;
             const int n2 = h2.n_node;
             real ksum = 0;
-            for (int i = tid; i < N; i += TPB) {
+            for (int i = ilo + tid; i < ihi; i += TPB) {
                 const int iA = i / nB, iB = i - iA * nB;
                 const node_t vA = gA.node[iA], vB = gB.node[iB];
                 real xi = X[i];
@@ -302,7 +407,12 @@ struct stream_solver {
             }
             if (!(flags & F_NODAL)) {
                 ksum = block_reduce<real, W>::sum(ksum, red);
-                if (tid == 0) {
+                {
+                    real v[1] = {ksum};
+                    grp.sum(v, red);
+                    ksum = v[0];
+                }
+                if (tid == 0 && grp.part == 0) {
                     if (flags & F_PACKED) {
                         prm.gramian[prm.order[t]] = ksum;
                     } else if (flags & F_DIAGONAL) {

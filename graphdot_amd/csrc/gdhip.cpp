@@ -206,6 +206,26 @@ int gd_launch(gd_function_t f, uint32_t grid_x, uint32_t block_x,
     return 0;
 }
 
+int gd_launch_cooperative(gd_function_t f, uint32_t grid_x, uint32_t block_x,
+                          uint32_t dynamic_lds_bytes, gd_stream_t s,
+                          const void *args, size_t args_bytes) {
+    if (!f) return fail("gd_launch_cooperative: null function");
+    if (grid_x == 0 || block_x == 0) return 0;
+    (void)args_bytes;      // (one by-value struct: the code object knows its size)
+    void *params[] = {const_cast<void *>(args)};
+    GD_TRY(hipModuleLaunchCooperativeKernel(reinterpret_cast<hipFunction_t>(f),
+                                            grid_x, 1, 1, block_x, 1, 1,
+                                            dynamic_lds_bytes, S(s), params));
+    return 0;
+}
+int gd_function_max_active_blocks(gd_function_t f, uint32_t block_x,
+                                  uint32_t dynamic_lds_bytes, int *per_cu) {
+    if (!f || !per_cu) return fail("gd_function_max_active_blocks: null argument");
+    GD_TRY(hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(
+        per_cu, reinterpret_cast<hipFunction_t>(f), (int)block_x, dynamic_lds_bytes));
+    return 0;
+}
+
 int gd_stream_create(gd_stream_t *out) {
     if (!out) return fail("gd_stream_create: null argument");
     hipStream_t s;

@@ -58,6 +58,8 @@ SIGNATURES = {
                                _P(ctypes.c_int)],
     'gd_function_set_max_dynamic_lds': [_vp, ctypes.c_int],
     'gd_launch': [_vp, _u32, _u32, _u32, _vp, _vp, _sz],
+    'gd_launch_cooperative': [_vp, _u32, _u32, _u32, _vp, _vp, _sz],
+    'gd_function_max_active_blocks': [_vp, _u32, _u32, _P(ctypes.c_int)],
     'gd_stream_create': [_P(_vp)],
     'gd_stream_create_low_priority': [_P(_vp)],
     'gd_stream_destroy': [_vp],
@@ -499,10 +501,23 @@ class Module:
                     num_regs=regs.value)
 
 
-def launch(function, grid, block, args: bytes, stream=None, dynamic_lds=0):
+def launch(function, grid, block, args: bytes, stream=None, dynamic_lds=0,
+           cooperative=False):
+    """`cooperative`: every workgroup of the grid resident at once
+    (gd_launch_cooperative): the kernel synchronises its workgroups through
+    device memory."""
     buf = ctypes.create_string_buffer(args, len(args))
-    check(lib().gd_launch(function, grid, block, dynamic_lds, stream, buf,
-                          len(args)))
+    fn = lib().gd_launch_cooperative if cooperative else lib().gd_launch
+    check(fn(function, grid, block, dynamic_lds, stream, buf, len(args)))
+
+
+def max_active_blocks(function, block, dynamic_lds=0):
+    """Workgroups of `block` threads and `dynamic_lds` bytes that one
+    compute unit holds at a time."""
+    n = ctypes.c_int(0)
+    check(lib().gd_function_max_active_blocks(function, block, dynamic_lds,
+                                              ctypes.byref(n)))
+    return n.value
 
 
 def null_stream_wait_event(event):

@@ -111,6 +111,8 @@ STREAM_THREADS = 1024
 STREAM_ROWS = 4
 #: neighbours per lane segment of the LDS-resident graph (mgk_stream.h SEG_CAP)
 STREAM_CAP = 16
+#: workgroups that may share one pair of the streamed solver
+STREAM_MAX_PARTS = 256
 LDS_LIMIT = 160 * 1024
 _LARGE_PAIR_SOLVERS = ([STREAM] if os.environ.get('GD_STREAM', '1') != '0'
                        else []) + [GENERAL]
@@ -384,14 +386,16 @@ class LaunchSet:
                 front.wait_event(self._last_done[slot])
         for L in plan.pre_launches:
             runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                           stream=fh, dynamic_lds=L['dynamic_lds'])
+                           stream=fh, dynamic_lds=L['dynamic_lds'],
+                           cooperative=L.get('cooperative', False))
         n = len(plan.launches)
         if serial:
             for k, L in enumerate(plan.launches):
                 if events is not None:
                     events[k][0].record()
                 runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                               dynamic_lds=L['dynamic_lds'])
+                               dynamic_lds=L['dynamic_lds'],
+                           cooperative=L.get('cooperative', False))
                 if events is not None:
                     events[k][1].record()
             self._n_last = 0
@@ -427,7 +431,8 @@ class LaunchSet:
             if events is not None:
                 events[k][0].record(s.h)
             runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                           stream=s.h, dynamic_lds=L['dynamic_lds'])
+                           stream=s.h, dynamic_lds=L['dynamic_lds'],
+                           cooperative=L.get('cooperative', False))
             if events is not None:
                 events[k][1].record(s.h)
         for slot in range(ns):
@@ -587,6 +592,17 @@ class HIPBackend(Backend):
         if self._props is None:
             self._props = runtime.device_props(self.device)
         return self._props
+
+    def _zeroed_buffer(self, name, nbytes):
+        """A pooled buffer that is all zeros when it is made (the barrier
+        cells of the streamed solver: the kernels leave them clean)."""
+        buf = self._pool.get(name)
+        if buf is None or buf.nbytes < nbytes:
+            buf = self._pool[name] = runtime.DeviceBuffer(
+                max(int(nbytes * 1.25), 256))
+            buf.upload(np.zeros(buf.nbytes, dtype=np.uint8))
+            runtime.synchronize()
+        return buf
 
     def _buffer(self, name, nbytes):
         """Grow-only pool of per-call device buffers.  A buffer that is too
@@ -756,12 +772,12 @@ struct ${name}_t : ${name}_theta_t {
         return np.dtype([
             ('arena', P), ('jobs', P), ('order', P), ('starts', P),
             ('gramian', P), ('gradient', P), ('iters', P), ('scratch', P),
-            ('tables', P), ('diag', P), ('diag_grad', P), ('hotspot', P),
+            ('sync', P), ('tables', P), ('diag', P), ('diag_grad', P), ('hotspot', P),
             ('node_starts', P), ('diag_ld', np.uint32),
             ('n_launch_jobs', np.uint32), ('nX', np.uint32),
             ('nY', np.uint32), ('nJ', np.uint32), ('flags', np.uint32),
             ('order_offset', np.uint32), ('u_capacity', np.uint32),
-            ('g_capacity', np.uint32),
+            ('g_capacity', np.uint32), ('parts', np.uint32),
             ('n_vclass', np.uint32), ('n_eclass', np.uint32),
             ('vrep', np.uint32), ('erep', np.uint32),
             ('q', self.real), ('q0', self.real), ('eps', self.real),
@@ -2016,7 +2032,28 @@ void ${name}(params_t prm) {
             L['fn'] = fn = L['module'].function(
                 self.kernel_name(L['variant'], C, nodal, L['tab'], ngrad,
                                  maximin is not None))
-            if L['variant'] in (GENERAL, STREAM):
+            if L['variant'] == STREAM:
+                # few pairs: several workgroups per pair, a cooperative
+                # launch (mgk_stream.h).  M = what the chip holds at once over
+                # the pairs; one workgroup per pair from half the chip up.
+                if L['dynamic_lds'] > 64 * 1024:
+                    runtime.set_max_dynamic_lds(fn, L['dynamic_lds'])
+                resident = self.props.compute_units * max(
+                    1, runtime.max_active_blocks(fn, L['threads'],
+                                                 L['dynamic_lds']))
+                parts = int(os.environ.get('GD_STREAM_PARTS', 0)) or \
+                    max(1, min(resident // L['count'], STREAM_MAX_PARTS))
+                parts = max(1, min(parts, resident))
+                slots = int(min(L['count'], max(1, resident // parts)))
+                if parts == 1:
+                    slots = int(min(L['count'],
+                                    2 * self.props.compute_units))
+                L['parts'], L['cooperative'] = parts, parts > 1
+                L['grid'] = slots * parts
+                L['scratch_bytes'] = slots * L['per_wg'] * rsize
+                L['sync_bytes'] = slots * 4 * (
+                    16 + 2 * parts * 4 * (rsize // 4)) if parts > 1 else 0
+            elif L['variant'] == GENERAL:
                 L['grid'] = int(min(L['count'],
                                     2 * self.props.compute_units))
                 L['scratch_bytes'] = L['grid'] * L['per_wg'] * rsize
@@ -2040,6 +2077,9 @@ void ${name}(params_t prm) {
                 scratch_bytes += -(-L['scratch_bytes'] // 256) * 256
         b_scratch = self._buffer('scratch', scratch_bytes) \
             if scratch_bytes else None
+        sync_bytes = max([L.get('sync_bytes', 0) for L in launches] + [0])
+        b_sync = self._zeroed_buffer('sync', sync_bytes) if sync_bytes \
+            else None
         # global microkernel tables of this evaluation: values (and, for the
         # gradient solvers, one plane per hyperparameter) per pair of classes
         b_tables = None
@@ -2118,6 +2158,8 @@ void ${name}(params_t prm) {
             a['u_capacity'] = L['ucap']
             if L.get('scratch_bytes', 0):
                 a['scratch'] = b_scratch.ptr + L['scratch_offset']
+            if L.get('parts', 1) > 1:
+                a['parts'], a['sync'] = L['parts'], b_sync.ptr
             if L.get('dense'):
                 a['flags'] |= F_DENSE
             if fd is not None:
@@ -2148,7 +2190,8 @@ void ${name}(params_t prm) {
         if stream is not None:
             for L in plan.pre_launches + plan.launches:
                 runtime.launch(L['fn'], L['grid'], L['threads'], L['args'],
-                               stream=stream, dynamic_lds=L['dynamic_lds'])
+                               stream=stream, dynamic_lds=L['dynamic_lds'],
+                           cooperative=L.get('cooperative', False))
             return
         if self._launch_set is None:
             self._launch_set = LaunchSet()

@@ -88,6 +88,19 @@ int gd_launch(gd_function_t f, uint32_t grid_x, uint32_t block_x,
               uint32_t dynamic_lds_bytes, gd_stream_t s, const void *args,
               size_t args_bytes);
 
+/* A COOPERATIVE launch (hipModuleLaunchCooperativeKernel): every workgroup
+ * of the grid is resident at once, so the kernel may synchronise its
+ * workgroups through device memory (the streamed solver of large pairs deals
+ * one pair to several workgroups, csrc/device/mgk_stream.h).  The runtime
+ * refuses a grid that cannot be co-resident; gd_function_max_active_blocks
+ * says how many workgroups of `block_x` threads and `dynamic_lds_bytes` one
+ * compute unit holds.  New (no PyCUDA counterpart in the reference). */
+int gd_launch_cooperative(gd_function_t f, uint32_t grid_x, uint32_t block_x,
+                          uint32_t dynamic_lds_bytes, gd_stream_t s,
+                          const void *args, size_t args_bytes);
+int gd_function_max_active_blocks(gd_function_t f, uint32_t block_x,
+                                  uint32_t dynamic_lds_bytes, int *per_cu);
+
 /* ---- streams & events (timing of the launched kernels on their own stream) */
 int gd_stream_create(gd_stream_t *out);
 /* A non-blocking stream of the LOWEST priority the device offers

@@ -51,12 +51,22 @@ def _worker(rank, world, port, tmp):
     gpr2 = GaussianProcessRegressor(k, alpha=float(0.1 * d.mean()))
     gpr2.X, gpr2.y = G, y2
     lml2, glml2 = gpr2.log_marginal_likelihood(eval_gradient=True)
+    # the overlapped form (off by default): the matrix from a value step of
+    # its own, the value + gradient solvers detached on low-priority streams
+    # while the factorisation is enqueued, joined before the contraction
+    os.environ['GD_GPR_OVERLAP'] = '1'
+    lml3, glml3 = gpr.log_marginal_likelihood(eval_gradient=True)
+    del os.environ['GD_GPR_OVERLAP']
+    assert k.backend.overlaps_dense_algebra() is False
+    pending = k.backend.last_step
+    assert not pending.gather_gradient and pending.n_grad == k.n_dims
     phases = step.phase_ms(steps=2)
     assert set(phases) == {'shard_ms', 'all_gather_ms', 'reassembly_ms'}
     assert all(v > 0 for v in phases.values())
     np.savez(os.path.join(tmp, f'rank{rank}.npz'), K=K, K2=K2, dK=dK,
              Kxy=Kxy, d=d, lml=lml, glml=glml, loo=loo, gloo=gloo,
-             lml2=lml2, glml2=glml2, n_local=n_local)
+             lml2=lml2, glml2=glml2, n_local=n_local, lml3=lml3,
+             glml3=glml3)
     dist.destroy_process_group()
 
 
@@ -119,6 +129,11 @@ def test_ranks_through_the_kernel_api(tmp_path, world):
         assert np.array_equal(r['glml2'], r0['glml2'])
         assert np.allclose(r['glml'], glml, rtol=1e-10, atol=1e-12 * np.abs(glml).max())
         assert np.allclose(r['glml2'], glml2, rtol=1e-10, atol=1e-12 * np.abs(glml2).max())
+        # overlapped: the matrix comes from the VALUE solvers (other
+        # instantiations than the value + gradient ones: round-off apart)
+        assert float(r['lml3']) == pytest.approx(lml, rel=1e-6)
+        assert np.allclose(r['glml3'], glml, rtol=1e-4,
+                           atol=1e-6 * np.abs(glml).max())
     # ... and against the numpy kernel protocol (host arrays, float64
     # conversion on the host) to round-off
     slow = GaussianProcessRegressor(k, alpha=float(0.1 * d.mean()),

@@ -670,6 +670,72 @@ def test_streamed_solver_on_large_spatial_graphs(real):
                        atol=rtol * np.abs(Kn).max())
 
 
+@pytest.mark.parametrize('real', [np.float32, np.float64])
+def test_streamed_solver_several_workgroups_per_pair(real, monkeypatch):
+    """A handful of large pairs (three protein-like graphs: six pairs -- the
+    reference's protein-time-to-solution.py evaluates ONE) would occupy six
+    compute units: the streamed solver deals each pair to M workgroups in a
+    cooperative launch (mgk_stream.h: row ranges of A per part, three
+    grid-wide barriers per CG iteration, partial scalar products summed in
+    part order).  Values against the C restatement, nodal outputs and
+    iteration counts against the one-workgroup form (GD_STREAM_PARTS=1)."""
+    from graphdot_amd.kernel.marginalized._backend_hip import (
+        HIPBackend, STREAM)
+    f64 = real is np.float64
+    G = Graph.unify_datatype(
+        cases.protein_like_graphs(3, nmin=120, nmax=380, seed=43))
+    knode, kedge, q = cases.tang2019_kernels()
+    kw = {'ftol': 1e-13} if f64 else {}
+
+    def evaluate(parts):
+        if parts is None:
+            monkeypatch.delenv('GD_STREAM_PARTS', raising=False)
+        else:
+            monkeypatch.setenv('GD_STREAM_PARTS', str(parts))
+        be = HIPBackend(real=real, record_iterations=True)
+        k = MarginalizedGraphKernel(knode, kedge, q=q, backend=be, **kw)
+        K = k(G)
+        L = [L for L in be.last_plan.launches if L['variant'] == STREAM]
+        assert len(L) == 1 and L[0]['count'] == 6
+        return K, be.iterations(be.last_plan), L[0], k(G[:2], nodal=True), \
+            k(G[2:], G[:2])
+
+    K, it, launch, Kn, Kxy = evaluate(None)
+    assert launch['parts'] > 1 and launch['cooperative']
+    assert launch['grid'] == launch['parts'] * min(
+        6, launch['grid'] // launch['parts'])
+    K1, it1, launch1, Kn1, Kxy1 = evaluate(1)
+    assert launch1['parts'] == 1 and not launch1['cooperative']
+    i, j = np.triu_indices(len(G))
+    ref, _ = oracle.TensorProductBatch(G, knode, kedge).run(
+        i, j, q=q, real='f64', tol=1e-13, omp=True)
+    tol = 1e-8 if f64 else 1e-5
+    assert np.abs(K[i, j] / ref - 1).max() <= tol
+    assert np.array_equal(K, K.T)
+    # the same iteration, the scalar products summed in another order
+    rt = 1e-11 if f64 else 2e-6
+    assert np.allclose(K, K1, rtol=rt)
+    assert np.abs(it.astype(int) - it1.astype(int)).max() <= 1
+    assert np.allclose(Kn, Kn1, rtol=rt, atol=rt * np.abs(Kn1).max())
+    assert np.allclose(Kxy, Kxy1, rtol=rt) and np.allclose(Kxy, K[2:, :2], rtol=rt)
+    # seven parts for a graph of ... rows each, and more parts than rows
+    K7, *_ = evaluate(7)
+    assert np.allclose(K7, K1, rtol=rt)
+    tiny = Graph.unify_datatype(
+        cases.protein_like_graphs(1, nmin=300, nmax=320, seed=44)
+        + cases.tang2019_graphs(1, seed=5))
+    monkeypatch.delenv('GD_STREAM_PARTS', raising=False)
+    from graphdot_amd.kernel.marginalized._backend_hip import GENERAL
+    be = HIPBackend(real=real, variants=[STREAM, GENERAL])
+    kt = MarginalizedGraphKernel(knode, kedge, q=q, backend=be, **kw)
+    Kt = kt(tiny)
+    assert all(L['variant'] == STREAM for L in be.last_plan.launches)            # (a 20-atom graph as A: fewer rows than parts)
+    it_, jt_ = np.triu_indices(2)
+    reft, _ = oracle.TensorProductBatch(tiny, knode, kedge).run(
+        it_, jt_, q=q, real='f64', tol=1e-13, omp=True)
+    assert np.abs(Kt[it_, jt_] / reft - 1).max() <= tol
+
+
 def test_gpr_log_marginal_likelihood_step(backend):
     """Config 5 in miniature: one hyperparameter-fit step of a Gaussian
     process on top of the kernel protocol (the computation of the reference's
