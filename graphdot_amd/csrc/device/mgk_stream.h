@@ -89,7 +89,7 @@ struct stream_solver {
     // Scalar products: every part publishes its partial sums, all parts add
     // the M partials up in part order -- the same numbers, hence the same
     // control flow, in every part.  M = 1: none of this is executed.
-    constexpr static unsigned SYNC_HEAD = 16;        // words: [count, generation, pad]
+    constexpr static unsigned SYNC_HEAD = 16;        // words: [count, generation, poisoned, pad]
     __device__ static __forceinline__ unsigned sync_words(unsigned M) {
         return SYNC_HEAD + 2u * M * 4u * (unsigned)(sizeof(real) / 4u);
     }
@@ -112,8 +112,21 @@ struct stream_solver {
                     __threadfence();
                     atomicAdd(&cells[1], 1u);
                 } else {
-                    while (__hip_atomic_load(&cells[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen)
+                    // (a part that never arrives -- a grid that is not fully
+                    // resident after all, a diverged part -- must not hang
+                    // the device: after ~2 s the slot is POISONED, cells[2],
+                    // every barrier of it falls through, and the host raises
+                    // when it collects the results)
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(&cells[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
                         __builtin_amdgcn_s_sleep(2);
+                        if ((++spins & 0xFFFu) == 0u &&
+                            (spins > (1u << 24) ||
+                             __hip_atomic_load(&cells[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                            atomicExch(&cells[2], 1u);
+                            break;
+                        }
+                    }
                 }
                 __threadfence();  // acquire: the other parts' stores are read afresh
             }

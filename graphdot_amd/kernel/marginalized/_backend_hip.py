@@ -2038,9 +2038,15 @@ void ${name}(params_t prm) {
                 # the pairs; one workgroup per pair from half the chip up.
                 if L['dynamic_lds'] > 64 * 1024:
                     runtime.set_max_dynamic_lds(fn, L['dynamic_lds'])
-                resident = self.props.compute_units * max(
-                    1, runtime.max_active_blocks(fn, L['threads'],
-                                                 L['dynamic_lds']))
+                # (workgroups the chip holds at once, by this build's own
+                # arithmetic as well as by the runtime's: a grid beyond it
+                # would wait for workgroups that wait for it)
+                per_cu = max(1, min(
+                    runtime.max_active_blocks(fn, L['threads'],
+                                              L['dynamic_lds']),
+                    LDS_LIMIT // (L['dynamic_lds'] + 1024),
+                    2048 // L['threads']))
+                resident = self.props.compute_units * per_cu
                 parts = int(os.environ.get('GD_STREAM_PARTS', 0)) or \
                     max(1, min(resident // L['count'], STREAM_MAX_PARTS))
                 parts = max(1, min(parts, resident))
@@ -2160,6 +2166,7 @@ void ${name}(params_t prm) {
                 a['scratch'] = b_scratch.ptr + L['scratch_offset']
             if L.get('parts', 1) > 1:
                 a['parts'], a['sync'] = L['parts'], b_sync.ptr
+                plan.sync = (b_sync, L['sync_bytes'])
             if L.get('dense'):
                 a['flags'] |= F_DENSE
             if fd is not None:
@@ -2206,6 +2213,23 @@ void ${name}(params_t prm) {
         gradient entries) per job, in job order."""
         runtime.synchronize()
         rs = np.dtype(self.real)
+        sync = getattr(plan, 'sync', None)
+        if sync is not None:
+            # the streamed solver's grid barriers: a slot whose parts did not
+            # all arrive was poisoned by the watchdog (mgk_stream.h) -- its
+            # results are not solutions
+            cells = np.empty(sync[1] // 4, dtype=np.uint32)
+            sync[0].download(cells)
+            L = [L for L in plan.launches if L.get('parts', 1) > 1][0]
+            stride = len(cells) // max(L['grid'] // L['parts'], 1)
+            if np.any(cells[2::stride][:L['grid'] // L['parts']]):
+                sync[0].upload(np.zeros(sync[0].nbytes, dtype=np.uint8))
+                runtime.synchronize()
+                raise RuntimeError(
+                    'streamed solver: a grid-wide barrier of a cooperative '
+                    f'launch ({L["grid"]} workgroups, {L["parts"]} per pair) '
+                    'timed out -- the grid was not co-resident; set '
+                    'GD_STREAM_PARTS=1 for one workgroup per pair')
 
         def fetch(buf, n, dest):
             # straight into the caller's array when it can take the bytes
