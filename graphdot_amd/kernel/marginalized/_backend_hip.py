@@ -593,15 +593,13 @@ class HIPBackend(Backend):
             self._props = runtime.device_props(self.device)
         return self._props
 
-    def _zeroed_buffer(self, name, nbytes):
-        """A pooled buffer that is all zeros when it is made (the barrier
-        cells of the streamed solver: the kernels leave them clean)."""
-        buf = self._pool.get(name)
-        if buf is None or buf.nbytes < nbytes:
-            buf = self._pool[name] = runtime.DeviceBuffer(
-                max(int(nbytes * 1.25), 256))
-            buf.upload(np.zeros(buf.nbytes, dtype=np.uint8))
-            runtime.synchronize()
+    @staticmethod
+    def _zeroed_buffer(nbytes):
+        """A device buffer of zeros (the barrier cells of the streamed
+        solver; owned by the plan that asked for it)."""
+        buf = runtime.DeviceBuffer(max(int(nbytes), 256))
+        buf.upload(np.zeros(buf.nbytes, dtype=np.uint8))
+        runtime.synchronize()
         return buf
 
     def _buffer(self, name, nbytes):
@@ -2084,8 +2082,11 @@ void ${name}(params_t prm) {
         b_scratch = self._buffer('scratch', scratch_bytes) \
             if scratch_bytes else None
         sync_bytes = max([L.get('sync_bytes', 0) for L in launches] + [0])
-        b_sync = self._zeroed_buffer('sync', sync_bytes) if sync_bytes \
-            else None
+        # (a buffer of its OWN per plan: the kernels leave the barrier cells
+        # clean at THIS plan's slot stride -- a pooled buffer re-used by a
+        # plan of another M had its counters on leftover partial sums, and
+        # the second evaluation of a backend dead-locked in its first barrier)
+        b_sync = self._zeroed_buffer(sync_bytes) if sync_bytes else None
         # global microkernel tables of this evaluation: values (and, for the
         # gradient solvers, one plane per hyperparameter) per pair of classes
         b_tables = None
