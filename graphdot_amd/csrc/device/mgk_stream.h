@@ -59,6 +59,10 @@ struct stream_solver {
 #endif
     constexpr static int SEG_CAP = GD_STREAM_CAP;     // neighbours of B per lane segment (doubled until the segments fit)
     constexpr static int MAX_LAYERS = 64;             // nB <= TPB = 1024 = 64 * 16
+#ifndef GD_STREAM_LDS_BUDGET
+#define GD_STREAM_LDS_BUDGET (159 * 1024)
+#endif
+    constexpr static unsigned LDS_BUDGET = GD_STREAM_LDS_BUDGET;   // dynamic LDS a pair may ask for (HIPBackend.stream_lds_bytes)
 
     struct lds_t {
         real red[2 * W];
@@ -192,9 +196,23 @@ struct stream_solver {
             const bool ok1 = h1.n_node <= TPB, ok2 = h2.n_node <= TPB;
             const bool sw = ok1 && (!ok2 || w1 < w2);     // B = graph 1
             const graph_header_t hA = sw ? h2 : h1, hB = sw ? h1 : h2;
+            const unsigned wB = sw ? w1 : w2;
+            // Does B's image fit the LDS beside the staged rows (at their
+            // largest: A_ROWS + 1 reals per lane)?  If not -- the double
+            // build's largest graphs, 16-byte edge records -- B is read
+            // where it lies, from L2: slower per term, but the pair keeps
+            // the streamed solver and its M workgroups.  The pair's body is
+            // instantiated for either case (`in_lds`): a view of B through
+            // one pointer type would turn every read into a flat load.
+            const bool fits = wB * 16u + (unsigned)((A_ROWS + 1) * TPB * sizeof(real)) <= LDS_BUDGET;
+            auto solve_pair = [&](auto in_lds) {
+            constexpr bool B_IN_LDS = decltype(in_lds)::value;
             const Graph gA(prm.arena, hA);
-            const Graph gB(lG - hB.degree, hB);
-            real *const stage = reinterpret_cast<real *>(lG + (sw ? w1 : w2) * 16u);
+            const Graph gB = [&] {
+                if constexpr (B_IN_LDS) return Graph(lG - hB.degree, hB);
+                else return Graph(prm.arena, hB);
+            }();
+            real *const stage = reinterpret_cast<real *>(lG + (B_IN_LDS ? wB * 16u : 0u));
             const int nA = hA.n_node, nB = hB.n_node, N = nA * nB;
             const real q = prm.q, q0 = prm.q0;
             const real inv1q2 = real(1) / ((real(1) - q) * (real(1) - q));
@@ -209,9 +227,8 @@ struct stream_solver {
             // this part's rows of A (and of every vector)
             const int rlo = (int)((long)nA * grp.part / grp.M), rhi = (int)((long)nA * (grp.part + 1u) / grp.M);
             const int ilo = rlo * nB, ihi = rhi * nB;
-            {
+            if constexpr (B_IN_LDS) {
                 typedef unsigned v4 __attribute__((ext_vector_type(4)));
-                const unsigned wB = sw ? w1 : w2;
                 const v4 *const src = reinterpret_cast<const v4 *>(prm.arena + hB.degree);
                 v4 *const dst = reinterpret_cast<v4 *>(lG);
                 for (unsigned w = tid; w < wB; w += TPB) dst[w] = src[w];
@@ -436,6 +453,9 @@ struct stream_solver {
                     }
                 }
             }
+            };      // solve_pair
+            if (fits) solve_pair(std::true_type{});
+            else solve_pair(std::false_type{});
         }
     }
 };

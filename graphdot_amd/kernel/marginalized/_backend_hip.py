@@ -113,6 +113,8 @@ STREAM_ROWS = 4
 STREAM_CAP = 16
 #: workgroups that may share one pair of the streamed solver
 STREAM_MAX_PARTS = 256
+#: dynamic LDS a pair of the streamed solver may ask for (mgk_stream.h LDS_BUDGET)
+STREAM_LDS_BUDGET = 159 * 1024
 LDS_LIMIT = 160 * 1024
 _LARGE_PAIR_SOLVERS = ([STREAM] if os.environ.get('GD_STREAM', '1') != '0'
                        else []) + [GENERAL]
@@ -1019,13 +1021,13 @@ extern "C" __global__ __launch_bounds__(${threads})
 void ${name}(params_t prm) {
     using solver = graphdot::mgk::stream_solver<real_t, ${threads}, ${C},
         graph_t, node_kernel_t, edge_kernel_t, p_start_t>;
-    static_assert(solver::A_ROWS == ${rows} && solver::SEG_CAP == ${cap}, "rows of p staged per pass, neighbours per segment: host and device disagree");
+    static_assert(solver::A_ROWS == ${rows} && solver::SEG_CAP == ${cap} && solver::LDS_BUDGET == ${budget}, "rows of p staged per pass, neighbours per segment, LDS budget: host and device disagree");
     __shared__ typename solver::lds_t lds;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     solver::run(prm, lds, dyn_lds, prm.scratch);
 }
 ''').render(threads=STREAM_THREADS, name=self.kernel_name(v, C), C=C,
-            rows=STREAM_ROWS, cap=STREAM_CAP)
+            rows=STREAM_ROWS, cap=STREAM_CAP, budget=STREAM_LDS_BUDGET)
         threads = 64 * v.W * (WPB1 if v.W == 1 else 1)
         return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
@@ -1119,10 +1121,12 @@ void ${name}(params_t prm) {
     def stream_lds_bytes(self, image1, image2, n1, n2, nv1, nv2):
         """Dynamic LDS of a pair in the streamed solver (mgk_stream.h): the
         image of B -- the smaller image among the graphs of at most
-        STREAM_THREADS nodes, ties: graph 2 -- in 16-byte units, and behind
-        it, for each of the G = STREAM_THREADS // ceil64(nV) row groups of a
-        workgroup step (nV: B's virtual rows), STREAM_ROWS rows of p and one
-        partial sum per lane.  A huge number if neither graph qualifies."""
+        STREAM_THREADS nodes, ties: graph 2 -- in 16-byte units (if it fits
+        STREAM_LDS_BUDGET beside the staged rows at their largest; otherwise
+        B is read from L2 and takes no LDS), and behind it, for each of the
+        G = STREAM_THREADS // ceil64(nV) row groups of a workgroup step (nV:
+        B's virtual rows), STREAM_ROWS rows of p and one partial sum per
+        lane.  A huge number if neither graph qualifies."""
         image1, image2 = np.asarray(image1), np.asarray(image2)
         n1, n2 = np.asarray(n1), np.asarray(n2)
         w1, w2 = -(-image1 // 16), -(-image2 // 16)
@@ -1132,8 +1136,14 @@ void ${name}(params_t prm) {
         nV = np.maximum(np.where(first, nv1, nv2), 1)
         LB = (-(-nV // 64) * 64).clip(max=STREAM_THREADS)
         G = STREAM_THREADS // LB
-        stage = (STREAM_ROWS * G * nB + G * LB) * np.dtype(self.real).itemsize
-        out = np.where(first, w1, w2) * 16 + -(-stage // 16) * 16
+        rs = np.dtype(self.real).itemsize
+        stage = (STREAM_ROWS * G * nB + G * LB) * rs
+        image = np.where(first, w1, w2) * 16
+        # (an image that does not fit beside the staged rows at their largest
+        # stays in L2: the pair's body is instantiated for that case too)
+        fits = image + (STREAM_ROWS + 1) * STREAM_THREADS * rs \
+            <= STREAM_LDS_BUDGET
+        out = np.where(fits, image, 0) + -(-stage // 16) * 16
         return np.where(ok1 | ok2, out, np.iinfo(np.int64).max // 4)
 
     def lds_slot_bytes(self, v, C, nodal=False):

@@ -734,6 +734,21 @@ def test_streamed_solver_several_workgroups_per_pair(real, monkeypatch):
     reft, _ = oracle.TensorProductBatch(tiny, knode, kedge).run(
         it_, jt_, q=q, real='f64', tol=1e-13, omp=True)
     assert np.abs(Kt[it_, jt_] / reft - 1).max() <= tol
+    if f64:
+        # a graph whose image (16-byte edge records in double) does not fit
+        # the LDS beside the staged rows: B is read from L2, the pair keeps
+        # the streamed solver and its many workgroups
+        big = Graph.unify_datatype(
+            cases.protein_like_graphs(1, nmin=570, nmax=600, seed=45))
+        be = HIPBackend(real=real)
+        kb = MarginalizedGraphKernel(knode, kedge, q=q, backend=be, **kw)
+        Kb = kb(big)
+        (Lb,) = be.last_plan.launches
+        assert Lb['variant'] == STREAM and Lb['parts'] > 1
+        assert Lb['dynamic_lds'] < 64 * 1024          # (no image in it)
+        refb, _ = oracle.TensorProductBatch(big, knode, kedge).run(
+            np.array([0]), np.array([0]), q=q, real='f64', tol=1e-13)
+        assert abs(Kb[0, 0] / refb[0] - 1) <= tol
 
 
 def test_gpr_log_marginal_likelihood_step(backend):
