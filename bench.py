@@ -976,8 +976,9 @@ def main():
             # profiled commands: config 3 in both arithmetics, its fp64
             # gradient step, configuration 2 in fp32 (scripts/profile_all.sh)
             key = {(3, False): args.dtype, (3, True): 'grad' + args.dtype[1:],
-                   (2, False): 'c2' if args.dtype == 'f32' else 'c2f64'}[
-                       (args.config, bool(args.gradient))]
+                   (2, False): 'c2' if args.dtype == 'f32' else 'c2f64',
+                   ('large', False): 'large' if args.dtype == 'f32'
+                   else 'large64'}[(args.config, bool(args.gradient))]
             tr = json.load(f)[key]['kernels'].get(roofline['kernel'])
         if tr and world == 1:
             # the image staging is a 16-byte-per-lane coalesced read, which
