@@ -101,6 +101,13 @@ GENERAL = Variant(0, 0, 0)
 #: sentinel: the kernel that fills the global microkernel tables
 TABLES = Variant(-1, 0, 0)
 GENERAL_THREADS = 1024
+#: sentinel: the dense-tile solver on the matrix cores (csrc/device/mgk_mfma.h):
+#: float value solves of DENSE pairs of graphs of at most 32 nodes under an
+#: edge microkernel that ignores the labels (`Constant`: one separable term).
+#: 82 M pairs/s against 4.2 M of the on-the-fly dense product on the dense
+#: molecular set (scripts/mfma_experiment.py).  GD_MFMA=0: off.
+MFMA = Variant(-3, 0, 0)
+MFMA_MAX_NODES = 32
 #: sentinel: the streamed solver for large pairs (csrc/device/mgk_stream.h):
 #: value solves of pairs beyond every register- and LDS-resident variant; one
 #: graph of the pair staged in LDS, the other streamed row by row, CG vectors
@@ -116,8 +123,8 @@ STREAM_MAX_PARTS = 256
 #: dynamic LDS a pair of the streamed solver may ask for (mgk_stream.h LDS_BUDGET)
 STREAM_LDS_BUDGET = 159 * 1024
 LDS_LIMIT = 160 * 1024
-_LARGE_PAIR_SOLVERS = ([STREAM] if os.environ.get('GD_STREAM', '1') != '0'
-                       else []) + [GENERAL]
+_LARGE_PAIR_SOLVERS = [MFMA] + (
+    [STREAM] if os.environ.get('GD_STREAM', '1') != '0' else []) + [GENERAL]
 #: independent pairs (waves) per workgroup of the one-wave variants;
 #: mgk_solver.h reads the same number from GD_WPB
 WPB1 = int(os.environ.get('GD_WPB', 1))
@@ -812,6 +819,8 @@ struct ${name}_t : ${name}_theta_t {
             return f'mgk_{f}_general_T{GENERAL_THREADS}_C{C}'
         if v == TABLES:
             return f'mgk_{f}_tables_C{C}'
+        if v == MFMA:
+            return f'mgk_{f}_mfma_C{C}'
         if v == STREAM:
             return f'mgk_{f}_stream_T{STREAM_THREADS}_C{C}'
         if isinstance(v, OCVariant):
@@ -1015,6 +1024,18 @@ void ${name}(params_t prm) {
     solver::run(prm, lds, prm.scratch);
 }
 ''').render(threads=GENERAL_THREADS, name=self.kernel_name(v, C), C=C)
+        if v == MFMA:
+            return Template(r'''
+extern "C" __global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(3)))
+void ${name}(params_t prm) {
+    using solver = graphdot::mgk::mfma_solver<real_t, graph_t, node_kernel_t,
+        edge_kernel_t, p_start_t>;
+    __shared__ typename solver::lds_t lds;
+    extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
+    solver::run(prm, lds, dyn_lds);
+}
+''').render(name=self.kernel_name(v, C))
         if v == STREAM:
             return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
@@ -1270,7 +1291,7 @@ void ${name}(params_t prm) {
         return worst
 
     def classify(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
-                 oc_only=False, nodal=False):
+                 oc_only=False, nodal=False, mfma=False):
         """Assign every job the cheapest solver variant it fits.  Returns
         (variant index, cost, stage-1 tasks, image bytes, padded rows, image
         bytes incl. class ids) per job.
@@ -1282,11 +1303,11 @@ void ${name}(params_t prm) {
         QM7-like molecules): large job lists are classified once per pair of
         graph classes and looked up."""
         sel, out = self._classify_classes(ji, jj, dgraphs, C, tab_bytes, gtab,
-                                          oc_only, nodal=nodal)
+                                          oc_only, nodal=nodal, mfma=mfma)
         return out if sel is None else tuple(a[sel.sel] for a in out)
 
     def _classify_classes(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
-                          oc_only=False, jobs=None, nodal=False):
+                          oc_only=False, jobs=None, nodal=False, mfma=False):
         """(sel, per-class-pair results): job t has the results of class pair
         sel.sel[t] (`ClassPairs`: class-pair key per job, jobs per key); sel is
         None for short job lists (results are per job).  `jobs`: the job list
@@ -1298,7 +1319,7 @@ void ${name}(params_t prm) {
             ji = np.asarray(ji, dtype=np.int64)
             jj = np.asarray(jj, dtype=np.int64)
             return None, self._classify_pairs(ji, jj, dgraphs, C, tab_bytes,
-                                              gtab, oc_only, nodal)
+                                              gtab, oc_only, nodal, mfma)
         # graphs of one degree histogram and image size are classified alike
         f = graph_features(dgraphs)
         if int(f['max_degree'].max()) < HIST_BINS - 1:
@@ -1335,7 +1356,7 @@ void ${name}(params_t prm) {
             count = np.bincount(pk, minlength=nc * nc)
         upk = np.flatnonzero(count)
         out = self._classify_pairs(rep[upk // nc], rep[upk % nc], dgraphs, C,
-                                   tab_bytes, gtab, oc_only, nodal)
+                                   tab_bytes, gtab, oc_only, nodal, mfma)
         return ClassPairs(pk, upk, count, nc), out
 
     #: row batches the trip tables cover (static layouts have at most this many)
@@ -1367,7 +1388,7 @@ void ${name}(params_t prm) {
         return tr, row
 
     def _classify_pairs(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
-                        oc_only=False, nodal=False):
+                        oc_only=False, nodal=False, mfma=False):
         f = graph_features(dgraphs)
         n_node, n_nz = f['n_node'], f['n_nz']
         deg_sorted = None      # (the two-stage variants' walk: made on demand)
@@ -1422,7 +1443,7 @@ void ${name}(params_t prm) {
         for k, v in enumerate(self.variants):
             if not len(rem):
                 break
-            if v in (GENERAL, STREAM) or (
+            if v in (GENERAL, STREAM, MFMA) or (
                     oc_only and not isinstance(v, OCVariant)):
                 continue
             if isinstance(v, OCVariant):
@@ -1505,6 +1526,16 @@ void ${name}(params_t prm) {
             fits &= slots[v.W][rem] <= v.S
             choice[rem[fits]] = k
             rem = rem[~fits]
+        if mfma and MFMA in self.variants and C == 1 and not oc_only:
+            # dense pairs of small graphs under a label-blind edge kernel: the
+            # dense-tile solver on the matrix cores (mgk_mfma.h) -- by the
+            # rule of the dense product of the on-the-fly variants (mgk_oc.h
+            # DENSE): adjacency matrices more than ~60 % full
+            dense = (n1 <= MFMA_MAX_NODES) & (n2 <= MFMA_MAX_NODES) & \
+                (23 * n_nz[ji] * n_nz[jj] > 9 * N * N)
+            choice[dense] = self.variants.index(MFMA)
+            gbytes = np.where(dense, np.maximum(f['image_bytes'][ji],
+                                                f['image_bytes'][jj]), gbytes)
         if np.any(choice < 0) and oc_only:
             raise NotOwnerComputes
         if np.any(choice < 0):
@@ -1585,14 +1616,14 @@ void ${name}(params_t prm) {
         return dgraphs, edge_kernel, C, fields
 
     def _partition(self, dgraphs, jobs, C, tab_bytes=0, gtab=False,
-                   oc_only=False, merge_map=None, nodal=False):
+                   oc_only=False, merge_map=None, nodal=False, mfma=False):
         """Host half of a layout: solver variant per job, launch order (by
         variant, then descending cost) and launch geometry.  No device."""
         jobs = np.ascontiguousarray(jobs)
         jobs_sorted = None             # (set by the native ordering)
         sel, (choice, cost, ntask, gbytes, NP, gbytes_oc) = \
             self._classify_classes(None, None, dgraphs, C, tab_bytes, gtab,
-                                   oc_only, jobs=jobs, nodal=nodal)
+                                   oc_only, jobs=jobs, nodal=nodal, mfma=mfma)
         # Launch order: by variant, then descending cost, then job index.
         # `choice` ... `gbytes_oc` are per class pair (or per job when sel is
         # None); the jobs are ordered by the rank of their class pair with one
@@ -1687,6 +1718,15 @@ void ${name}(params_t prm) {
                     threads=GENERAL_THREADS, per_wg=per_wg))
                 cursor += count
                 continue
+            if v == MFMA:
+                # one wave per pair; dynamic LDS: the two images
+                gcap = int(-(-gbytes[idx].max() // 16) * 16)
+                launches.append(dict(
+                    variant=v, k=k, offset=cursor, ucap=0, gcap=gcap,
+                    dynamic_lds=2 * gcap, count=count, grid=count,
+                    threads=64))
+                cursor += count
+                continue
             if v == STREAM:
                 # one workgroup per pair; scratch [x | r | p | Ap | diag]
                 # (N <= NP reals each); LDS: image of B | staged rows of p
@@ -1775,7 +1815,7 @@ void ${name}(params_t prm) {
         fallback = None
         for k in sorted(set(choice.tolist())):
             v = self.variants[k]
-            if k < 0 or v in (GENERAL, STREAM):
+            if k < 0 or v in (GENERAL, STREAM, MFMA):
                 continue
             while True:
                 idx = np.flatnonzero(choice == k)
@@ -1837,7 +1877,7 @@ void ${name}(params_t prm) {
                 self.tables)
         for k, v in todo:
             # (the entry point also carries the variant's occupancy target)
-            waves = None if v in (GENERAL, TABLES, STREAM) else (
+            waves = None if v in (GENERAL, TABLES, STREAM, MFMA) else (
                 self._oc_waves(v, C, ngrad) if ngrad and isinstance(
                     v, OCVariant) else self.waves_per_eu(v, C))
             key = (sig, tuple(v), waves, opts)
@@ -1846,17 +1886,26 @@ void ${name}(params_t prm) {
                     node_kernel, edge_kernel, p, dgraphs[0].node_t,
                     dgraphs[0].edge_t, [v], C, nodal,
                     tab=gtab if isinstance(v, OCVariant)
-                    else (tab and v not in (GENERAL, TABLES, STREAM)),
+                    else (tab and v not in (GENERAL, TABLES, STREAM, MFMA)),
                     weighted=dgraphs[0].weighted, ngrad=ngrad,
                     maximin=maximin and isinstance(v, OCVariant))
             out[k] = self._source_cache[key]
         return out
+
+    def _label_blind(self, edge_kernel):
+        """Is the edge microkernel (as the caller gave it, without the weight
+        wrapper) a constant -- separable in one term, what the dense-tile
+        MFMA solver takes (mgk_mfma.h)?  Float builds only."""
+        return (np.dtype(self.real) == np.float32
+                and os.environ.get('GD_MFMA', '1') != '0'
+                and getattr(edge_kernel, 'name', None) == 'Constant')
 
     def _frontend(self, graphs, node_kernel, edge_kernel, p, jobs, traits,
                   timer=None):
         """Host-only half of `prepare` (used by `precompile`): pack graphs,
         partition the jobs and render one translation unit per solver variant
         in use."""
+        edge_kernel_in = edge_kernel
         dgraphs, edge_kernel, C, fields = self._graphs_and_kernels(
             graphs, node_kernel, edge_kernel, traits, timer)
         arena = self._host_arena(dgraphs, fields)
@@ -1864,7 +1913,8 @@ void ${name}(params_t prm) {
         gtab = self._global_tables(arena)
         jobs, used, order_all, launches = self._partition(
             dgraphs, jobs, C, tab_bytes, gtab,
-            nodal=traits.nodal is not False)
+            nodal=traits.nodal is not False,
+            mfma=self._label_blind(edge_kernel_in))
         sources = self._sources(used, node_kernel, edge_kernel, p, dgraphs, C,
                                 traits.nodal is not False, tab_bytes > 0,
                                 gtab)
@@ -1880,7 +1930,7 @@ void ${name}(params_t prm) {
 
     def _layout(self, dgraphs, jobs, starts, C, fields=(None, None),
                 timer=None, ngrad=False, maximin=False, merge_map=None,
-                nodal=False):
+                nodal=False, mfma=False):
         """Everything of a plan that depends only on WHICH pairs of WHICH
         graphs are evaluated: variant per job, launch order and geometry, and
         the device copies of the job list, the order and `starts`.  Cached
@@ -1896,7 +1946,7 @@ void ${name}(params_t prm) {
             ('crc', zlib.crc32(jobs.view(np.uint8)))
         key = (_ids(dgraphs), len(jobs), jobs_id,
                zlib.crc32(starts.view(np.uint8)), C, fields, self.tables,
-               ngrad, maximin, bool(nodal),
+               ngrad, maximin, bool(nodal), bool(mfma),
                None if merge_map is None else tuple(sorted(merge_map.items())))
         hit = self._layouts.get(key)
         if hit is not None:
@@ -1919,7 +1969,7 @@ void ${name}(params_t prm) {
         tic('  solver variants and launch order')
         part = self._partition(dgraphs, jobs, C, lay.tab_bytes, lay.gtab,
                                oc_only=ngrad or maximin, merge_map=merge_map,
-                               nodal=nodal)
+                               nodal=nodal, mfma=mfma)
         jobs, lay.used, lay.order_host, lay.launches = part
         toc('  solver variants and launch order')
         tic('  job list to the device')
@@ -1967,7 +2017,8 @@ void ${name}(params_t prm) {
             graphs, node_kernel, edge_kernel, traits, timer, ngrad)
         lay = self._layout(dgraphs, jobs, starts, C, fields, timer, ngrad,
                            maximin is not None, merge_map,
-                           nodal=traits.nodal is not False)
+                           nodal=traits.nodal is not False,
+                           mfma=self._label_blind(edge_kernel_in))
         tab = lay.tab_bytes > 0
 
         tic('code generation')
@@ -2036,7 +2087,7 @@ void ${name}(params_t prm) {
             L['module'] = modules[L['k']]
             L['tab'] = L.get('tab', False) \
                 if isinstance(L['variant'], OCVariant) \
-                else tab and L['variant'] not in (GENERAL, STREAM)
+                else tab and L['variant'] not in (GENERAL, STREAM, MFMA)
             L['fn'] = fn = L['module'].function(
                 self.kernel_name(L['variant'], C, nodal, L['tab'], ngrad,
                                  maximin is not None))

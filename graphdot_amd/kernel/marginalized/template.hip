@@ -17,6 +17,7 @@
 #include <mgk_solver.h>
 #include <mgk_oc.h>
 #include <mgk_stream.h>
+#include <mgk_mfma.h>
 
 using namespace graphdot::numpy_type;
 using namespace graphdot::basekernel;

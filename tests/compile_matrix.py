@@ -96,7 +96,7 @@ def sources(select=None):
     solver family."""
     from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
     from graphdot_amd.kernel.marginalized._backend_hip import (
-        HIPBackend, OCVariant, GENERAL)
+        HIPBackend, OCVariant, GENERAL, MFMA, STREAM)
     for fname, graphs, knode, kedge in families():
         if select and fname not in select:
             continue
@@ -120,10 +120,19 @@ def sources(select=None):
                         if not (v.S == 0 and C == 2 and nodal)]
                 if not (ngrad or maximin):
                     todo += [(v, False) for v in two_stage + general]
+                # the streamed solver of large pairs: value solves
+                if C == 1 and not (ngrad or maximin):
+                    todo.append((STREAM, False))
+                # the dense-tile MFMA solver: float value solves under a
+                # label-blind edge kernel
+                if C == 1 and not (ngrad or maximin) and \
+                        backend._label_blind(kedge):
+                    todo.append((MFMA, False))
                 for v, tab in todo:
                     src = backend.render_source(
                         knode, ek, k.p, dgraphs[0].node_t, dgraphs[0].edge_t,
-                        [v], C, nodal and v != GENERAL, tab=tab,
+                        [v], C, nodal and v not in (GENERAL, MFMA, STREAM),
+                        tab=tab,
                         weighted=dgraphs[0].weighted,
                         ngrad=ngrad and isinstance(v, OCVariant),
                         maximin=maximin and isinstance(v, OCVariant))

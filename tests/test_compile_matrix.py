@@ -19,7 +19,8 @@ def test_every_solver_mode_compiles_for_every_microkernel_family():
     # solver families: static one-wave, dynamic multi-wave, on-the-fly,
     # two-stage, general -- in both gradient forms and with nodal outputs
     for needle in ('_L16', 'oc8_W4_S32', 'oc8_W16_S40', 'oc0_W4_S0',
-                   'mgk_f32_W1_S8', 'mgk_f64_W16_S16', '_general_', '_ngrad',
+                   'mgk_f32_W1_S8', 'mgk_f64_W16_S16', '_general_', '_mfma_', '_stream_',
+                   '_ngrad',
                    '_maximin', '_nodal', '_tab', '_C2'):
         assert any(needle in k for k in kernels), needle
     assert len(labels) > 500

@@ -1209,6 +1209,83 @@ def test_dense_product_with_kernels_undefined_on_empty_records(which):
                                       2e-3, 2e-5) <= 1.0
 
 
+@pytest.mark.parametrize('weighted', [True, False])
+def test_dense_tile_solver_on_the_matrix_cores(weighted, monkeypatch):
+    """Dense graphs of at most 32 nodes under a label-blind (`Constant`) edge
+    kernel take the dense-tile solver of mgk_mfma.h: the off-diagonal
+    operator as two 32 x 32 x 32 products of v_mfma_f32_32x32x2_f32 per CG
+    iteration, every vector in the accumulator layout (82 M pairs/s
+    against 4.2 M on the vector pipe).  Weighted and unweighted, sizes from 2
+    to 32 nodes incl. the row limit, self loops; values, X x Y in both orders,
+    nodal, lmin = 1, diag and nodal diag against the dense oracle, iteration
+    counts against the vector-pipe solvers (GD_MFMA=0); sparse graphs and
+    value + gradient calls keep their solvers."""
+    import networkx as nx
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend, MFMA
+    rng = np.random.default_rng(99)
+    gs = []
+    for n in (2, 5, 9, 16, 23, 31, 32):
+        g = nx.gnp_random_graph(n, 0.85, seed=int(rng.integers(1 << 30)))
+        for u in range(n - 1):
+            g.add_edge(u, u + 1)
+        if n == 9:
+            g.add_edge(3, 3)
+        for v in g.nodes:
+            g.nodes[v]['category'] = int(rng.integers(1, 4))
+            g.nodes[v]['radius'] = float(rng.choice([1.0, 1.5, 2.0]))
+        for e in g.edges:
+            g.edges[e]['w'] = float(rng.choice([0.5, 1.0, 2.0]))
+            g.edges[e]['length'] = float(rng.uniform(0.5, 2.5))
+        gs.append(Graph.from_networkx(g, weight='w' if weighted else None))
+    G = Graph.unify_datatype(gs)
+    knode = TensorProduct(category=KroneckerDelta(0.4),
+                          radius=SquareExponential(1.3))
+    kedge = Constant(0.8)
+    q = 0.05
+    be = HIPBackend(real=np.float32, record_iterations=True)
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=be)
+    K = k(G)
+    assert [L['variant'] for L in be.last_plan.launches] == [MFMA]
+    it = be.iterations(be.last_plan)
+    ref = oracle.gram(G, knode, kedge, q=q)
+    assert np.allclose(K, ref, rtol=1e-5), np.abs(K / ref - 1).max()
+    assert np.array_equal(K, K.T)
+    assert np.allclose(k(G[:3], G[3:]), ref[:3, 3:], rtol=1e-5)
+    assert np.allclose(k(G[3:], G[:3]), ref[3:, :3], rtol=1e-5)
+    sub = G[:5]
+    refn = oracle.gram(sub, knode, kedge, q=q, nodal=True)
+    Kn = k(sub, nodal=True)
+    assert [L['variant'] for L in be.last_plan.launches] == [MFMA]
+    assert np.allclose(Kn, refn, rtol=1e-5, atol=1e-5 * np.abs(refn).max())
+    assert np.allclose(k(G, lmin=1), oracle.gram(G, knode, kedge, q=q, lmin=1),
+                       rtol=1e-4)
+    assert np.allclose(k.diag(G), np.diag(ref), rtol=1e-5)
+    assert np.allclose(k.diag(sub, nodal=True), np.diag(refn), rtol=1e-5,
+                       atol=1e-5 * np.abs(refn).max())
+    # value + gradient: not this solver's; the values agree
+    K2, dK = k(G, eval_gradient=True)
+    assert MFMA not in [L['variant'] for L in be.last_plan.launches]
+    assert np.allclose(K2, ref, rtol=1e-5)
+    # the same system on the vector pipe: the same iteration counts
+    monkeypatch.setenv('GD_MFMA', '0')
+    bv = HIPBackend(real=np.float32, record_iterations=True)
+    kv = MarginalizedGraphKernel(knode, kedge, q=q, backend=bv)
+    Kv = kv(G)
+    assert MFMA not in [L['variant'] for L in bv.last_plan.launches]
+    assert np.allclose(K, Kv, rtol=2e-6)
+    assert abs(int(it.sum()) - int(bv.iterations(bv.last_plan).sum())) \
+        <= 0.05 * it.sum()
+    monkeypatch.delenv('GD_MFMA')
+    # sparse graphs keep the register-slot solvers
+    S = cases.config3_graphs(6, seed=2)
+    kn3, _, q3 = cases.config3_kernels()
+    bs = HIPBackend(real=np.float32)
+    ks = MarginalizedGraphKernel(kn3, Constant(1.0), q=q3, backend=bs)
+    Ks = ks(S)
+    assert MFMA not in [L['variant'] for L in bs.last_plan.launches]
+    assert np.allclose(Ks, oracle.gram(S, kn3, Constant(1.0), q=q3), rtol=1e-5)
+
+
 @pytest.mark.parametrize('real', [np.float32, np.float64])
 def test_dense_graphs_take_the_on_the_fly_solver(real):
     """Dense, from_ase-like molecular graphs (the reference's flagship preset,
