@@ -29,7 +29,7 @@
 //    update (general_solver re-summed U), and every vector pass is flat and
 //    coalesced.
 //
-// Scratch per workgroup: [x | r | p | Ap | diag], N reals each
+// Scratch per pair slot: [x | r | p | Ap | diag (| second solution)], N reals each
 // (prm.u_capacity reals).  Dynamic LDS: [image of B | A_ROWS rows of p per
 // group | one partial sum per lane], sized pair by pair.  The edge microkernel is evaluated per term and iteration, as the
 // reference does (marginalized_kernel.h:299-300,346): nnz_A nnz_B values do
@@ -44,7 +44,23 @@ namespace mgk {
 
 template<class real, int TPB, int C, class Graph, class NodeK, class EdgeK, class PStart>
 struct stream_solver {
-    static_assert(C == 1, "value solves; value + gradient pairs of this size take general_solver");
+    static_assert(C == 1 || C == 2, "C = 1: values; C = 2: values and the analytic gradient");
+    // C = 2: the two right-hand sides of the reference's compute_duo
+    // (marginalized_kernel.h:492-804), D q^2/q0^2 and p1 (x) p2, are solved ONE
+    // AFTER THE OTHER by the same iteration (as the static double solvers of
+    // mgk_oc.h do, SEQ): the stacked system's stopping rule rTr_0 + rTr_1 <
+    // (1e-10 * 2N)^2 (:769) as half the budget for the first system and what
+    // it left for the second.  Then the analytic derivative (:806-997): a flat
+    // pass over the rows for d/dp, d/dq and the node hyperparameters, and for
+    // the edge hyperparameters one more streamed walk over the terms -- the
+    // rows of the FIRST solution staged where the rows of p were, the
+    // microkernel's Jacobian in place of its value, weighted with the second
+    // solution at the row.
+    constexpr static int n_jac = PStart::jac_dims + 1 + NodeK::jac_dims + EdgeK::jac_dims;
+    constexpr static int off_q = PStart::jac_dims;
+    constexpr static int off_v = off_q + 1;
+    constexpr static int off_e = off_v + NodeK::jac_dims;
+    constexpr static int NVEC = C == 2 ? 6 : 5;      // vectors of N reals in the scratch
     using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
     using node_t = typename Graph::node_t;
     using edge_t = typename Graph::edge_t;
@@ -217,11 +233,12 @@ struct stream_solver {
             const real q = prm.q, q0 = prm.q0;
             const real inv1q2 = real(1) / ((real(1) - q) * (real(1) - q));
             const real bscale = q * q / (q0 * q0);
-            real *const X = scratch;
+            real *const X = scratch;                 // first solution ("YDq")
             real *const Rv = X + (size_t)N;
             real *const Pv = Rv + (size_t)N;
             real *const AP = Pv + (size_t)N;
             real *const DG = AP + (size_t)N;
+            [[maybe_unused]] real *const X2 = DG + (size_t)N;     // C = 2: second solution ("Yp")
 
             grp.barrier();       // the previous pair is done with LDS and scratch
             // this part's rows of A (and of every vector)
@@ -292,6 +309,10 @@ struct stream_solver {
             real *const st = stage + (size_t)g * A_ROWS * nB;
             real *const ys = stage + (size_t)G * A_ROWS * nB + (size_t)g * LB;
 
+            unsigned it_total = 0;
+            real rTr_first = 0;
+            for (int sys = 0; sys < C; ++sys) {
+            real *const Xs = sys == 0 ? X : X2;
             // ---- diagonal, right-hand side, start vectors ---------------------
             real rTz = 0;
             for (int i = ilo + tid; i < ihi; i += TPB) {
@@ -299,9 +320,10 @@ struct stream_solver {
                 const real dx = real(gA.degree[iA]) * real(gB.degree[iB]) * inv1q2;
                 const node_t vA = gA.node[iA], vB = gB.node[iB];
                 const real vx = real(prm.node_kernel(pick(sw, vA, vB), pick(sw, vB, vA)));
-                const real b = dx * bscale, mi = vx / dx;
+                const real b = sys == 0 ? dx * bscale : real(prm.p_start(vA)) * real(prm.p_start(vB));
+                const real mi = vx / dx;
                 DG[i] = dx / vx;
-                X[i] = 0;
+                Xs[i] = 0;
                 Rv[i] = b;
                 Pv[i] = b * mi;
                 rTz += b * b * mi;
@@ -313,8 +335,8 @@ struct stream_solver {
                 rTz = v[0];
             }
 
-            const real tol = prm.ftol * real(N);
-            const real tol2 = tol * tol;
+            const real tol = C == 2 ? real(1e-10) * real(2 * N) : prm.ftol * real(N);
+            const real tol2 = C == 2 ? (sys == 0 ? tol * tol * real(0.5) : tol * tol - rTr_first) : tol * tol;
             unsigned it = 0;
             for (; it < (unsigned)N && rTz != real(0); ++it) {
                 grp.barrier();       // p of this iteration is in memory, every part's rows of it
@@ -384,7 +406,7 @@ struct stream_solver {
                 const real alpha = rTz / pAp;
                 real rTr = 0, rTz_next = 0;
                 for (int i = ilo + tid; i < ihi; i += TPB) {
-                    X[i] += alpha * Pv[i];
+                    Xs[i] += alpha * Pv[i];
                     const real rv = Rv[i] - alpha * AP[i];
                     Rv[i] = rv;
                     rTr += rv * rv;
@@ -397,6 +419,7 @@ struct stream_solver {
                     rTr = v[0];
                     rTz_next = v[1];
                 }
+                if (sys == 0) rTr_first = rTr;
                 if (rTr < tol2) {
                     ++it;
                     break;
@@ -405,6 +428,9 @@ struct stream_solver {
                 for (int i = ilo + tid; i < ihi; i += TPB) Pv[i] = Rv[i] / DG[i] + beta * Pv[i];
                 rTz = rTz_next;
             }
+            it_total += it;
+            }       // sys
+            const unsigned it = C == 2 ? (it_total + 1u) / 2u : it_total;     // (iterations per system)
             __syncthreads();
             if (prm.iters != nullptr && tid == 0 && grp.part == 0) prm.iters[prm.order[t]] = it;
 
@@ -450,6 +476,104 @@ struct stream_solver {
                     } else {
                         prm.gramian[(size_t)I1 + (size_t)prm.nX * I2] = ksum;
                         if (mirror) prm.gramian[(size_t)I2 + (size_t)prm.nX * I1] = ksum;
+                    }
+                }
+            }
+
+            if constexpr (C == 2) {
+                // ---- analytic derivative (marginalized_kernel.h:831-994) --------
+                grp.barrier();       // both solutions complete, every part's rows
+                real jac[n_jac];
+#pragma unroll
+                for (int j = 0; j < n_jac; ++j) jac[j] = 0;
+                const real Q = real(1) / (real(1) - q), Q3 = Q * Q * Q;
+                for (int i = ilo + tid; i < ihi; i += TPB) {
+                    const int iA = i / nB, iB = i - iA * nB;
+                    const node_t vA = gA.node[iA], vB = gB.node[iB];
+                    const node_t v1 = pick(sw, vA, vB), v2 = pick(sw, vB, vA);
+                    const real p1 = prm.p_start(v1), p2 = prm.p_start(v2);
+                    const real dox = real(gA.degree[iA]) * real(gB.degree[iB]);
+                    const real dx = dox * inv1q2;
+                    const real v = prm.node_kernel(v1, v2);
+                    const real YDq = X[i], Yp = X2[i];
+                    auto dp1 = prm.p_start._j_a_c_o_b_i_a_n_(v1);
+                    auto dp2 = prm.p_start._j_a_c_o_b_i_a_n_(v2);
+                    auto dv = prm.node_kernel._j_a_c_o_b_i_a_n_(v1, v2);
+#pragma unroll
+                    for (int j = 0; j < PStart::jac_dims; ++j)
+                        jac[j] += (real(dp1[j]) * p2 + p1 * real(dp2[j])) * YDq;
+                    jac[off_q] += real(2) * Q * p1 * p2 * YDq - real(2) * Q3 * Yp * dox / v * YDq;
+#pragma unroll
+                    for (int j = 0; j < NodeK::jac_dims; ++j)
+                        jac[off_v + j] += dx * Yp * YDq / (v * v) * real(dv[j]);
+                }
+                if constexpr (EdgeK::jac_dims > 0) {
+                    // d/d(edge theta): sum over the terms of Yp[row] YDq[column]
+                    // dE_j -- the walk of the mat-vec with the rows of the first
+                    // solution staged
+                    for (int base = rlo; base < rhi; base += G) {
+                        const int iA = base + g;
+                        const bool row_ok = g < G && iA < rhi;
+                        const int rsA = row_ok ? (int)gA.rowptr[iA] : 0;
+                        const int dA = row_ok ? (int)gA.rowptr[iA + 1] - rsA : 0;
+                        int dmax = 0;
+                        for (int k = 0; k < G && base + k < rhi; ++k) {
+                            const int d = (int)gA.rowptr[base + k + 1] - (int)gA.rowptr[base + k];
+                            dmax = d > dmax ? d : dmax;
+                        }
+                        const int b0 = seg_b0;
+                        const int b1 = row_ok ? seg_b1 : b0;
+                        real acc[EdgeK::jac_dims];
+#pragma unroll
+                        for (int j = 0; j < EdgeK::jac_dims; ++j) acc[j] = 0;
+                        for (int a0 = 0; a0 < dmax; a0 += A_ROWS) {
+                            __syncthreads();
+                            const int nv = dA - a0 < A_ROWS ? dA - a0 : A_ROWS;
+                            edge_t eA[A_ROWS];
+#pragma unroll
+                            for (int u = 0; u < A_ROWS; ++u) {
+                                if (u < nv) {
+                                    eA[u] = gA.edge[rsA + a0 + u];
+                                    const unsigned jA = gA.nz[rsA + a0 + u].j;
+                                    if (lane_ok) st[u * nB + lb] = X[(size_t)jA * nB + lb];
+                                }
+                            }
+                            __syncthreads();
+                            for (int b = b0; b < b1; ++b) {
+                                const edge_t eB = gB.edge[b];
+                                const unsigned col = gB.nz[b].j;
+#pragma unroll
+                                for (int u = 0; u < A_ROWS; ++u) {
+                                    if (u < nv) {
+                                        auto de = prm.edge_kernel._j_a_c_o_b_i_a_n_(pick(sw, eA[u], eB), pick(sw, eB, eA[u]));
+                                        const real w = st[u * nB + col];
+#pragma unroll
+                                        for (int j = 0; j < EdgeK::jac_dims; ++j) acc[j] += w * real(de[j]);
+                                    }
+                                }
+                            }
+                        }
+                        if (seg_ok && row_ok) {
+                            const real Yp = X2[(size_t)iA * nB + iBs];
+#pragma unroll
+                            for (int j = 0; j < EdgeK::jac_dims; ++j) jac[off_e + j] += Yp * acc[j];
+                        }
+                    }
+                }
+                const size_t plane = (size_t)prm.nX * prm.nY;
+#pragma unroll
+                for (int j = 0; j < n_jac; ++j) {
+                    real v[1] = {block_reduce<real, W>::sum(jac[j], red)};
+                    grp.sum(v, red);
+                    if (tid == 0 && grp.part == 0) {
+                        if (flags & F_PACKED) {
+                            prm.gradient[(size_t)prm.order[t] * n_jac + j] = v[0];
+                        } else if (flags & F_DIAGONAL) {
+                            prm.gradient[(size_t)I1 + (size_t)prm.nX * j] = v[0];
+                        } else {
+                            prm.gradient[(size_t)I1 + (size_t)prm.nX * I2 + plane * j] = v[0];
+                            if (mirror) prm.gradient[(size_t)I2 + (size_t)prm.nX * I1 + plane * j] = v[0];
+                        }
                     }
                 }
             }

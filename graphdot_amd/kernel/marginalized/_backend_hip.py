@@ -1549,8 +1549,9 @@ void ${name}(params_t prm) {
                     'solver is disabled')
             left = choice < 0
             choice[left] = self.variants.index(GENERAL)
-            if C == 1 and STREAM in self.variants:
-                # value solves of large pairs: the streamed solver, if the
+            if STREAM in self.variants:
+                # large pairs (values, and values + analytic gradient as two
+                # sequential solves): the streamed solver, if the
                 # image of the smaller graph (of at most STREAM_THREADS nodes:
                 # one lane per node of it) fits the LDS beside the staged
                 # rows of p -- the rule of mgk_stream.h
@@ -1728,9 +1729,10 @@ void ${name}(params_t prm) {
                 cursor += count
                 continue
             if v == STREAM:
-                # one workgroup per pair; scratch [x | r | p | Ap | diag]
-                # (N <= NP reals each); LDS: image of B | staged rows of p
-                per_wg = int(5 * NP[idx].max())
+                # one to 256 workgroups per pair; scratch [x | r | p | Ap |
+                # diag (| second solution)] (N <= NP reals each); LDS: image
+                # of B | staged rows of p | partial sums
+                per_wg = int((6 if C == 2 else 5) * NP[idx].max())
                 dyn = int(-(-gbytes[idx].max() // 16) * 16)
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=per_wg, gcap=dyn,

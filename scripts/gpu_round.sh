@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun session: GPU tests, the bench lines, and the JIT cache back.
+# One gpurun session: GPU tests and the bench lines.
 # Usage (from the repo root, through gpurun):  bash scripts/gpu_round.sh [tests|bench|all|scale]
 set -u
 cd "$GRAFT_REPO_ROOT"
@@ -23,5 +23,6 @@ if [ "$what" = scale ] || [ "$what" = all ]; then
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/bench_2ranks.json 2> gpurun_out/bench_2ranks.err
   echo "bench 2 ranks rc=$?"; tail -c 700 gpurun_out/bench_2ranks.json; echo
 fi
-mkdir -p gpurun_out/jit && cp -n graphdot_amd/_jit_cache/*.hsaco gpurun_out/jit/ 2>/dev/null
-ls gpurun_out/jit | wc -l
+# (the JIT cache is pre-built by __graft_entry__.build() and travels with the
+# snapshot: nothing to bring back -- thousands of code objects would exceed
+# what gpurun merges into gpurun_out/)

@@ -120,8 +120,9 @@ def sources(select=None):
                         if not (v.S == 0 and C == 2 and nodal)]
                 if not (ngrad or maximin):
                     todo += [(v, False) for v in two_stage + general]
-                # the streamed solver of large pairs: value solves
-                if C == 1 and not (ngrad or maximin):
+                # the streamed solver of large pairs: values (any output
+                # mode) and graph-level value + gradient
+                if not (ngrad or maximin) and not (C == 2 and nodal):
                     todo.append((STREAM, False))
                 # the dense-tile MFMA solver: float value solves under a
                 # label-blind edge kernel

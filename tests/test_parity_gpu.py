@@ -578,9 +578,10 @@ def test_general_solver_matches_register_solver():
 
 def test_large_pair_leaves_the_resident_solvers(backend):
     """A 300 x 280 node pair (N = 84 000 product rows) exceeds every
-    register-resident variant: the value solve takes the streamed solver
-    (mgk_stream.h), value + gradient the general solver; both checked against
-    the C restatement of the reference PCG in fp64."""
+    register-resident variant: values and value + gradient take the streamed
+    solver (mgk_stream.h; the gradient as two sequential solves and the
+    streamed derivative); both checked against the C restatement of the
+    reference's PCG, compute_duo and derivative in fp64."""
     G = cases.config2_graphs(2, nmin=280, nmax=300, seed=9)
     knode, kedge, q = cases.config2b_kernels()
     mlgk = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
@@ -596,7 +597,7 @@ def test_large_pair_leaves_the_resident_solvers(backend):
     R2, dR = mlgk(G, eval_gradient=True)
     names = {backend.kernel_name(L['variant'], 2)
              for L in backend.last_plan.launches}
-    assert any('general' in n for n in names), names
+    assert any('stream' in n and n.endswith('C2') for n in names), names
     assert np.allclose(R2[i, j], ref_v, rtol=1e-5)
     assert elementwise_gradient_error(
         dR[i, j, :], ref_g[:, mlgk.active_theta_mask], 2e-3, 2e-5) <= 1
@@ -721,6 +722,25 @@ def test_streamed_solver_several_workgroups_per_pair(real, monkeypatch):
     # seven parts for a graph of ... rows each, and more parts than rows
     K7, *_ = evaluate(7)
     assert np.allclose(K7, K1, rtol=rt)
+    # value + gradient: two sequential solves and the streamed derivative,
+    # every plane of every pair against compute_duo + derivative restated in C
+    ref_v, ref_g, _ = oracle.TensorProductBatch(G, knode, kedge).run_gradient(
+        i, j, q=q, real='f64', omp=True)
+    for parts in (None, 1):
+        if parts is None:
+            monkeypatch.delenv('GD_STREAM_PARTS', raising=False)
+        else:
+            monkeypatch.setenv('GD_STREAM_PARTS', str(parts))
+        be = HIPBackend(real=real)
+        kg = MarginalizedGraphKernel(knode, kedge, q=q, backend=be, **kw)
+        Kg, dK = kg(G, eval_gradient=True)
+        (Lg,) = be.last_plan.launches
+        assert Lg['variant'] == STREAM and (Lg['parts'] > 1) == (parts is None)
+        assert np.allclose(Kg[i, j], ref_v, rtol=1e-8 if f64 else 1e-5)
+        assert np.array_equal(dK, dK.transpose(1, 0, 2))
+        assert elementwise_gradient_error(
+            dK[i, j, :], ref_g[:, np.asarray(kg.active_theta_mask)],
+            *((1e-6, 1e-9) if f64 else (2e-3, 2e-5))) <= 1
     tiny = Graph.unify_datatype(
         cases.protein_like_graphs(1, nmin=300, nmax=320, seed=44)
         + cases.tang2019_graphs(1, seed=5))
