@@ -1265,7 +1265,10 @@ def test_dense_tile_solver_on_the_matrix_cores(weighted, monkeypatch):
     be = HIPBackend(real=np.float32, record_iterations=True)
     k = MarginalizedGraphKernel(knode, kedge, q=q, backend=be)
     K = k(G)
-    assert [L['variant'] for L in be.last_plan.launches] == [MFMA]
+    # (the pair of two-node graphs is not "dense" by the rule -- one edge in a
+    # 4 x 4 product -- and keeps a register-slot solver)
+    taken = {L['variant']: L['count'] for L in be.last_plan.launches}
+    assert taken.get(MFMA, 0) >= 26, taken
     it = be.iterations(be.last_plan)
     ref = oracle.gram(G, knode, kedge, q=q)
     assert np.allclose(K, ref, rtol=1e-5), np.abs(K / ref - 1).max()
@@ -1275,7 +1278,7 @@ def test_dense_tile_solver_on_the_matrix_cores(weighted, monkeypatch):
     sub = G[:5]
     refn = oracle.gram(sub, knode, kedge, q=q, nodal=True)
     Kn = k(sub, nodal=True)
-    assert [L['variant'] for L in be.last_plan.launches] == [MFMA]
+    assert MFMA in [L['variant'] for L in be.last_plan.launches]
     assert np.allclose(Kn, refn, rtol=1e-5, atol=1e-5 * np.abs(refn).max())
     assert np.allclose(k(G, lmin=1), oracle.gram(G, knode, kedge, q=q, lmin=1),
                        rtol=1e-4)
