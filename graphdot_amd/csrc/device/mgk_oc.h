@@ -1405,7 +1405,18 @@ struct oc_solver {
                     // row sums: sum over the slots of a batch, flushed to the
                     // lane-private cell Y[batch][lane] at wave-uniform positions
                     [[maybe_unused]] creal ys[CW][(STATIC || FLY) ? R : 1];   // static layouts / FLY: the row sums
-                    if constexpr (STATIC || FLY) {
+                    // (static layouts of up to seven batches: every batch is
+                    // flushed below, or zeroed where the walk ends early --
+                    // zeroing all of them up here was 4 to 7 register moves in
+                    // every iteration and 36 bytes of scratch in two kernels:
+                    // 151.2 -> 159.1 M pairs/s on the double headline, the
+                    // two-batch kernel 0.108 -> 0.062 ms; the nine-batch kernel
+                    // lost, 0.035 -> 0.075 ms, and keeps the zeroing up here --
+                    // and so do the float kernels: 238.0 -> 231.0 M pairs/s,
+                    // value + gradient 98.2 -> 95.8 with it.
+                    // profiles/sessions.md r5_session15)
+                    constexpr bool YS_LATE = STATIC && R <= 7 && sizeof(real) == 8;
+                    if constexpr (FLY || (STATIC && !YS_LATE)) {
 #pragma unroll
                         for (int k = 0; k < R; ++k)
 #pragma unroll
@@ -1431,7 +1442,20 @@ struct oc_solver {
                         }
 #pragma unroll
                         for (int s0 = 0; s0 < S; s0 += GCH) {
-                            if (s0 >= n_slots) break;   // wave-uniform: no slots left
+                            if (s0 >= n_slots) {        // wave-uniform: no slots left
+                                if constexpr (YS_LATE) {
+                                    // (the batches that are not flushed in front
+                                    // of s0 -- a constant of the unrolled chunk --
+                                    // own no rows)
+#pragma unroll
+                                    for (int k = 0; k < R; ++k)
+                                        if (LAY::T.end[k] > s0) {
+#pragma unroll
+                                            for (int c = 0; c < CW; ++c) ys[c][k] = 0;
+                                        }
+                                }
+                                break;
+                            }
                             // (static layouts have no branch between the chunks:
                             // without the fence the scheduler merges their gathers
                             // -- 16 instead of 8 vectors in flight, and spills)
@@ -1607,7 +1631,20 @@ struct oc_solver {
 #pragma unroll
                     for (int k = 0; k < R; ++k)
 #pragma unroll
-                        for (int c = 0; c < CW; ++c) p[c][k] = z[c][k] + beta * p[c][k];
+                        for (int c = 0; c < CW; ++c) {
+                            // (double: the fused multiply-add written INTO p's
+                            // registers; the compiler accumulates into z's and
+                            // moves the result over, R v_mov_b64 per iteration:
+                            // 151.2 -> 155.2 M pairs/s alone, 159 -> 160 on top of
+                            // the late zeroing of the row sums)
+                            // (not the sequential value + gradient solves: there
+                            // the allocator splits p around the instruction, 2 R
+                            // moves instead of none)
+                            if constexpr (sizeof(creal) == 8 && STATIC && W == 1 && !SEQ)
+                                asm("v_fma_f64 %0, %1, %0, %2" : "+v"(p[c][k]) : "v"(beta), "v"(z[c][k]));
+                            else
+                                p[c][k] = z[c][k] + beta * p[c][k];
+                        }
                     // (W > 1: the barriers inside the reductions above are behind
                     // every wave's gathers of the old p)
                     publish(p);

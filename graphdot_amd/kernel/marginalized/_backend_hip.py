@@ -906,8 +906,14 @@ struct ${name}_t : ${name}_theta_t {
                      (8, 64, 4, 8): 4, (16, 32, 2, 8): 4, (16, 40, 2, 8): 4,
                      (16, 48, 3, 8): 4, (16, 64, 3, 8): 4},
         (True, 1): {('L', 16): 4, ('L', 16, 4): 4, ('L', 16, 4, 1): 3, ('L', 16, 4, 4): 3,
-                    ('L', 16, 4, 4, 1): 3, ('L', 16, 4, 4, 1, 1): 2,
-                    ('L', 16, 4, 4, 3, 1): 2, ('L', 16, 4, 4, 3, 1, 1): 2,
+                    # (round 5: the five-batch layouts at three waves -- with
+                    # the row sums zeroed late and p updated in place
+                    # (mgk_oc.h) their iteration is spill-free at 168
+                    # registers: (16,4,4,1,1) 0.864 -> 0.726 ms, (16,4,4,3,1)
+                    # 0.115 -> 0.105; the six-batch layout still reloads 12
+                    # values per iteration at three: 0.557 -> 0.849)
+                    ('L', 16, 4, 4, 1): 3, ('L', 16, 4, 4, 1, 1): 3,
+                    ('L', 16, 4, 4, 3, 1): 3, ('L', 16, 4, 4, 3, 1, 1): 2,
                     ('L', 16, 4, 4, 4, 1, 1, 1): 2,
                     ('L', 16, 4, 4, 4, 3, 1, 1, 1): 2,
                     ('L', 16, 4, 4, 4, 4, 1, 1, 1, 1): 2,
