@@ -1617,6 +1617,13 @@ struct oc_solver {
                             rTr += r[c][k] * r[c][k];
                             rTz_next += r[c][k] * z[c][k];
                         }
+                    if constexpr (SEQ && !SEQ_XLDS) {
+                        // (x += alpha p is done HERE: moved behind the update of
+                        // p by the scheduler it keeps the old p alive, a copy
+                        // per row -- as for xs above)
+#pragma unroll
+                        for (int k = 0; k < R; ++k) asm volatile("" : "+v"(xq[k]));
+                    }
                     sreal rTr_s = (sreal)rTr, rTz_next_s = (sreal)rTz_next;
                     sreduce::sum2(rTr_s, rTz_next_s, sred1);
                     if (rTr_s < tol2) {   // sqrt(rTr) < tol
@@ -1640,7 +1647,7 @@ struct oc_solver {
                             // (not the sequential value + gradient solves: there
                             // the allocator splits p around the instruction, 2 R
                             // moves instead of none)
-                            if constexpr (sizeof(creal) == 8 && STATIC && W == 1 && !SEQ)
+                            if constexpr (sizeof(creal) == 8 && STATIC && W == 1)
                                 asm("v_fma_f64 %0, %1, %0, %2" : "+v"(p[c][k]) : "v"(beta), "v"(z[c][k]));
                             else
                                 p[c][k] = z[c][k] + beta * p[c][k];
