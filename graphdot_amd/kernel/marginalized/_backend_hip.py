@@ -934,8 +934,13 @@ struct ${name}_t : ${name}_theta_t {
         # (static layouts: the sequential solves of mgk_oc.h SEQ, round 4 --
         # profiles/sessions.md r4_session2 / r4_session4: three waves only
         # where the loop stays free of scratch reloads, the three-batch kernel)
+        # (round 5: the four-batch sequential solver at three waves -- with
+        # the row sums zeroed late and p updated in place nothing is reloaded
+        # inside its iteration at 168 registers: 2.89 -> 2.65 ms; (16,4,4)
+        # loses at three, 0.175 -> 0.188, the five-batch kernel reloads three
+        # values per iteration there, 2.0 -> 2.86 ms)
         (True, 2): {('L', 16): 2, ('L', 16, 4): 2, ('L', 16, 4, 1): 3, ('L', 16, 4, 4): 2,
-                    ('L', 16, 4, 4, 1): 2, ('L', 16, 4, 4, 1, 1): 2,
+                    ('L', 16, 4, 4, 1): 3, ('L', 16, 4, 4, 1, 1): 2,
                     ('L', 16, 4, 4, 3, 1): 2, ('L', 16, 4, 4, 3, 1, 1): 2,
                     ('L', 16, 4, 4, 4, 1, 1, 1): 2,
                     ('L', 16, 4, 4, 4, 3, 1, 1, 1): 2,
