@@ -20,7 +20,7 @@ fi
 if [ "$what" = scale ] || [ "$what" = all ]; then
   # the multi-rank launch line of the driver, two ranks sharing this GPU
   # (gloo collective on host memory: correctness of the N > 1 path)
-  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/bench_2ranks.json 2> gpurun_out/bench_2ranks.err
+  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 bench.py --gpus 2 --steps 5 --warmup 2 --share-devices > gpurun_out/bench_2ranks.json 2> gpurun_out/bench_2ranks.err
   echo "bench 2 ranks rc=$?"; tail -c 700 gpurun_out/bench_2ranks.json; echo
 fi
 # (the JIT cache is pre-built by __graft_entry__.build() and travels with the
