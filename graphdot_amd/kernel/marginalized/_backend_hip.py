@@ -1123,12 +1123,14 @@ void ${name}(params_t prm) {
 
     # -- job partitioning ---------------------------------------------------------
     @staticmethod
-    def _dense_bytes(dgraphs):
+    def _dense_bytes(dgraphs, n):
         """LDS bytes of the two dense edge arrays of a pair (mgk_oc.h DENSE)
-        for the largest graph of the list: n x n records, and the record's
-        dword planes in rows of 32 words -- 0 if a graph has more than 32
-        nodes (the kernel's row stride) or the records are not whole words."""
-        n = int(graph_features(dgraphs)['n_node'].max()) if len(dgraphs) else 0
+        for graphs of at most n nodes -- the largest graph among the pairs of
+        the LAUNCH, not of the call: a call that mixes small dense graphs with
+        large ones keeps the dense product for the small ones --: n x n
+        records, and the record's dword planes in rows of 32 words; 0 if n
+        exceeds 32 nodes (the kernel's row stride) or the records are not
+        whole words."""
         esize = np.dtype(dgraphs[0].edge_t).itemsize if len(dgraphs) else 0
         if not 0 < n <= 32 or esize == 0 or esize % 4:
             return 0
@@ -1315,6 +1317,7 @@ void ${name}(params_t prm) {
         graph classes and looked up."""
         sel, out = self._classify_classes(ji, jj, dgraphs, C, tab_bytes, gtab,
                                           oc_only, nodal=nodal, mfma=mfma)
+        out = out[:6]      # (the seventh, the larger node count, is _partition's)
         return out if sel is None else tuple(a[sel.sel] for a in out)
 
     def _classify_classes(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
@@ -1580,7 +1583,7 @@ void ${name}(params_t prm) {
                 choice[fits] = self.variants.index(STREAM)
                 # (for these pairs `gbytes` is the dynamic LDS of the pair)
                 gbytes = np.where(fits, sb, gbytes)
-        return choice, cost, ntask, gbytes, NP, gbytes_oc
+        return choice, cost, ntask, gbytes, NP, gbytes_oc, np.maximum(n1, n2)
 
     # -- the three phases -----------------------------------------------------------
     def _graphs_and_kernels(self, graphs, node_kernel, edge_kernel, traits,
@@ -1633,7 +1636,7 @@ void ${name}(params_t prm) {
         variant, then descending cost) and launch geometry.  No device."""
         jobs = np.ascontiguousarray(jobs)
         jobs_sorted = None             # (set by the native ordering)
-        sel, (choice, cost, ntask, gbytes, NP, gbytes_oc) = \
+        sel, (choice, cost, ntask, gbytes, NP, gbytes_oc, nmax) = \
             self._classify_classes(None, None, dgraphs, C, tab_bytes, gtab,
                                    oc_only, jobs=jobs, nodal=nodal, mfma=mfma)
         # Launch order: by variant, then descending cost, then job index.
@@ -1766,7 +1769,7 @@ void ${name}(params_t prm) {
                     # of both graphs (mgk_oc.h DENSE), sized for the largest
                     # graph of the call -- when they fit (F_DENSE tells the
                     # kernel that they are there)
-                    extra = self._dense_bytes(dgraphs)
+                    extra = self._dense_bytes(dgraphs, int(nmax[idx].max()))
                     if extra and dyn + extra + 4096 <= LDS_LIMIT:
                         # (+ 4 cells of p: the last trip of a row of the
                         # dense product reads up to three cells past it)
