@@ -1124,6 +1124,28 @@ def test_double_build_on_systems_of_a_few_rows():
         assert np.isfinite(dK).all()
 
 
+def test_dense_product_is_decided_per_launch():
+    """A call that mixes small dense graphs with a large one keeps the dense
+    product for the small ones: the dense arrays are sized from the pairs of
+    the on-the-fly LAUNCH (the larger pairs leave for the streamed solver),
+    not from the largest graph of the call."""
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    small = cases.tang2019_graphs(6, seed=9)
+    big = cases.protein_like_graphs(n_graphs=1, nmin=160, nmax=170, seed=5,
+                                    cutoff=2.7)
+    knode, kedge, q = cases.tang2019_kernels()
+    G = small + big            # (the same attributes: element, length)
+    assert max(len(g.nodes) for g in small) <= 32 < len(big[0].nodes)
+    be = HIPBackend(real=np.float32)
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=be)
+    K = k(G)
+    fly = [L for L in be.last_plan.launches
+           if getattr(L['variant'], 'S', None) == 0]
+    assert fly and any(L.get('dense') for L in fly), be.last_plan.launches
+    ref = oracle.gram(G, knode, kedge, q=q)
+    assert np.allclose(K, ref, rtol=1e-5), np.abs(K / ref - 1).max()
+
+
 @pytest.mark.parametrize('sizes', [(5, 8, 28, 29, 30, 31, 32),
                                    (4, 17, 24, 32, 33)])
 def test_dense_product_at_the_row_limit(sizes):
