@@ -42,6 +42,47 @@ Variant = namedtuple('Variant', 'W S R')
 OCVariant = namedtuple('OCVariant', 'W S R D L', defaults=(None,))
 
 
+#: measured efficiency of M workgroups on one pair of the streamed solver
+#: against M times one workgroup (MI355X, protein-like graphs of 150-600
+#: atoms, float; profiles/sessions.md r5_session18 and DESIGN.md section 4c:
+#: three grid-wide barriers per iteration, B staged by every part)
+STREAM_PART_EFFICIENCY = ((1, 1.0), (2, 0.74), (4, 0.58), (8, 0.53),
+                          (16, 0.50), (32, 0.49), (64, 0.46), (128, 0.35),
+                          (256, 0.26))
+
+
+def stream_parts(costs, count, resident, queued):
+    """Workgroups per pair (M) of a streamed launch: the M with the smallest
+    estimated time for the launch's pairs -- `costs`, largest first, in
+    arbitrary units.  One workgroup per pair (`queued` workgroups, the
+    hardware hands the next pair to the first free compute unit) takes
+    max(largest pair, sum / resident); M workgroups per pair form
+    resident // M groups that walk the pairs round-robin, a group's time is
+    the sum of its pairs over M x efficiency(M).  136 pairs of 16 graphs:
+    M = 1 105.8 ms (the largest pair on one workgroup, 120 compute units
+    idle), 2 / 4 / 8 / 16: 84.8 / 73.7 / 65.8 / 65.7 ms; 528 pairs: 140.9 ms
+    at M = 1 against 191-198 at 2 ... 16."""
+    if costs is None or len(costs) == 0:
+        return max(1, min(resident // max(count, 1), STREAM_MAX_PARTS))
+    c = np.asarray(costs, dtype=np.float64)
+    best, best_t = 1, max(c[0], c.sum() / max(1, min(resident, queued)))
+    table = dict(STREAM_PART_EFFICIENCY)
+    ms, es = zip(*STREAM_PART_EFFICIENCY)
+    # (powers of two, and what gives every pair a group of its own)
+    own = min(resident // max(len(c), 1), STREAM_MAX_PARTS)
+    for M in sorted(set(ms[1:]) | ({own} if own > 1 else set())):
+        if M > min(resident, STREAM_MAX_PARTS):
+            break
+        eff = table.get(M) or float(np.interp(np.log2(M), np.log2(ms), es))
+        groups = max(1, resident // M)
+        pad = -len(c) % groups
+        load = np.concatenate((c, np.zeros(pad))).reshape(-1, groups).sum(0)
+        t = load.max() / (M * eff)
+        if t < 0.95 * best_t:        # (a larger M must earn its barriers)
+            best, best_t = M, t
+    return best
+
+
 def OCStatic(*L, D=4):
     """One-wave owner-computes variant with the static layout L."""
     return OCVariant(1, int(sum(L)), len(L), D, tuple(int(x) for x in L))
@@ -1748,9 +1789,13 @@ void ${name}(params_t prm) {
                 # of B | staged rows of p | partial sums
                 per_wg = int((6 if C == 2 else 5) * NP[idx].max())
                 dyn = int(-(-gbytes[idx].max() // 16) * 16)
+                # (the pairs' costs in launch order, largest first: `prepare`
+                # picks the workgroups per pair from them)
+                costs = np.sort(np.repeat(cost[idx], members[idx])
+                                .astype(np.float64))[::-1]
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=per_wg, gcap=dyn,
-                    dynamic_lds=dyn, count=count,
+                    dynamic_lds=dyn, count=count, costs=costs,
                     grid=None, threads=STREAM_THREADS, per_wg=per_wg))
                 cursor += count
                 continue
@@ -2123,7 +2168,8 @@ void ${name}(params_t prm) {
                     2048 // L['threads']))
                 resident = self.props.compute_units * per_cu
                 parts = int(os.environ.get('GD_STREAM_PARTS', 0)) or \
-                    max(1, min(resident // L['count'], STREAM_MAX_PARTS))
+                    stream_parts(L.get('costs'), L['count'], resident,
+                                 2 * self.props.compute_units)
                 parts = max(1, min(parts, resident))
                 slots = int(min(L['count'], max(1, resident // parts)))
                 if parts == 1:
