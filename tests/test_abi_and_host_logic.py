@@ -710,3 +710,28 @@ def test_a_launch_is_sized_for_two_maxima_and_must_still_fit_the_lds():
         # calls that only the owner-computes solvers serve cannot fall back
         with pytest.raises(NotOwnerComputes):
             be._fit_launches_into_lds(choice, C, vec, vec, img, img, 0, True)
+
+
+def test_workgroups_per_pair_of_the_streamed_solver():
+    """`stream_parts`: one pair takes the whole chip, a list too long for a
+    group per pair keeps one workgroup per pair (the hardware queue balances
+    it), in between the pairs' costs decide -- a few groups that walk
+    several pairs each beat one workgroup per pair when the largest pair
+    would otherwise be the step."""
+    from graphdot_amd.kernel.marginalized._backend_hip import (
+        stream_parts, STREAM_MAX_PARTS)
+    assert stream_parts(np.array([7.0]), 1, 256, 512) == min(256, STREAM_MAX_PARTS)
+    assert stream_parts(None, 3, 256, 512) == 85         # (no costs: the first rule)
+    rng = np.random.default_rng(0)
+    n = rng.integers(150, 600, size=32)
+    i, j = np.triu_indices(32)
+    c = np.sort((n[i] * n[j]).astype(float))[::-1]
+    assert stream_parts(c, len(c), 256, 512) == 1        # 528 pairs
+    i, j = np.triu_indices(16)
+    c = np.sort((n[i] * n[j]).astype(float))[::-1]
+    m = stream_parts(c, len(c), 256, 512)                # 136 pairs
+    assert 8 <= m <= 32, m
+    # equal pairs, exactly one per compute unit: nothing to gain from sharing
+    assert stream_parts(np.ones(256), 256, 256, 512) == 1
+    # never more workgroups than the chip holds
+    assert stream_parts(np.array([5.0, 4.0]), 2, 64, 128) <= 64
