@@ -65,10 +65,26 @@ struct stream_solver {
     using node_t = typename Graph::node_t;
     using edge_t = typename Graph::edge_t;
     constexpr static int W = TPB / 64;
-#ifndef GD_STREAM_ROWS
-#define GD_STREAM_ROWS 4
+    // rows of p staged per pass and group.  A pass costs every lane the reads
+    // of its segment's edge records and columns whatever the number of staged
+    // rows: 2 / 4 / 8 / 12 rows: 173 / 136 / 122 / 127 ms on the 528 pairs of
+    // bench.py --config large in float (12: the records of the staged rows
+    // spill).  Measured beside it and NOT kept (profiles/sessions.md
+    // r5_session20): the microkernel on two staged rows at once with the
+    // packed float instructions -- half the vector instructions per term, the
+    // same time --, and the loads of the next pass's rows issued in front of
+    // the products of this one, two stage buffers, one barrier per pass --
+    // 137 against 136 ms: the passes wait neither for the vector pipe nor for
+    // those loads.  What did pay: the staged values of a COLUMN side by side
+    // (`load_staged`: one 16-byte read per four terms instead of four gathers)
+    // -- 122 -> 100.6 ms, 136 pairs 63.7 -> 43.7 ms, one pair 1.13 -> 0.87 ms,
+    // value + gradient of 36 pairs 60.5 -> 40.6 ms.  Double: 8 rows too (316
+    // -> 303 ms on the 528 pairs, although more of B's images then stay in L2).
+#ifdef GD_STREAM_ROWS
+    constexpr static int A_ROWS = GD_STREAM_ROWS;
+#else
+    constexpr static int A_ROWS = 8;
 #endif
-    constexpr static int A_ROWS = GD_STREAM_ROWS;     // rows of p staged per pass and group
 
 #ifndef GD_STREAM_CAP
 #define GD_STREAM_CAP 16
@@ -88,6 +104,18 @@ struct stream_solver {
     // bytes of the contiguous image [degree .. perm] of a graph, in 16-byte units
     __device__ static __forceinline__ unsigned image_words(graph_header_t const &h) {
         return (h.perm + 2u * (unsigned)h.n_node - h.degree + 15u) / 16u;
+    }
+
+    // the A_ROWS staged values of one column of p (A_ROWS reals, 16-byte
+    // aligned: the stage starts on a 16-byte boundary and a column is 32 bytes)
+    static_assert((A_ROWS * sizeof(real)) % 16 == 0, "a staged column is read in 16-byte pieces");
+    __device__ static __forceinline__ void load_staged(real const *src, real (&v)[A_ROWS]) {
+        typedef unsigned v4 __attribute__((ext_vector_type(4)));
+        constexpr int NQ = A_ROWS * sizeof(real) / 16;
+        v4 q[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) q[k] = reinterpret_cast<v4 const *>(src)[k];
+        __builtin_memcpy(v, q, sizeof(v));
     }
 
     template<class V> __device__ static __forceinline__ V pick(bool second, V const &a, V const &b) {
@@ -210,9 +238,9 @@ struct stream_solver {
             // region by the same rule, pair by pair
             const unsigned w1 = image_words(h1), w2 = image_words(h2);
             const bool ok1 = h1.n_node <= TPB, ok2 = h2.n_node <= TPB;
-            const bool sw = ok1 && (!ok2 || w1 < w2);     // B = graph 1
-            const graph_header_t hA = sw ? h2 : h1, hB = sw ? h1 : h2;
-            const unsigned wB = sw ? w1 : w2;
+            const bool sw_ = ok1 && (!ok2 || w1 < w2);     // B = graph 1
+            const graph_header_t hA = sw_ ? h2 : h1, hB = sw_ ? h1 : h2;
+            const unsigned wB = sw_ ? w1 : w2;
             // Does B's image fit the LDS beside the staged rows (at their
             // largest: A_ROWS + 1 reals per lane)?  If not -- the double
             // build's largest graphs, 16-byte edge records -- B is read
@@ -221,8 +249,14 @@ struct stream_solver {
             // instantiated for either case (`in_lds`): a view of B through
             // one pointer type would turn every read into a flat load.
             const bool fits = wB * 16u + (unsigned)((A_ROWS + 1) * TPB * sizeof(real)) <= LDS_BUDGET;
-            auto solve_pair = [&](auto in_lds) {
+            auto solve_pair = [&](auto in_lds, auto swapped) {
             constexpr bool B_IN_LDS = decltype(in_lds)::value;
+            // (which graph is B, at compile time: as a run-time flag the
+            // argument order of every microkernel call was two selects per
+            // leaf of both records, per term -- four of the ten vector
+            // instructions of a term of the benchmark's edge kernel; 140.9 ->
+            // 136.0 ms on the 528 pairs of bench.py --config large)
+            constexpr bool sw = decltype(swapped)::value;
             const Graph gA(prm.arena, hA);
             const Graph gB = [&] {
                 if constexpr (B_IN_LDS) return Graph(lG - hB.degree, hB);
@@ -365,18 +399,23 @@ struct stream_solver {
                             if (u < nv) {
                                 eA[u] = gA.edge[rsA + a0 + u];
                                 const unsigned jA = gA.nz[rsA + a0 + u].j;
-                                if (lane_ok) st[u * nB + lb] = Pv[(size_t)jA * nB + lb];
+                                if (lane_ok) st[lb * A_ROWS + u] = Pv[(size_t)jA * nB + lb];
                             }
                         }
                         __syncthreads();
                         for (int b = b0; b < b1; ++b) {
                             const edge_t eB = gB.edge[b];
                             const unsigned col = gB.nz[b].j;
+                            // (the A_ROWS staged values of a column lie side by
+                            // side: one or two 16-byte reads instead of A_ROWS
+                            // gathers of 4 or 8 bytes)
+                            real pv[A_ROWS];
+                            load_staged(st + (size_t)col * A_ROWS, pv);
 #pragma unroll
                             for (int u = 0; u < A_ROWS; ++u) {
                                 if (u < nv) {
                                     const real e = real(prm.edge_kernel(pick(sw, eA[u], eB), pick(sw, eB, eA[u])));
-                                    acc += e * st[u * nB + col];
+                                    acc += e * pv[u];
                                 }
                             }
                         }
@@ -535,18 +574,20 @@ struct stream_solver {
                                 if (u < nv) {
                                     eA[u] = gA.edge[rsA + a0 + u];
                                     const unsigned jA = gA.nz[rsA + a0 + u].j;
-                                    if (lane_ok) st[u * nB + lb] = X[(size_t)jA * nB + lb];
+                                    if (lane_ok) st[lb * A_ROWS + u] = X[(size_t)jA * nB + lb];
                                 }
                             }
                             __syncthreads();
                             for (int b = b0; b < b1; ++b) {
                                 const edge_t eB = gB.edge[b];
                                 const unsigned col = gB.nz[b].j;
+                                real pv[A_ROWS];
+                                load_staged(st + (size_t)col * A_ROWS, pv);
 #pragma unroll
                                 for (int u = 0; u < A_ROWS; ++u) {
                                     if (u < nv) {
                                         auto de = prm.edge_kernel._j_a_c_o_b_i_a_n_(pick(sw, eA[u], eB), pick(sw, eB, eA[u]));
-                                        const real w = st[u * nB + col];
+                                        const real w = pv[u];
 #pragma unroll
                                         for (int j = 0; j < EdgeK::jac_dims; ++j) acc[j] += w * real(de[j]);
                                     }
@@ -578,8 +619,13 @@ struct stream_solver {
                 }
             }
             };      // solve_pair
-            if (fits) solve_pair(std::true_type{});
-            else solve_pair(std::false_type{});
+            if (fits) {
+                if (sw_) solve_pair(std::true_type{}, std::true_type{});
+                else solve_pair(std::true_type{}, std::false_type{});
+            } else {
+                if (sw_) solve_pair(std::false_type{}, std::true_type{});
+                else solve_pair(std::false_type{}, std::false_type{});
+            }
         }
     }
 };

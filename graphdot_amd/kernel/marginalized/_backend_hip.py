@@ -156,7 +156,7 @@ MFMA_MAX_NODES = 32
 STREAM = Variant(-2, 0, 0)
 STREAM_THREADS = 1024
 #: rows of p staged per pass and row group (mgk_stream.h A_ROWS)
-STREAM_ROWS = 4
+STREAM_ROWS = {4: 8, 8: 8}       # by the size of a real
 #: neighbours per lane segment of the LDS-resident graph (mgk_stream.h SEG_CAP)
 STREAM_CAP = 16
 #: workgroups that may share one pair of the streamed solver
@@ -1100,7 +1100,8 @@ void ${name}(params_t prm) {
     solver::run(prm, lds, dyn_lds, prm.scratch);
 }
 ''').render(threads=STREAM_THREADS, name=self.kernel_name(v, C), C=C,
-            rows=STREAM_ROWS, cap=STREAM_CAP, budget=STREAM_LDS_BUDGET)
+            rows=STREAM_ROWS[np.dtype(self.real).itemsize], cap=STREAM_CAP,
+            budget=STREAM_LDS_BUDGET)
         threads = 64 * v.W * (WPB1 if v.W == 1 else 1)
         return Template(r'''
 extern "C" __global__ __launch_bounds__(${threads})
@@ -1212,11 +1213,11 @@ void ${name}(params_t prm) {
         LB = (-(-nV // 64) * 64).clip(max=STREAM_THREADS)
         G = STREAM_THREADS // LB
         rs = np.dtype(self.real).itemsize
-        stage = (STREAM_ROWS * G * nB + G * LB) * rs
+        stage = (STREAM_ROWS[rs] * G * nB + G * LB) * rs
         image = np.where(first, w1, w2) * 16
         # (an image that does not fit beside the staged rows at their largest
         # stays in L2: the pair's body is instantiated for that case too)
-        fits = image + (STREAM_ROWS + 1) * STREAM_THREADS * rs \
+        fits = image + (STREAM_ROWS[rs] + 1) * STREAM_THREADS * rs \
             <= STREAM_LDS_BUDGET
         out = np.where(fits, image, 0) + -(-stage // 16) * 16
         return np.where(ok1 | ok2, out, np.iinfo(np.int64).max // 4)
