@@ -1792,8 +1792,9 @@ void ${name}(params_t prm) {
                 dyn = int(-(-gbytes[idx].max() // 16) * 16)
                 # (the pairs' costs in launch order, largest first: `prepare`
                 # picks the workgroups per pair from them)
-                costs = np.sort(np.repeat(cost[idx], members[idx])
-                                .astype(np.float64))[::-1]
+                # (a tuple: launch descriptions are compared as values)
+                costs = tuple(np.sort(np.repeat(cost[idx], members[idx])
+                                      .astype(np.float64))[::-1].tolist())
                 launches.append(dict(
                     variant=v, k=k, offset=cursor, ucap=per_wg, gcap=dyn,
                     dynamic_lds=dyn, count=count, costs=costs,
