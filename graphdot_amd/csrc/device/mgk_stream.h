@@ -392,7 +392,11 @@ struct stream_solver {
                     __syncthreads();     // the partial sums of the step before are read
                     for (int a0 = 0; a0 < dmax; a0 += A_ROWS) {
                         __syncthreads();     // the rows staged before are consumed
-                        const int nv = dA - a0 < A_ROWS ? dA - a0 : A_ROWS;   // (wave-uniform; may be <= 0)
+                        // (wave-uniform -- the lanes of a wave share their row of A --
+                        // and said so: the tests `u < nv` below are scalar branches
+                        // then, not an exec mask saved and restored around every term;
+                        // may be <= 0)
+                        const int nv = __builtin_amdgcn_readfirstlane(dA - a0 < A_ROWS ? dA - a0 : A_ROWS);
                         edge_t eA[A_ROWS];
 #pragma unroll
                         for (int u = 0; u < A_ROWS; ++u) {
@@ -403,22 +407,45 @@ struct stream_solver {
                             }
                         }
                         __syncthreads();
-                        for (int b = b0; b < b1; ++b) {
-                            const edge_t eB = gB.edge[b];
-                            const unsigned col = gB.nz[b].j;
-                            // (the A_ROWS staged values of a column lie side by
-                            // side: one or two 16-byte reads instead of A_ROWS
-                            // gathers of 4 or 8 bytes)
-                            real pv[A_ROWS];
-                            load_staged(st + (size_t)col * A_ROWS, pv);
+                        // A pass of nv rows: the terms of its FULL groups of four rows
+                        // are computed without tests between them -- four independent
+                        // chains the scheduler interleaves (and packs: the weights and
+                        // staged values as v_pk_mul / v_pk_fma_f32, B's weight factored
+                        // out of the sum) --, the rows of the last, partial group behind
+                        // scalar tests.  (All eight rows behind tests: 100.4 ms on the
+                        // 528 pairs of bench.py --config large; full passes of eight
+                        // without: 92.0.)
+                        auto pass = [&](auto full_groups) {
+                            constexpr int NF = 4 * decltype(full_groups)::value;    // rows without a test
+                            for (int b = b0; b < b1; ++b) {
+                                const edge_t eB = gB.edge[b];
+                                const unsigned col = gB.nz[b].j;
+                                // (the A_ROWS staged values of a column lie side by
+                                // side: one or two 16-byte reads instead of A_ROWS
+                                // gathers of 4 or 8 bytes)
+                                real pv[A_ROWS];
+                                load_staged(st + (size_t)col * A_ROWS, pv);
+                                if constexpr (NF > 0) {
+                                    real part[NF];
 #pragma unroll
-                            for (int u = 0; u < A_ROWS; ++u) {
-                                if (u < nv) {
-                                    const real e = real(prm.edge_kernel(pick(sw, eA[u], eB), pick(sw, eB, eA[u])));
-                                    acc += e * pv[u];
+                                    for (int u = 0; u < NF; ++u)
+                                        part[u] = real(prm.edge_kernel(pick(sw, eA[u], eB), pick(sw, eB, eA[u]))) * pv[u];
+#pragma unroll
+                                    for (int u = 0; u < NF; ++u) acc += part[u];
+                                }
+#pragma unroll
+                                for (int u = NF; u < A_ROWS && u < NF + 4; ++u) {
+                                    if (u < nv) {
+                                        const real e = real(prm.edge_kernel(pick(sw, eA[u], eB), pick(sw, eB, eA[u])));
+                                        acc += e * pv[u];
+                                    }
                                 }
                             }
-                        }
+                        };
+                        static_assert(A_ROWS == 4 || A_ROWS == 8, "passes of one or two groups of four rows");
+                        if (nv >= 8 && A_ROWS == 8) pass(std::integral_constant<int, A_ROWS == 8 ? 2 : 1>{});
+                        else if (nv >= 4) pass(std::integral_constant<int, 1>{});
+                        else pass(std::integral_constant<int, 0>{});
                     }
                     // partial sums of the segments -> their nodes
                     if (seg_ok) ys[lb] = acc;
@@ -567,7 +594,7 @@ struct stream_solver {
                         for (int j = 0; j < EdgeK::jac_dims; ++j) acc[j] = 0;
                         for (int a0 = 0; a0 < dmax; a0 += A_ROWS) {
                             __syncthreads();
-                            const int nv = dA - a0 < A_ROWS ? dA - a0 : A_ROWS;
+                            const int nv = __builtin_amdgcn_readfirstlane(dA - a0 < A_ROWS ? dA - a0 : A_ROWS);
                             edge_t eA[A_ROWS];
 #pragma unroll
                             for (int u = 0; u < A_ROWS; ++u) {
