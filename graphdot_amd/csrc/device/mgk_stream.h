@@ -605,21 +605,28 @@ struct stream_solver {
                                 }
                             }
                             __syncthreads();
-                            for (int b = b0; b < b1; ++b) {
-                                const edge_t eB = gB.edge[b];
-                                const unsigned col = gB.nz[b].j;
-                                real pv[A_ROWS];
-                                load_staged(st + (size_t)col * A_ROWS, pv);
+                            // (full groups of four rows without tests, as in the mat-vec)
+                            auto pass = [&](auto full_groups) {
+                                constexpr int NF = 4 * decltype(full_groups)::value;
+                                for (int b = b0; b < b1; ++b) {
+                                    const edge_t eB = gB.edge[b];
+                                    const unsigned col = gB.nz[b].j;
+                                    real pv[A_ROWS];
+                                    load_staged(st + (size_t)col * A_ROWS, pv);
 #pragma unroll
-                                for (int u = 0; u < A_ROWS; ++u) {
-                                    if (u < nv) {
-                                        auto de = prm.edge_kernel._j_a_c_o_b_i_a_n_(pick(sw, eA[u], eB), pick(sw, eB, eA[u]));
-                                        const real w = pv[u];
+                                    for (int u = 0; u < A_ROWS && u < NF + 4; ++u) {
+                                        if (u < NF || u < nv) {
+                                            auto de = prm.edge_kernel._j_a_c_o_b_i_a_n_(pick(sw, eA[u], eB), pick(sw, eB, eA[u]));
+                                            const real w = pv[u];
 #pragma unroll
-                                        for (int j = 0; j < EdgeK::jac_dims; ++j) acc[j] += w * real(de[j]);
+                                            for (int j = 0; j < EdgeK::jac_dims; ++j) acc[j] += w * real(de[j]);
+                                        }
                                     }
                                 }
-                            }
+                            };
+                            if (nv >= 8 && A_ROWS == 8) pass(std::integral_constant<int, A_ROWS == 8 ? 2 : 1>{});
+                            else if (nv >= 4) pass(std::integral_constant<int, 1>{});
+                            else pass(std::integral_constant<int, 0>{});
                         }
                         if (seg_ok && row_ok) {
                             const real Yp = X2[(size_t)iA * nB + iBs];

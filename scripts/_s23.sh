@@ -5,8 +5,5 @@ run() { name=$1; shift; timeout 600 python bench.py --config large --steps 4 --w
   echo -n "[$(date +%T)] $name rc=$? "; python -c "
 import json; d=json.loads(open('gpurun_out/s23_$name.json').read().strip().splitlines()[-1])
 print(d['config'].get('pairs'), 'pairs', round(d['ms_per_step'],3), 'ms/step', [(k['kernel'][-14:],k['pairs'],k['grid'],round(k['isolated_ms'],3)) for k in d['kernels']])" 2>&1 | tail -1; }
-run l32 --graphs 32
-run l16 --graphs 16
-run l1 --graphs 1
 run l8g --graphs 8 --gradient
-run l32_f64 --graphs 32 --dtype f64
+run l8g_f64 --graphs 8 --gradient --dtype f64
