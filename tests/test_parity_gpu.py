@@ -2048,6 +2048,34 @@ def test_mixed_degree_structures_all_pairs(real):
         assert np.allclose(kc(graphs)[i, j], conv, rtol=1e-9)
 
 
+def test_double_scalars_build_follows_the_restatement():
+    """-DGD_OC_FSCAL=0: the double solver with DOUBLE scalars (pAp, rTr, rTz,
+    alpha, beta -- float by default since round 4, mgk_oc.h FSCAL: same
+    stopping rule, same accuracy class at the default ftol, iterates no longer
+    the restatement's to the last bits).  With the switch off the iteration is
+    the C restatement's again: at the DEFAULT tolerance -- where both stop
+    early, at sqrt(rTr) < 1e-8 N -- the values agree to 1e-9, the iteration
+    counts exactly."""
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
+    G = cases.config3_graphs(40, seed=17)
+    knode, kedge, q = cases.config3_kernels()
+    backend = HIPBackend(real=np.float64, hipcc_extra=['-DGD_OC_FSCAL=0'],
+                         record_iterations=True)
+    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
+    K = k(G)
+    it = backend.iterations(backend.last_plan)
+    ii, jj = np.triu_indices(len(G))
+    batch = oracle.TensorProductBatch(G, knode, kedge)
+    val, it_ref = batch.run(ii, jj, q=q, real='f64', tol=k.ftol)
+    assert np.allclose(K[ii, jj], val, rtol=1e-9), np.abs(K[ii, jj] / val - 1).max()
+    assert np.abs(it.astype(int) - np.asarray(it_ref).astype(int)).max() <= 1
+    # the default build at the same tolerance: the same accuracy class
+    # (2e-7 of each other: what the stopping rule leaves), not the same bits
+    kd = MarginalizedGraphKernel(knode, kedge, q=q,
+                                 backend=HIPBackend(real=np.float64))
+    assert np.allclose(kd(G)[ii, jj], val, rtol=2e-7)
+
+
 def test_mixed_precision_refinement_build():
     """-DGD_OC_MIXED=1 (mgk_oc.h MIXED: float iteration, double residual,
     iterative refinement; measured slower than the float-scalar double
