@@ -11,6 +11,7 @@ import os
 import re
 import subprocess
 import tempfile
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 _here = os.path.dirname(os.path.abspath(__file__))
@@ -80,6 +81,7 @@ def compile_source(source, flags=(), keep_source=True):
     """Return the path of the code object for `source`, compiling it if it is
     not cached.  Raises CompileError with hipcc's diagnostics."""
     key = cache_key(source, flags)
+    _used.add(key)
     os.makedirs(CACHE_DIR, exist_ok=True)
     out = os.path.join(CACHE_DIR, key + '.hsaco')
     if os.path.exists(out) and os.path.getsize(out) > 0:
@@ -118,6 +120,37 @@ def compile_source(source, flags=(), keep_source=True):
     return out
 
 
+#: cache keys this process asked for (`prune_unused`)
+_used = set()
+_started = time.time()
+
+
+def prune_unused():
+    """Delete the cached code objects and sources that this process did not
+    ask for and that were written before it started: the key of every object
+    contains the digest of the device headers, so each edit of a header
+    leaves a full set of dead objects behind (the cache is shipped with the
+    tree to the GPU box).  For a process that has asked for everything worth
+    keeping -- `__graft_entry__.build()`.  Returns the number of files removed."""
+    removed = 0
+    try:
+        names = os.listdir(CACHE_DIR)
+    except OSError:
+        return 0
+    for name in names:
+        stem, ext = os.path.splitext(name)
+        if ext not in ('.hsaco', '.hip') or stem in _used:
+            continue
+        path = os.path.join(CACHE_DIR, name)
+        try:
+            if os.path.getmtime(path) < _started:
+                os.unlink(path)
+                removed += 1
+        except OSError:
+            pass
+    return removed
+
+
 def entry_points(source):
     """Names of the ``extern "C" __global__`` kernels a source defines."""
     return re.findall(
@@ -132,8 +165,9 @@ def compile_many(sources, flags=(), max_workers=None):
     if not sources:
         return []
     # everything cached (the usual case): no thread pool
-    paths = [os.path.join(CACHE_DIR, cache_key(s, flags) + '.hsaco')
-             for s in sources]
+    keys = [cache_key(s, flags) for s in sources]
+    _used.update(keys)
+    paths = [os.path.join(CACHE_DIR, k + '.hsaco') for k in keys]
     if all(os.path.exists(p) and os.path.getsize(p) > 0 for p in paths):
         return paths
     max_workers = max_workers or min(len(sources), os.cpu_count() or 1)
