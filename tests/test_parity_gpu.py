@@ -6,6 +6,7 @@ against ``HIPBackend``; tolerances are the reference's (fp32 device
 arithmetic vs an fp64 oracle):  rel 1e-5 on kernel values, exact symmetry,
 normalised self-similarity 1 +- 2e-7 ... see each test.
 """
+import os
 import numpy as np
 import pytest
 from _fixtures import load, graphs_from, kernel_from_repr
@@ -669,6 +670,85 @@ def test_streamed_solver_on_large_spatial_graphs(real):
     dn = k.diag(sub, nodal=True)
     assert np.allclose(dn, np.diag(Kn), rtol=rtol,
                        atol=rtol * np.abs(Kn).max())
+
+
+def _spatial_graph(rng, n, degree, isolated=0, hub=0):
+    """n nodes with `element` labels; every connected node gets about
+    `degree` random neighbours (weights in (0.1, 1], the attribute `length`),
+    the last `isolated` nodes none, node 0 `hub` more."""
+    import networkx as nx
+    g = nx.Graph()
+    for v in range(n):
+        g.add_node(v, element=int(rng.choice([1, 6, 7, 8])))
+    live = n - isolated
+    for v in range(live):
+        for u in rng.choice(live, size=max(1, degree // 2), replace=False):
+            if u != v:
+                g.add_edge(v, int(u))
+    for u in rng.choice(np.arange(1, live), size=min(hub, live - 1), replace=False):
+        g.add_edge(0, int(u))
+    for a, b in g.edges:
+        g.edges[a, b]['w'] = float(np.float32(rng.uniform(0.1, 1.0)))
+        g.edges[a, b]['length'] = float(np.float32(rng.uniform(0.9, 2.6)))
+    return Graph.from_networkx(g, weight='w')
+
+
+def test_streamed_solver_segment_cap_isolated_nodes_and_a_streamed_side_beyond_1024_nodes():
+    """Shapes of the streamed solver (mgk_stream.h) the spatial sets do not
+    reach: (i) the resident graph's segments of 16 neighbours do not fit the
+    1024 lanes -- 700 nodes of ~44 neighbours: 2 100 segments, the cap doubles
+    twice --, (ii) isolated nodes (rows of A without a neighbour: passes of
+    zero rows, whole row groups without one) and a hub of 300 neighbours
+    beside nodes of four, (iii) a graph of more than 1024 nodes: it can only
+    be the streamed side, whatever the image sizes.  Every pair, values
+    against the C oracle converged in double, M workgroups per pair and
+    one."""
+    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend, STREAM
+    rng = np.random.default_rng(77)
+    G = Graph.unify_datatype([
+        _spatial_graph(rng, 700, 44),
+        _spatial_graph(rng, 400, 4, isolated=30, hub=300),
+        _spatial_graph(rng, 1100, 3),
+    ])
+    assert len(G[2].nodes) > 1024
+    knode, kedge, q = cases.tang2019_kernels()
+    # (every pair but the dense graph against itself -- 9e8 terms per
+    # mat-vec, two minutes of oracle: it is the resident graph of pair (0, 2),
+    # the 1100-node graph cannot be)
+    i, j = np.array([0, 0, 1, 1, 2]), np.array([1, 2, 1, 2, 2])
+    ref, _ = oracle.TensorProductBatch(G, knode, kedge).run(
+        i, j, q=q, real='f64', tol=1e-13, omp=True)
+    for real, tol in ((np.float32, 2e-5), (np.float64, 1e-8)):
+        for parts in (None, '1'):
+            be = HIPBackend(real=real)
+            k = MarginalizedGraphKernel(knode, kedge, q=q, backend=be,
+                                        **({'ftol': 1e-13} if real is np.float64 else {}))
+            if parts:
+                os.environ['GD_STREAM_PARTS'] = parts
+            try:
+                Kxy = k(G[:1], G[1:])
+                used = [L['variant'] for L in be.last_plan.launches]
+                Kyy = k(G[1:])
+                used += [L['variant'] for L in be.last_plan.launches]
+            finally:
+                os.environ.pop('GD_STREAM_PARTS', None)
+            assert STREAM in used and len(used) >= 3, used
+            got = np.array([Kxy[0, 0], Kxy[0, 1], Kyy[0, 0], Kyy[0, 1], Kyy[1, 1]])
+            assert np.abs(got / ref - 1).max() <= tol, \
+                (real.__name__, parts, np.abs(got / ref - 1))
+            assert np.array_equal(Kyy, Kyy.T)
+    # value + gradient on the same shapes (two sequential solves and the
+    # streamed derivative; the pair of 1100-node graphs: the general solver)
+    ig, jg = np.array([0, 0, 1]), np.array([0, 1, 1])
+    ref_v, ref_g, _ = oracle.TensorProductBatch(G[1:], knode, kedge).run_gradient(
+        ig, jg, q=q, real='f64', omp=True)
+    be = HIPBackend(real=np.float64)
+    kg = MarginalizedGraphKernel(knode, kedge, q=q, backend=be)
+    Kg, dK = kg(G[1:], eval_gradient=True)
+    assert STREAM in [L['variant'] for L in be.last_plan.launches]
+    assert np.allclose(Kg[ig, jg], ref_v, rtol=1e-8)
+    assert elementwise_gradient_error(
+        dK[ig, jg, :], ref_g[:, np.asarray(kg.active_theta_mask)], 1e-6, 1e-9) <= 1
 
 
 @pytest.mark.parametrize('real', [np.float32, np.float64])
