@@ -415,6 +415,7 @@ class LaunchSet:
         self.start = runtime.Event()
         self._n_last = 0
         self.max_streams = int(os.environ.get('GD_MAX_STREAMS', '3'))
+        self.streams_forced = 'GD_MAX_STREAMS' in os.environ
 
     def enqueue(self, plan, events=None, serial=False, front=None, after=(),
                 detached=False):
@@ -458,6 +459,10 @@ class LaunchSet:
                 for k in range(n)]
         order = sorted(range(n), key=lambda k: -cost[k])
         ns = max(1, min(n, self.max_streams or n))
+        # (a plan may ask for fewer: HIPBackend.prepare, `stream_hint`)
+        hint = getattr(plan, 'stream_hint', None)
+        if hint and not self.streams_forced:
+            ns = max(1, min(ns, hint))
         low = detached and os.environ.get('GD_DETACHED_PRIORITY', '1') != '0'
         streams, done, spool, epool = (
             (self.low_streams, self.low_done, _LOW_STREAM_POOL,
@@ -2190,6 +2195,20 @@ void ${name}(params_t prm) {
                 runtime.set_max_dynamic_lds(fn, L['dynamic_lds'])
             launches.append(L)
         plan.launches = launches
+        # Streams the launches are dealt onto (LaunchSet): three by default
+        # (short launches fill the tails of long ones: +4-6 % over one, the
+        # dense molecular set +10 % over two), TWO for the double value plans
+        # of one-wave static layouts -- latency-bound kernels at two or three
+        # waves per SIMD whose dominant launch loses more residency to a
+        # third concurrent grid than its tail gains: 168.4-168.6 against
+        # 166.1-166.3 M pairs/s on the headline, alternating on one box
+        # (profiles/sessions.md r5_session29; float: equal; double value +
+        # gradient: three, 64.5 against 63.7 M).
+        plan.stream_hint = 2 if (
+            np.dtype(self.real) == np.float64 and C == 1 and not nodal
+            and not ngrad and len(launches) > 2
+            and all(isinstance(L['variant'], OCVariant) and L['variant'].L
+                    for L in launches)) else None
 
         # per-call device buffers (outputs, scratch) from the grow-only pool
         b_out = self._buffer('gramian', n_out * rsize)
