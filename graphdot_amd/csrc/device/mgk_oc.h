@@ -462,7 +462,26 @@ struct oc_solver {
     constexpr static int MAXR = 4;               // refinement rounds at most
     using creal = std::conditional_t<MIXED, float, real>;   // arithmetic of the CG iteration
     constexpr static int NSYS = MIXED ? MAXR : C / CW;   // solves per pair (MIXED: refinement rounds at most)
-    constexpr static bool HAS_Y = (!STATIC && !FLY) || LEAN || SEQ;   // the [Y] region exists (SEQ: the first system's solution waits there)
+#ifndef GD_OC_DLDS
+#define GD_OC_DLDS 1
+#endif
+    // DLDS (the double one-wave static value solver of SIX row batches): the
+    // Jacobi diagonal and its inverse -- 2 R reals, 4 R registers, read once
+    // per iteration each -- live in lane-private LDS cells ([2 R][T] in the
+    // [Y] region, HIPBackend.diagonals_in_lds sizes it) instead of registers.
+    // The layout needs 200 registers spill-free and ran at two waves per SIMD
+    // (at 168 the allocator reloads 12 values from scratch in every
+    // iteration: 0.557 -> 0.849 ms); with the 24 registers out nothing is
+    // reloaded at three waves.  The kernel alone gains little (0.555 -> 0.547
+    // ms: the 12 conflict-free reads cost what the third wave brings, as
+    // they did on the five-batch kernel, DESIGN.md "tried and dropped") -- but
+    // beside the other launches of a step it overlaps better: 168.5 / 168.0
+    // -> 170.4 / 169.9 M pairs/s on the headline, alternating on one box
+    // (profiles/sessions.md r5_session33).  -DGD_OC_DLDS=0: off.
+    constexpr static bool DLDS = GD_OC_DLDS != 0 && sizeof(real) == 8 && STATIC && W == 1 && C == 1 && !NODAL &&
+                                 !NGRAD && !MAXIMIN && !MIXED && !FLY && R == 6;
+    constexpr static bool HAS_Y = (!STATIC && !FLY) || LEAN || SEQ || DLDS;   // the [Y] region exists (SEQ: the first system's solution waits there)
+    constexpr static int Y_REALS = DLDS ? 2 * R * 64 * W : R * 64 * W * C;    // its size
 #ifndef GD_OC_GRID
 #define GD_OC_GRID 1
 #endif
@@ -589,7 +608,7 @@ struct oc_solver {
         real *const lp = dyn;
         creal *const lpc = reinterpret_cast<creal *>(dyn);      // p in the arithmetic of the iteration
         real *const lY = lp + (size_t)prm.u_capacity * C;
-        unsigned *const rowmap = reinterpret_cast<unsigned *>(lY + (HAS_Y ? (size_t)NR * C : (size_t)0));
+        unsigned *const rowmap = reinterpret_cast<unsigned *>(lY + (HAS_Y ? (size_t)Y_REALS : (size_t)0));
         char *const lG1 = reinterpret_cast<char *>(rowmap + NR);
         char *const lG2 = lG1 + prm.g_capacity;
         // SL: [SL][T] slot values behind the second image
@@ -1294,6 +1313,10 @@ struct oc_solver {
                 const real dgk = ok ? cg_ratio(dx, vx) : real(0);
                 dg[k] = (creal)dgk;
                 mi[k] = (creal)(ok ? cg_ratio(vx, dx) : real(0));
+                if constexpr (DLDS) {
+                    lY[k * T + tid] = dg[k];
+                    lY[(R + k) * T + tid] = mi[k];
+                }
                 paddr[k] = ok ? (int)__umul24((unsigned)i1, (unsigned)ldp) + i2 : dump;
                 const real b = ok ? dx * bscale : real(0);
                 if constexpr (MIXED) {
@@ -1576,6 +1599,15 @@ struct oc_solver {
                     // LDS operations of one wave execute in order)
                     creal Ap[CW][R];
                     creal pAp = 0;
+                    if constexpr (DLDS) {
+                        unsigned ly_lane = lY_off + (unsigned)tid * (unsigned)sizeof(creal);
+                        asm volatile("" : "+v"(ly_lane));
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            dg[k] = load_real_at<creal>(ly_lane + (unsigned)(k * T * (int)sizeof(creal)));
+                            mi[k] = load_real_at<creal>(ly_lane + (unsigned)((R + k) * T * (int)sizeof(creal)));
+                        }
+                    }
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
                         creal y[CW];

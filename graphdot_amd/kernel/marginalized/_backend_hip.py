@@ -149,6 +149,7 @@ GENERAL_THREADS = 1024
 #: molecular set (scripts/mfma_experiment.py).  GD_MFMA=0: off.
 MFMA = Variant(-3, 0, 0)
 MFMA_MAX_NODES = 32
+DLDS_DEFAULT = True       # mgk_oc.h GD_OC_DLDS
 #: sentinel: the streamed solver for large pairs (csrc/device/mgk_stream.h):
 #: value solves of pairs beyond every register- and LDS-resident variant; one
 #: graph of the pair staged in LDS, the other streamed row by row, CG vectors
@@ -956,10 +957,13 @@ struct ${name}_t : ${name}_theta_t {
                     # the row sums zeroed late and p updated in place
                     # (mgk_oc.h) their iteration is spill-free at 168
                     # registers: (16,4,4,1,1) 0.864 -> 0.726 ms, (16,4,4,3,1)
-                    # 0.115 -> 0.105; the six-batch layout still reloads 12
-                    # values per iteration at three: 0.557 -> 0.849)
+                    # 0.115 -> 0.105; the six-batch layout reloads 12 values
+                    # per iteration at three -- 0.557 -> 0.849 -- unless its
+                    # diagonals leave the registers, below)
                     ('L', 16, 4, 4, 1): 3, ('L', 16, 4, 4, 1, 1): 3,
-                    ('L', 16, 4, 4, 3, 1): 3, ('L', 16, 4, 4, 3, 1, 1): 2,
+                    # ((16,4,4,3,1,1): three waves with the Jacobi diagonals in
+                    # LDS, mgk_oc.h DLDS -- nothing reloaded in the iteration)
+                    ('L', 16, 4, 4, 3, 1): 3, ('L', 16, 4, 4, 3, 1, 1): 3,
                     ('L', 16, 4, 4, 4, 1, 1, 1): 2,
                     ('L', 16, 4, 4, 4, 3, 1, 1, 1): 2,
                     ('L', 16, 4, 4, 4, 4, 1, 1, 1, 1): 2,
@@ -1244,6 +1248,18 @@ void ${name}(params_t prm) {
             return n * 64 * v.W * 8
         return 0
 
+    def diagonals_in_lds(self, v, C, nodal=False):
+        """mgk_oc.h DLDS: the double one-wave static value solver of six row
+        batches keeps the Jacobi diagonal and its inverse in lane-private LDS
+        cells (2 R reals per lane in the [Y] region)."""
+        on = DLDS_DEFAULT
+        for f in self.hipcc_extra:               # (-DGD_OC_DLDS=n: experiments)
+            if f.startswith('-DGD_OC_DLDS='):
+                on = int(f.split('=')[1]) != 0
+        return bool(on and isinstance(v, OCVariant) and v.L and v.W == 1
+                    and v.R == 6 and C == 1 and not nodal
+                    and np.dtype(self.real) == np.float64)
+
     def lds_bytes(self, v, C, ntask=0, gbytes=0, tab_bytes=0, nodal=False):
         """LDS bytes of one workgroup: static p + scratch, dynamic U, the two
         staged graph images per pair slot and the microkernel tables."""
@@ -1256,6 +1272,8 @@ void ${name}(params_t prm) {
             # static layouts keep the row sums in registers: no Y region,
             # except the value + gradient solvers, which keep x there
             NR_y = 0 if ((v.L and C != 2) or v.S == 0) else NR
+            if self.diagonals_in_lds(v, C, nodal):
+                NR_y = 2 * NR
             return (pcap + NR_y) * C * rs + 4 * NR + 2 * np.asarray(gbytes) \
                 + 4 * v.W * rs + 4 * (128 if v.D > 6 else 64) + 256 + 16 \
                 + self.lds_slot_bytes(v, C, nodal)
@@ -1812,8 +1830,10 @@ void ${name}(params_t prm) {
                 pcap = int(-(-(NP[idx].max() + 1) // 4) * 4)
                 gcap = int(-(-gbytes_oc[idx].max() // 16) * 16)
                 NR = 64 * v.W * v.R
-                dyn = (pcap + (0 if ((v.L and C != 2) or v.S == 0)
-                               else NR)) * C * rsize + 4 * NR + 2 * gcap
+                NR_y = 0 if ((v.L and C != 2) or v.S == 0) else NR
+                if self.diagonals_in_lds(v, C, nodal):
+                    NR_y = 2 * NR
+                dyn = (pcap + NR_y) * C * rsize + 4 * NR + 2 * gcap
                 dyn += self.lds_slot_bytes(v, C, nodal)
                 dense = False
                 if v.S == 0:
