@@ -1059,18 +1059,21 @@ void ${name}(${params} prm) {
     using solver = graphdot::mgk::oc_solver<real_t, ${S}, ${R}, ${W}, ${C},
         ${nodal}, ${D}, ${tab}, ${ngrad}, ${maximin}, ${layout}, graph_t,
         node_kernel_t, edge_kernel_t, p_start_t>;
+    static_assert(solver::DLDS == ${dlds}, "Jacobi diagonals in LDS: the host sized the [Y] region for the other answer (HIPBackend.diagonals_in_lds)");
     __shared__ typename solver::lds_t lds;
     extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
     solver::run(prm, lds, reinterpret_cast<real_t *>(dyn_lds));
 }
 ''').render(threads=64 * v.W,
             name=self.kernel_name(v, C, nodal, tab, ngrad, maximin),
+            dlds='true' if self.diagonals_in_lds(v, C, nodal or ngrad
+                                                 or bool(maximin)) else 'false',
             maximin='true' if maximin else 'false',
             layout=('graphdot::mgk::seg_layout<%s>' % ', '.join(map(str, v.L))
                     if v.L else 'graphdot::mgk::dynamic_layout'),
             S=v.S, R=v.R, W=v.W, C=C, D=v.D if v.S else 1,
             waves=self._oc_waves(v, C, ngrad) if ngrad
-            else self.waves_per_eu(v, C),
+            else self._waves_without_lds_diagonals(v, C, nodal or bool(maximin)),
             nodal='true' if nodal else 'false',
             tab='true' if tab else 'false',
             ngrad='true' if ngrad else 'false',
@@ -1248,6 +1251,19 @@ void ${name}(params_t prm) {
             return n * 64 * v.W * 8
         return 0
 
+    def _waves_without_lds_diagonals(self, v, C, nodal):
+        """Occupancy target of a kernel: `waves_per_eu`, but the six-batch
+        double value layout runs three waves only WITH its Jacobi diagonals in
+        LDS (mgk_oc.h DLDS) -- its nodal flavours and the builds without them
+        stay at two (twelve values reloaded per iteration at three)."""
+        w = self.waves_per_eu(v, C)
+        if (isinstance(v, OCVariant) and v.L == (16, 4, 4, 3, 1, 1) and C == 1
+                and np.dtype(self.real) == np.float64
+                and not self.diagonals_in_lds(v, C, nodal)
+                and not (self.occupancy and (v.W, v.S) in self.occupancy)):
+            w = min(w, 2)
+        return w
+
     def diagonals_in_lds(self, v, C, nodal=False):
         """mgk_oc.h DLDS: the double one-wave static value solver of six row
         batches keeps the Jacobi diagonal and its inverse in lane-private LDS
@@ -1256,6 +1272,8 @@ void ${name}(params_t prm) {
         for f in self.hipcc_extra:               # (-DGD_OC_DLDS=n: experiments)
             if f.startswith('-DGD_OC_DLDS='):
                 on = int(f.split('=')[1]) != 0
+            if f.startswith('-DGD_OC_MIXED=') and int(f.split('=')[1]) != 0:
+                on = False                       # (the refinement build keeps them)
         return bool(on and isinstance(v, OCVariant) and v.L and v.W == 1
                     and v.R == 6 and C == 1 and not nodal
                     and np.dtype(self.real) == np.float64)
