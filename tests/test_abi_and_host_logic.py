@@ -735,3 +735,29 @@ def test_workgroups_per_pair_of_the_streamed_solver():
     assert stream_parts(np.ones(256), 256, 256, 512) == 1
     # never more workgroups than the chip holds
     assert stream_parts(np.array([5.0, 4.0]), 2, 64, 128) <= 64
+
+
+def test_lds_diagonals_of_the_six_batch_layout_on_the_host():
+    """mgk_oc.h DLDS, host half: the double graph-level value kernel of the
+    six-batch static layout keeps its Jacobi diagonals in LDS -- 2 R reals
+    per lane more in the [Y] region, three waves per SIMD --, its nodal
+    flavours, the value + gradient solver, the float build and a build with
+    -DGD_OC_DLDS=0 do not (two waves for the double ones).  (That host and
+    device agree is a static_assert in every rendered kernel: the compile
+    matrix checks it.)"""
+    from graphdot_amd.kernel.marginalized._backend_hip import (
+        HIPBackend, OCStatic)
+    v6, v5 = OCStatic(16, 4, 4, 3, 1, 1), OCStatic(16, 4, 4, 1, 1)
+    b = HIPBackend(real=np.float64)
+    assert b.diagonals_in_lds(v6, 1) and not b.diagonals_in_lds(v6, 1, nodal=True)
+    assert not b.diagonals_in_lds(v6, 2) and not b.diagonals_in_lds(v5, 1)
+    extra = b.lds_bytes(v6, 1, 380, 800) - b.lds_bytes(v6, 1, 380, 800, nodal=True)
+    assert extra == 2 * 6 * 64 * 8
+    assert b._waves_without_lds_diagonals(v6, 1, False) == 3
+    assert b._waves_without_lds_diagonals(v6, 1, True) == 2
+    off = HIPBackend(real=np.float64, hipcc_extra=['-DGD_OC_DLDS=0'])
+    assert not off.diagonals_in_lds(v6, 1)
+    assert off._waves_without_lds_diagonals(v6, 1, False) == 2
+    assert not HIPBackend(real=np.float32).diagonals_in_lds(v6, 1)
+    mixed = HIPBackend(real=np.float64, hipcc_extra=['-DGD_OC_MIXED=1'])
+    assert not mixed.diagonals_in_lds(v6, 1)
