@@ -2,7 +2,7 @@
 """Gram-matrix throughput of the marginalized graph kernel on MI355X.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-                    [--config 3|2] [--dtype f64|f32] [--gradient]
+                    [--config 3|2|tang2019|large] [--dtype f64|f32] [--gradient]
                     [--graphs n] [--sharded] [--serial]
 
 A *step* is one full pass of the hot path over the batch: every pair of the
@@ -18,6 +18,13 @@ job list and hyperparameters into the device-resident result.
                         reference workload benchmark/kernel/marginalized/
                         time_kernel.py:14-29), fp32 by default (the reference
                         solver's arithmetic)
+  --config tang2019     256 dense from_ase-like molecular graphs under the
+                        reference's Tang2019MolecularKernel preset (on-the-fly
+                        solvers)
+  --config large        protein-like spatial graphs of 150-600 atoms (default
+                        32 graphs = 528 pairs; --graphs n for fewer): the
+                        regime of example/perfbench/protein-time-to-solution.py,
+                        the streamed solver of csrc/device/mgk_stream.h
   --gradient            value + dK/dtheta (the kernel part of config 5)
   --gpr                 config 5 end to end on one GPU: GPR log marginal
                         likelihood + gradient step (kernel + dense algebra)
