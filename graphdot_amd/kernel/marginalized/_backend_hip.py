@@ -2241,10 +2241,12 @@ void ${name}(params_t prm) {
         # third concurrent grid than its tail gains: 168.4-168.6 against
         # 166.1-166.3 M pairs/s on the headline, alternating on one box
         # (profiles/sessions.md r5_session29; float: equal; double value +
-        # gradient: three, 64.5 against 63.7 M).
+        # gradient: three, 64.5 against 63.7 M; the same plans run to
+        # convergence, ftol 1e-13 and 26 iterations instead of 17: three, 126.6
+        # against 125.7 M, r5_session36 -- hence the tolerance in the rule).
         plan.stream_hint = 2 if (
             np.dtype(self.real) == np.float64 and C == 1 and not nodal
-            and not ngrad and len(launches) > 2
+            and not ngrad and len(launches) > 2 and ftol >= 1e-10
             and all(isinstance(L['variant'], OCVariant) and L['variant'].L
                     for L in launches)) else None
 
