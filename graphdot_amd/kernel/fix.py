@@ -94,9 +94,11 @@ class Normalization(_Transformed):
                                        + (ddr / dr[:, None])[None, :, :]))
         return K, np.asfortranarray(dK)
 
-    def device_gram(self, X, eval_gradient=False):
+    def device_gram(self, X, eval_gradient=False, local_gradient=False):
         """`__call__(X)` computed on the GPU from the wrapped kernel's device
-        buffers; returns torch tensors."""
+        buffers; returns torch tensors.  (`local_gradient`: accepted for the
+        regressor's call and not forwarded -- the transformation needs the
+        whole gradient planes, not one rank's pairs.)"""
         R, dR = self._inner_device_gram(X, eval_gradient)
         d = R.diagonal()
         s = d.rsqrt()
@@ -136,7 +138,9 @@ class Exponentiation(_Transformed):
                             axis=2)
         return K, dK
 
-    def device_gram(self, X, eval_gradient=False):
+    def device_gram(self, X, eval_gradient=False, local_gradient=False):
+        """(`local_gradient` is accepted and not forwarded: see
+        `Normalization.device_gram`.)"""
         import torch
         R, dR = self._inner_device_gram(X, eval_gradient)
         K = R**self.xi

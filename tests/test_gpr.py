@@ -417,11 +417,30 @@ def test_molecular_kernel_normalised_in_a_gpr():
         dev.X = host.X = G
         dev.y = host.y = y
         assert dev._device_gramian(dev._dense(), wrapped, G, True) is not None
+        # ... also with the arguments the likelihood itself passes (round 5's
+        # advisor finding: the transformers refused `local_gradient`, the
+        # TypeError was swallowed, every training step of a wrapped kernel
+        # went through host arrays)
+        assert dev._device_gramian(dev._dense(), wrapped, G, True,
+                                   local_gradient=True) is not None
         v1, g1 = dev.log_marginal_likelihood(eval_gradient=True)
         v2, g2 = host.log_marginal_likelihood(eval_gradient=True)
         assert v1 == pytest.approx(v2, rel=1e-5)
         assert np.allclose(g1, g2, rtol=2e-3, atol=1e-4 * np.abs(g2).max())
     assert np.abs(gpr.predict(G) - y).max() < 1.0
+
+
+def test_transformers_accept_the_regressors_device_gram_arguments():
+    """`GaussianProcessRegressor.log_marginal_likelihood` calls
+    ``kernel.device_gram(X, eval_gradient=..., local_gradient=...)``: the
+    transformers of kernel/fix.py must take the same keywords as
+    `MarginalizedGraphKernel.device_gram` (CPU: signatures only)."""
+    import inspect
+    from graphdot_amd.kernel.fix import Normalization, Exponentiation
+    from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
+    want = {'X', 'eval_gradient', 'local_gradient'}
+    for cls in (Normalization, Exponentiation, MarginalizedGraphKernel):
+        assert want <= set(inspect.signature(cls.device_gram).parameters), cls
 
 
 @pytest.mark.parametrize('device,native', [
