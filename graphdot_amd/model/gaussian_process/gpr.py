@@ -133,20 +133,19 @@ class _Dense:
         base.py:126-127, linalg/spectral.py)."""
         torch = _torch()
         if K.is_cuda and K.dtype == torch.float64 and self.native_cholesky:
-            # blocked factorisation of potrf.hip (0.87 ms against the 2.7 ms
-            # of the library's column-by-column one at n = 1000), then
-            # K^-1 = X^T X with X = L^-1 from one triangular solve
-            from ._potrf import cholesky_
-            L = torch.tril(cholesky_(K.clone()))
-            # (one host synchronisation: a diagonal entry that is not finite
-            # and positive -- the matrix was not positive definite -- makes
-            # the sum of logarithms non-finite)
-            logdet = 2.0 * torch.log(torch.diagonal(L)).sum()
-            X = torch.linalg.solve_triangular(
-                L, torch.eye(len(L), dtype=L.dtype, device=L.device),
-                upper=False)
-            Kinv = X.T @ X
-            logdet = float(logdet)
+            # factor and inverse in ONE data-flow launch of potrf.hip (round
+            # 6: 31 launches + a triangular solve + X^T X before, 1.24 ms at
+            # n = 1000), then ONE small download: the launch's status word
+            # and the log-determinant shares of the diagonal blocks -- the
+            # only host synchronisation of the factorisation (a pivot that
+            # is not positive makes the sum of logarithms NaN)
+            from ._potrf import factor_inverse, read_head, FactorisationError
+            Kinv, head, nb = factor_inverse(K)
+            completed, logdet = read_head(head, nb)
+            if not completed:
+                raise FactorisationError(
+                    'spd_factor_invert_f64 gave up waiting for a tile')
+            logdet *= 2.0
             if np.isfinite(logdet):
                 return Kinv, logdet
         else:
