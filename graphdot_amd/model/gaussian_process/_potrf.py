@@ -80,12 +80,21 @@ def _dataflow(A, invert, stamps=None):
     return Kinv, head
 
 
+def parse_head(words, nb):
+    """(completed, log|L|) from the first 16 + 2 nb int32 words of the
+    launch's sync buffer, given as 8 + nb float64 (how the regressor packs
+    them into its one download) or as the int32 words themselves."""
+    import numpy as np
+    words = np.ascontiguousarray(words)
+    status = int(words.view(np.int32)[1])
+    shares = words.view(np.float64)[8:8 + nb]
+    return status == 0, float(shares.sum())
+
+
 def read_head(head, nb):
     """(completed, log|L|) from the first words of the launch's sync buffer:
     ONE device-to-host copy (it synchronises with the launch)."""
-    import numpy as np
-    h = head[:16 + 2 * nb].cpu().numpy()
-    return int(h[1]) == 0, float(h[16:].view(np.float64).sum())
+    return parse_head(head[:16 + 2 * nb].cpu().numpy(), nb)
 
 
 def factor_inverse(K):

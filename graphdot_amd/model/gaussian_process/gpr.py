@@ -126,13 +126,21 @@ class _Dense:
             return t.permute(*reversed(range(a.ndim)))
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
-    def factor(self, K, rcond):
+    def native(self, K):
+        """Does `K` take the one-launch factor-and-invert of potrf.hip?"""
+        return bool(K.is_cuda and K.dtype == _torch().float64
+                    and self.native_cholesky)
+
+    def factor(self, K, rcond, try_native=True):
         """Returns (Kinv as a dense tensor, log-determinant).  Cholesky
         first; a clamped pseudo-inverse if the matrix is not positive
         definite (the reference clamps small eigenvalues to the cutoff:
-        base.py:126-127, linalg/spectral.py)."""
+        base.py:126-127, linalg/spectral.py).  `try_native=False`: the
+        caller has already seen the native factorisation fail on `K`."""
         torch = _torch()
-        if K.is_cuda and K.dtype == torch.float64 and self.native_cholesky:
+        if self.native(K) and not try_native:
+            pass
+        elif self.native(K):
             # factor and inverse in ONE data-flow launch of potrf.hip (round
             # 6: 31 launches + a triangular solve + X^T X before, 1.24 ms at
             # n = 1000), then ONE small download: the launch's status word
@@ -448,21 +456,49 @@ class GaussianProcessRegressor:
             theta, X, y, eval_gradient, clone_kernel, local_gradient=True)
         torch = _torch()
         t = time.perf_counter()
-        Kinv, logdet = la.factor(K, self.beta)
-        Ky = Kinv @ y
-        yKy = float(y @ Ky)
-        value = yKy + logdet
         grad = None
-        if eval_gradient is True:
-            # tr(K^-1 dK_k) - (K^-1 y)^T dK_k (K^-1 y) = sum_ij W_ij dK_ijk
-            # with the symmetric W = K^-1 - (K^-1 y)(K^-1 y)^T: one pass over dK
-            W = Kinv - torch.outer(Ky, Ky)
-            if hasattr(dK, 'columns'):
-                # pair-sharded kernel: this rank's pairs, then one all-reduce
-                d = _contract_local(W, dK, self._keep)
-            else:
-                d = _contract_planes(W, dK)
-            grad = d.cpu().numpy() * np.exp(theta)
+        done = False
+        if la.native(K):
+            # everything enqueued behind the one-launch factor-and-invert of
+            # potrf.hip, then ONE download: the launch's status word and
+            # log-determinant shares, y^T K^-1 y and the gradient's
+            # contractions (round 5: three host synchronisations)
+            from ._potrf import factor_inverse, parse_head, FactorisationError
+            Kinv, head, nb = factor_inverse(K)
+            Ky = Kinv @ y
+            parts = [head[:16 + 2 * nb].view(torch.float64),
+                     (y @ Ky).reshape(1)]
+            if eval_gradient is True:
+                W = Kinv - torch.outer(Ky, Ky)
+                parts.append(_contract_local(W, dK, self._keep)
+                             if hasattr(dK, 'columns')
+                             else _contract_planes(W, dK))
+            packed = torch.cat(parts).cpu().numpy()
+            completed, logdet = parse_head(packed[:8 + nb], nb)
+            if not completed:
+                raise FactorisationError(
+                    'spd_factor_invert_f64 gave up waiting for a tile')
+            logdet *= 2.0
+            if np.isfinite(logdet):       # (else: not positive definite)
+                yKy = float(packed[8 + nb])
+                if eval_gradient is True:
+                    grad = packed[9 + nb:] * np.exp(theta)
+                done = True
+        if not done:
+            Kinv, logdet = la.factor(K, self.beta, try_native=False)
+            Ky = Kinv @ y
+            yKy = float(y @ Ky)
+            if eval_gradient is True:
+                # tr(K^-1 dK_k) - (K^-1 y)^T dK_k (K^-1 y) = sum_ij W_ij dK_ijk
+                # with the symmetric W = K^-1 - (K^-1 y)(K^-1 y)^T: one pass
+                W = Kinv - torch.outer(Ky, Ky)
+                if hasattr(dK, 'columns'):
+                    # pair-sharded kernel: this rank's pairs + one all-reduce
+                    d = _contract_local(W, dK, self._keep)
+                else:
+                    d = _contract_planes(W, dK)
+                grad = d.cpu().numpy() * np.exp(theta)
+        value = yKy + logdet
         t_linalg = time.perf_counter() - t
         if verbose:
             print(f'logP {value:12.5g}  y^T.K.y {yKy:12.5g}  '

@@ -52,6 +52,19 @@
 // the arithmetic is IEEE.
 #include <hip/hip_runtime.h>
 
+// (hooks of scripts/micro/factor_probe.hip, which times the factorisation of
+// one block in isolation with parts of a step taken out; the product compiles
+// with the defaults)
+#ifndef GD_POTRF_STEP_BARRIER
+#define GD_POTRF_STEP_BARRIER() __syncthreads()
+#endif
+#ifndef GD_POTRF_RCP
+#define GD_POTRF_RCP(x) rcp_f64(x)
+#endif
+#ifndef GD_POTRF_STEP_LOOP
+#define GD_POTRF_STEP_LOOP _Pragma("nounroll")
+#endif
+
 namespace {
 
 constexpr int B = 64;        // tile edge
@@ -61,52 +74,76 @@ constexpr int LT = B + 2;    // LDS row stride of a staged tile: the 16 rows x 2
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// 1 / sqrt(x) to the last bit or two: the hardware estimate (good to ~2^-23)
-// and ONE third-order step, y (1 + e / 2 + 3 e^2 / 8) with e = 1 - x y^2 --
-// five dependent operations where two Newton steps are eight (the IEEE sqrt
-// and division it replaces are ~80, on the critical path of every column)
+// 1 / sqrt(x) and 1 / x to the last bit or two: the hardware estimates (good
+// to ~2^-23) and ONE third-order step each -- y (1 + e / 2 + 3 e^2 / 8) with
+// e = 1 - x y^2; r (1 + e + e^2) with e = 1 - x r -- three to five dependent
+// operations where the IEEE sqrt and division are ~80
 __device__ __forceinline__ double rsqrt_f64(double x) {
     const double y = __builtin_amdgcn_rsq(x);
     const double e = __builtin_fma(-(x * y), y, 1.0);
     const double q = e * __builtin_fma(e, 0.375, 0.5);
     return x > 0.0 ? __builtin_fma(y, q, y) : __builtin_nan("");
 }
+__device__ __forceinline__ double rcp_f64(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
 
 // Factorisation of one 64 x 64 diagonal block held in registers by 256
 // threads: thread (ti, tj) of a 16 x 16 grid owns the elements
 // (ti + 16 u, tj + 16 v), u, v = 0..3, of the block D (its lower triangle is
-// what counts) and of W, which starts as the identity.  TWO columns j, j + 1
-// per barrier: the owners publish columns j, j + 1 of D and rows j, j + 1 of W
-// (unscaled, as they stand before the step) to one of two LDS buffers; every
-// thread derives the 2 x 2 pivot factor
-//     l_jj = sqrt(D_jj),  l_j+1,j = D_j+1,j / l_jj,
-//     l_j+1,j+1 = sqrt(D_j+1,j+1 - l_j+1,j^2)
-// itself (two inverse square roots instead of a broadcast and a second
-// barrier), scales what it needs and applies the rank-2 updates
-//     D[r][c] -= l0_r l0_c + l1_r l1_c   (r >= c > j + 1),
-//     W[r][c] -= l0_r W'[j][c] + l1_r W'[j+1][c]   (r > j + 1, c <= j + 1),
-// i.e. the eliminations that turn D into L also turn the identity into L^-1.
-// Round 6: the quarter jq = j / 16 of the step is a compile-time fact (one
-// instantiation per quarter), and with it WHICH of the thread's sixteen 1 x 1
-// blocks a step can touch: D only where jq <= v <= u (rows and columns of
-// finished quarters are final, the strict upper triangle is never read), W
-// only where u >= jq >= v (W stays lower triangular) -- 20 + 20 block updates
-// over the four quarters where the first form did 64 + 64, each one two FMAs
-// (the compiler had made multiply, multiply-add and subtract of them).
+// what counts) and of W, which starts as the identity; the eliminations that
+// turn D into its factor turn W into the factor's inverse.
+//
+// What binds it (scripts/micro/f64_latency.hip, scripts/potrf_timeline.py):
+// one wave per SIMD ISSUES a double-precision instruction every 2.4 ns,
+// dependent or not, and the publish -> barrier -> read round trip through LDS
+// is 60 ns; the first form of the round -- two columns per barrier, every
+// thread scaling and masking all sixteen of its blocks in every step, ~270
+// instructions -- took 0.75 us per step, 24 us per block, 57 % of a panel's
+// time.  So the step is written for its instruction count:
+//
+//  * root-free, D = L' P L'^T with unit lower L': a step needs the two pivots'
+//    reciprocals (one estimate + three operations each) where the Cholesky
+//    step needs two inverse square roots one after the other, and only the ROW
+//    factors are scaled -- l'_rj = x_rj / p_j; the column side of the update
+//    takes the raw column (D[r][c] -= l'_rj x_cj: x_cj = l'_cj p_j).  The
+//    square roots come once per block, at the end, off the chain:
+//    L = L' sqrt(P), L^-1 = P^-1/2 L'^-1;
+//  * the quarter jq = j / 16 of a step is a compile-time fact (one
+//    instantiation per quarter) and with it which of the thread's sixteen 1 x 1
+//    blocks a step can touch: D only where jq <= v <= u, W only where
+//    u >= jq >= v -- 20 + 20 block updates over the four quarters instead of
+//    64 + 64, each two FMAs;
+//  * nothing is masked: finished columns of L' and finished rows of L'^-1 are
+//    CAPTURED in two LDS tiles the moment their owners have them (the staging
+//    buffers of the role are free meanwhile), so the register copies of
+//    finished rows and columns, and the strict upper triangle, may take any
+//    update -- no compare, no select in the step (the first form: ~40 of
+//    them).  Valid entries only ever read valid factors;
+//  * the blocks outside block column jq of D and block row jq of W take a
+//    step's update one step LATE, among the next step's chain (pivot
+//    reciprocals): nothing of them is published within the quarter.
+//
+// A pivot that is not positive goes through the elimination as it is and
+// makes its column of L NaN at the end (the inverse square root refuses it).
 struct factor_lds_t {
     double colD[2][2][B];     // [buffer][column j / j + 1][row]
     double rowW[2][2][B];     // [buffer][row j / j + 1][column]
+    double piv[B], scal[B], rscal[B];     // p_c, sqrt(p_c), 1 / sqrt(p_c)
 };
 
 template<int JQ>
-__device__ __forceinline__ void factor_quarter(double (&d)[4][4], double (&w)[4][4], factor_lds_t &s) {
+__device__ __forceinline__ void factor_quarter(double (&d)[4][4], double (&w)[4][4], factor_lds_t &s,
+                                               double (*Lt)[LT], double (*Wt)[LT]) {
     const int tid = threadIdx.x;
     const int ti = tid >> 4, tj = tid & 15;
     // the factors of the step before, for the blocks whose update waits
     double pa0[4], pa1[4], pb0[4], pb1[4], pw0[4], pw1[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) pa0[u] = pa1[u] = pb0[u] = pb1[u] = pw0[u] = pw1[u] = 0.0;
-#pragma nounroll
+    GD_POTRF_STEP_LOOP
     for (int jr = 0; jr < 16; jr += 2) {
         const int j = 16 * JQ + jr, buf = (jr >> 1) & 1;
         // owners publish columns j, j + 1 of D (rows of this quarter and
@@ -119,18 +156,20 @@ __device__ __forceinline__ void factor_quarter(double (&d)[4][4], double (&w)[4]
 #pragma unroll
             for (int v = 0; v <= JQ; ++v) s.rowW[buf][ti & 1][tj + 16 * v] = w[JQ][v];
         }
-        __syncthreads();
+        GD_POTRF_STEP_BARRIER();
         double const *const c0 = s.colD[buf][0], *const c1 = s.colD[buf][1];
         double const *const w0 = s.rowW[buf][0], *const w1 = s.rowW[buf][1];
-        const double inv0 = rsqrt_f64(c0[j]);             // (NaN if not positive)
-        const double lj1 = c0[j + 1] * inv0;              // l_j+1,j
-        const double d11 = __builtin_fma(-lj1, lj1, c1[j + 1]);
-        const double inv1 = rsqrt_f64(d11);
-        // -- the blocks OUTSIDE block column JQ of D and block row JQ of W
-        // take the update of the step BEFORE, now: nothing of them is
-        // published in this quarter, and their FMAs fill the latencies of
-        // the chain above (LDS read, two inverse square roots) instead of
-        // standing behind it
+        // the 2 x 2 pivot: p_j, l'_j+1,j, p_j+1 (every thread for itself)
+        const double p0 = c0[j], x01 = c0[j + 1];
+        const double r0 = GD_POTRF_RCP(p0);
+        const double m = x01 * r0;
+        const double p1 = __builtin_fma(-m, x01, c1[j + 1]);
+        const double r1 = GD_POTRF_RCP(p1);
+        if (tid == 0) {
+            s.piv[j] = p0;
+            s.piv[j + 1] = p1;
+        }
+        // -- the waiting blocks take the update of the step before
 #pragma unroll
         for (int u = JQ + 1; u < 4; ++u) {
 #pragma unroll
@@ -140,51 +179,44 @@ __device__ __forceinline__ void factor_quarter(double (&d)[4][4], double (&w)[4]
             for (int v = 0; v <= JQ; ++v)
                 w[u][v] = __builtin_fma(-pa0[u], pw0[v], __builtin_fma(-pa1[u], pw1[v], w[u][v]));
         }
-        // -- this step's factors
+        // -- this step's factors: rows l'_rj, l'_r,j+1; columns x_cj and
+        // x_c,j+1 less its share of column j; rows j, j + 1 of L'^-1
 #pragma unroll
         for (int u = JQ; u < 4; ++u) {
             const int r = ti + 16 * u;
-            pa0[u] = c0[r] * inv0;
-            pa1[u] = __builtin_fma(-pa0[u], lj1, c1[r]) * inv1;
+            const double x0 = c0[r];
+            pa0[u] = x0 * r0;
+            pa1[u] = __builtin_fma(-x0, m, c1[r]) * r1;
         }
 #pragma unroll
         for (int v = JQ; v < 4; ++v) {
             const int c = tj + 16 * v;
-            pb0[v] = c0[c] * inv0;
-            pb1[v] = __builtin_fma(-pb0[v], lj1, c1[c]) * inv1;
+            pb0[v] = c0[c];
+            pb1[v] = __builtin_fma(-pb0[v], m, c1[c]);
         }
 #pragma unroll
         for (int v = 0; v <= JQ; ++v) {
             const int c = tj + 16 * v;
-            pw0[v] = w0[c] * inv0;
-            pw1[v] = __builtin_fma(-lj1, pw0[v], w1[c]) * inv1;
+            pw0[v] = w0[c];
+            pw1[v] = __builtin_fma(-m, pw0[v], w1[c]);
+        }
+        // -- finished: columns j, j + 1 of L' and rows j, j + 1 of L'^-1
+        if ((tj & ~1) == jr) {
+#pragma unroll
+            for (int u = JQ; u < 4; ++u) Lt[ti + 16 * u][j + (tj & 1)] = (tj & 1) ? pa1[u] : pa0[u];
+        }
+        if ((ti & ~1) == jr) {
+#pragma unroll
+            for (int v = 0; v <= JQ; ++v) Wt[j + (ti & 1)][tj + 16 * v] = (ti & 1) ? pw1[v] : pw0[v];
         }
         // -- block column JQ of D and block row JQ of W at once: the next
-        // step publishes from them.  (Rows and columns up to j + 1 take no
-        // update: they exist in quarter JQ only.)
-        {
-            const int rq = ti + 16 * JQ, cq = tj + 16 * JQ;
-            const double m0 = cq > j + 1 ? pb0[JQ] : 0.0, m1 = cq > j + 1 ? pb1[JQ] : 0.0;
+        // step publishes from them
 #pragma unroll
-            for (int u = JQ; u < 4; ++u) {
-                const int r = ti + 16 * u;
-                const double a0 = (u > JQ || r > j + 1) ? pa0[u] : 0.0;
-                const double a1 = (u > JQ || r > j + 1) ? pa1[u] : 0.0;
-                double x = __builtin_fma(-a0, m0, __builtin_fma(-a1, m1, d[u][JQ]));
-                // columns j and j + 1 keep the scaled entries
-                if (tj == jr && r >= j) x = pa0[u];
-                if (tj == jr + 1 && r >= j + 1) x = pa1[u];
-                d[u][JQ] = x;
-            }
-            const double a0 = rq > j + 1 ? pa0[JQ] : 0.0, a1 = rq > j + 1 ? pa1[JQ] : 0.0;
+        for (int u = JQ; u < 4; ++u)
+            d[u][JQ] = __builtin_fma(-pa0[u], pb0[JQ], __builtin_fma(-pa1[u], pb1[JQ], d[u][JQ]));
 #pragma unroll
-            for (int v = 0; v <= JQ; ++v) {
-                double x = __builtin_fma(-a0, pw0[v], __builtin_fma(-a1, pw1[v], w[JQ][v]));
-                if (ti == jr) x = pw0[v];
-                if (ti == jr + 1) x = pw1[v];
-                w[JQ][v] = x;
-            }
-        }
+        for (int v = 0; v <= JQ; ++v)
+            w[JQ][v] = __builtin_fma(-pa0[JQ], pw0[v], __builtin_fma(-pa1[JQ], pw1[v], w[JQ][v]));
         // (no second barrier: the next pair of columns goes to the other
         // buffer, and a thread is at most one barrier ahead of the slowest)
     }
@@ -200,11 +232,28 @@ __device__ __forceinline__ void factor_quarter(double (&d)[4][4], double (&w)[4]
     }
 }
 
-__device__ __forceinline__ void factor_block(double (&d)[4][4], double (&w)[4][4], factor_lds_t &s) {
-    factor_quarter<0>(d, w, s);
-    factor_quarter<1>(d, w, s);
-    factor_quarter<2>(d, w, s);
-    factor_quarter<3>(d, w, s);
+// D (registers; A_jj - S on entry) -> the tiles Lt = L' and Wt = L'^-1 in LDS
+// (rows x columns, strict upper triangles undefined) and the pivots in `s`:
+// L[r][c] = Lt[r][c] s.scal[c] below the diagonal, s.scal[c] on it;
+// L^-1[r][c] = Wt[r][c] s.rscal[r] on and below it.
+__device__ __forceinline__ void factor_block(double (&d)[4][4], factor_lds_t &s, double (*Lt)[LT],
+                                             double (*Wt)[LT]) {
+    double w[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) w[u][v] = ((threadIdx.x >> 4) == (threadIdx.x & 15) && u == v) ? 1.0 : 0.0;
+    factor_quarter<0>(d, w, s, Lt, Wt);
+    factor_quarter<1>(d, w, s, Lt, Wt);
+    factor_quarter<2>(d, w, s, Lt, Wt);
+    factor_quarter<3>(d, w, s, Lt, Wt);
+    __syncthreads();
+    if (threadIdx.x < B) {
+        const double p = s.piv[threadIdx.x], rs = rsqrt_f64(p);
+        s.rscal[threadIdx.x] = rs;
+        s.scal[threadIdx.x] = p * rs;
+    }
+    __syncthreads();
 }
 
 // device-scope accesses of everything one workgroup hands to another
@@ -269,7 +318,7 @@ struct acc_t {
         const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
         const double *const p0 = &P[32 * (w >> 1) + (l & 15)][l >> 4];
         const double *const q0 = &Q[32 * (w & 1) + (l & 15)][l >> 4];
-#pragma unroll 4
+#pragma unroll
         for (int s = 0; s < B; s += 4) {
             const double a0 = p0[s], a1 = p0[16 * LT + s];
             const double b0 = q0[s], b1 = q0[16 * LT + s];
@@ -388,12 +437,17 @@ void spd_factor_invert_f64(spd_args_t a) {
             const bool is_a = p < nb - j;
             const int i = is_a ? j + p : p - (nb - j);
             if (!is_a && !a.invert) continue;
+            if (is_a && p == 1) continue;      // (j + 1, j): the diagonal role of row j + 1 owns it
             if (is_a && i == j) {
-                // -- the diagonal block.  Its own entries are fetched before
-                // the wait for the tiles to its left (they are the caller's:
-                // nothing in this launch writes them before this role does)
+                // -- the diagonal block AND the tile to its left, (j, j - 1):
+                // the chain FACTOR(j - 1) -> L_j,j-1 -> update of A_jj ->
+                // FACTOR(j) stays in one workgroup from the moment
+                // L_j-1,j-1^-1 arrives (a role of its own for the tile to the
+                // left cost the chain a store, a flag and a staging: 2.7 of
+                // 29 us per panel).  Own entries are fetched before the
+                // waits: nothing in this launch writes them before this role.
                 const int ti = tid >> 4, tj = tid & 15;
-                double d[4][4], w[4][4];
+                double d[4][4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -402,14 +456,53 @@ void spd_factor_invert_f64(spd_args_t a) {
                         const int gr = B * j + r, gc = B * j + c;
                         d[u][v] = (gr < n && gc < n) ? ld_sc1(a.A + (size_t)gr * a.ld + gc)
                                                      : (r == c ? 1.0 : 0.0);
-                        w[u][v] = (r == c) ? 1.0 : 0.0;
                     }
-                for (int k = 0; k < j; ++k) {
-                    if (!sy.wait(sy.flag_l + j * nb + k, nullptr)) return;
-                    stamp(1);
+                acc_t T;        // sum_{k < j - 1} L_jk L_j-1,k^T; then A_j,j-1 less it
+                T.zero();
+                if (j > 0) {
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int gr = B * j + acc_t::row(rb, g), gc = B * (j - 1) + acc_t::col(cb);
+                                T.c[rb][cb][g] = gr < n ? -ld_sc1(a.A + (size_t)gr * a.ld + gc) : 0.0;
+                            }
+                }
+                for (int k = 0; k + 1 < j; ++k) {
+                    if (!sy.wait(sy.flag_l + j * nb + k, sy.flag_l + (j - 1) * nb + k)) return;
                     stage_tile(P, l_tile(j, k));
+                    stage_tile(Q, l_tile(j - 1, k));
+                    __syncthreads();
+                    S.mma(P, P);
+                    T.mma(P, Q);
+                    __syncthreads();
+                }
+                if (j > 0) {
+                    // L_j,j-1 = (A_j,j-1 - sum) L_j-1,j-1^-T; T holds the negative
+                    T.to_lds(P, -1.0);
+                    if (!sy.wait(sy.flag_l + (j - 1) * nb + j - 1, nullptr)) return;
+                    stamp(1);
+                    stage_tile(Q, tile_src_t{a.Linv + ((size_t)(j - 1) << 12), B, B, B, false});
                     __syncthreads();
                     stamp(2);
+                    T.zero();
+                    T.mma(P, Q);
+                    __syncthreads();
+                    double *const out = a.A + (size_t)(B * j) * a.ld + B * (j - 1);
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int r = acc_t::row(rb, g), c = acc_t::col(cb);
+                                if (r < rows_of(j)) st_sc1(out + (size_t)r * a.ld + c, T.c[rb][cb][g]);
+                            }
+                    // ... and its share of A_jj, straight from the registers
+                    T.to_lds(P, 1.0);
+                    __syncthreads();
                     S.mma(P, P);
                     __syncthreads();
                     stamp(3);
@@ -422,33 +515,34 @@ void spd_factor_invert_f64(spd_args_t a) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v)
                         if (B * j + max(ti + 16 * u, tj + 16 * v) < n) d[u][v] -= P[ti + 16 * u][tj + 16 * v];
+                // (L_j,j-1 for the other roles of row and column j: its stores
+                // have drained behind the product above)
+                if (j > 0) sy.publish(sy.flag_l + j * nb + j - 1);
                 stamp(4);
-                factor_block(d, w, fs);
+                factor_block(d, fs, P, Q);        // (its first barrier is behind these reads of P)
                 stamp(5);
                 // what the roles below and to the right wait for is L_jj^-1
                 double *const li = a.Linv + ((size_t)j << 12);
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int r = ti + 16 * u, c = tj + 16 * v;
-                        st_sc1(li + r * B + c, c <= r ? w[u][v] : 0.0);
-                    }
+                for (int q = 0; q < 16; ++q) {
+                    const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+                    st_sc1(li + e, c <= r ? Q[r][c] * fs.rscal[r] : 0.0);
+                }
                 sy.publish(sy.flag_l + j * nb + j);
                 stamp(6);
                 // (off the critical path: L_jj for the caller and the block's
                 // share of log det L)
-                double lg = 0.0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int r = ti + 16 * u, c = tj + 16 * v;
-                        const int gr = B * j + r, gc = B * j + c;
-                        if (gr < n && gc < n) st_sc1(a.A + (size_t)gr * a.ld + gc, c <= r ? d[u][v] : 0.0);
-                        if (r == c) lg += log(d[u][v]);
-                    }
-                if (ti == tj) red[ti] = lg;
+                for (int q = 0; q < 16; ++q) {
+                    const int e = tid + 256 * q, r = e >> 6, c = e & 63;
+                    const int gr = B * j + r, gc = B * j + c;
+                    if (gr < n && gc < n)
+                        st_sc1(a.A + (size_t)gr * a.ld + gc,
+                               c < r ? P[r][c] * fs.scal[c] : (c == r ? fs.scal[c] : 0.0));
+                }
+                if (tid < 16)
+                    red[tid] = log(fs.scal[tid]) + log(fs.scal[tid + 16]) + log(fs.scal[tid + 32]) +
+                               log(fs.scal[tid + 48]);
                 __syncthreads();
                 if (tid == 0) {
                     double t = 0.0;

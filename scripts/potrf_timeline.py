@@ -1,8 +1,8 @@
 """Timeline of the critical path of `spd_factor_invert_f64` (potrf.hip) from
 its in-kernel wall-clock stamps (100 MHz, the same clock on every compute
-unit): per panel j -- factor of A_jj, hand-over of L_jj^-1 to the owner of
-A_j+1,j, its product and store, hand-over of L_j+1,j to the owner of
-A_j+1,j+1, its product, the next factor.
+unit): per panel j -- factor of A_jj, hand-over of L_jj^-1 to the role of
+the next diagonal block, which makes L_j+1,j and its share of A_j+1,j+1
+itself, the next factor.
 Usage: python scripts/potrf_timeline.py [n]"""
 import os
 import sys
@@ -32,27 +32,18 @@ def role_a(i, j):
 
 
 print(f'n = {n}: first stamp to last stamp {np.nanmax(t):.1f} us')
-print('panel | diag: start lastflag staged mma | factor: begin end published '
-      '| below: flagseen staged trsm published | (all us from launch)')
+print('panel | start | L^-1 of the block above: seen, staged | both products '
+      'done | factor: begin end | L^-1 published   (all us from launch)')
 for j in range(nb):
     d = t[role_a(j, j)]
-    line = (f'{j:3d} | {d[0]:7.1f} {d[1]:7.1f} {d[2]:7.1f} {d[3]:7.1f} | '
-            f'{d[4]:7.1f} {d[5]:7.1f} {d[6]:7.1f}')
-    if j + 1 < nb:
-        b = t[role_a(j + 1, j)]
-        line += f' | {b[5]:7.1f} {b[6]:7.1f} {b[7]:7.1f} {b[8]:7.1f}'
-    print(line)
+    print(f'{j:3d} | {d[0]:7.1f} | {d[1]:7.1f} {d[2]:7.1f} | {d[3]:7.1f} | '
+          f'{d[4]:7.1f} {d[5]:7.1f} | {d[6]:7.1f}')
 dd = np.array([t[role_a(j, j)] for j in range(nb)])
-bb = np.array([t[role_a(j + 1, j)] for j in range(nb - 1)])
 print('means over the panels (us):')
-print(f'  factor_block                         {np.nanmean(dd[:, 5] - dd[:, 4]):6.2f}')
-print(f'  store L_jj, L_jj^-1 + publish        {np.nanmean(dd[:, 6] - dd[:, 5]):6.2f}')
-print(f'  publish -> flag seen below           {np.nanmean(bb[:, 5] - dd[:-1, 6]):6.2f}')
-print(f'  stage L_jj^-1                        {np.nanmean(bb[:, 6] - bb[:, 5]):6.2f}')
-print(f'  product with L_jj^-T                 {np.nanmean(bb[:, 7] - bb[:, 6]):6.2f}')
-print(f'  store L_j+1,j + publish              {np.nanmean(bb[:, 8] - bb[:, 7]):6.2f}')
-print(f'  publish -> flag seen on the diagonal {np.nanmean(dd[1:, 1] - bb[:, 8]):6.2f}')
-print(f'  stage L_j+1,j                        {np.nanmean(dd[1:, 2] - dd[1:, 1]):6.2f}')
-print(f'  product                              {np.nanmean(dd[1:, 3] - dd[1:, 2]):6.2f}')
-print(f'  to the factor layout                 {np.nanmean(dd[1:, 4] - dd[1:, 3]):6.2f}')
-print(f'  panel period                         {np.nanmean(np.diff(dd[:, 6])):6.2f}')
+print(f'  factor_block                              {np.nanmean(dd[:, 5] - dd[:, 4]):6.2f}')
+print(f'  scale + store L_jj^-1 + publish           {np.nanmean(dd[:, 6] - dd[:, 5]):6.2f}')
+print(f'  publish -> flag seen by the next diagonal {np.nanmean(dd[1:, 1] - dd[:-1, 6]):6.2f}')
+print(f'  stage L_jj^-1                             {np.nanmean(dd[1:, 2] - dd[1:, 1]):6.2f}')
+print(f'  L_j+1,j = . L_jj^-T, store, S += L L^T    {np.nanmean(dd[1:, 3] - dd[1:, 2]):6.2f}')
+print(f'  to the factor layout + publish L_j+1,j    {np.nanmean(dd[1:, 4] - dd[1:, 3]):6.2f}')
+print(f'  panel period                              {np.nanmean(np.diff(dd[:, 6])):6.2f}')

@@ -501,14 +501,16 @@ def test_against_the_reference_regressor(device, native):
 
 @pytest.mark.gpu
 def test_native_blocked_cholesky():
-    """potrf.hip (64-column panels, two launches per panel, one workgroup per
-    diagonal block) against
-    torch.linalg.cholesky in float64: sizes around the panel width, the
-    benchmark size, a non-contiguous row stride; a matrix that is not
-    positive definite ends with NaN on the diagonal; the GPR uses it
+    """potrf.hip (round 6: factor AND inverse in one data-flow launch over
+    64 x 64 tiles -- a role per tile, hand-offs through flag words in device
+    memory) against torch.linalg.cholesky / inv in float64: sizes around the
+    tile edge, the benchmark size, a non-contiguous row stride; a matrix that
+    is not positive definite ends with NaN on the diagonal; the launch under
+    uneven load (every word of L and of the inverse checked); the GPR uses it
     (likelihood and gradient equal to the library path's)."""
     import torch
-    from graphdot_amd.model.gaussian_process._potrf import cholesky_
+    from graphdot_amd.model.gaussian_process._potrf import (
+        cholesky_, factor_inverse, read_head)
     g = torch.Generator(device='cuda').manual_seed(0)
     for n in (1, 2, 5, 63, 64, 65, 128, 130, 500, 1000, 1037):
         A = torch.randn(n, n, dtype=torch.float64, device='cuda', generator=g)
@@ -519,6 +521,15 @@ def test_native_blocked_cholesky():
         err = float((L - ref).abs().max() / ref.abs().max())
         assert err < 1e-12, (n, err)
         assert float((L @ L.T - K).abs().max() / K.abs().max()) < 1e-13
+        # the inverse and the log-determinant of the same launch
+        K0 = K.clone()
+        Kinv, head, nb = factor_inverse(K)
+        completed, logdet_l = read_head(head, nb)
+        assert completed and torch.equal(K, K0)        # (input untouched)
+        inv = torch.linalg.inv(K)
+        assert float((Kinv - inv).abs().max() / inv.abs().max()) < 1e-12, n
+        assert float((Kinv - Kinv.T).abs().max()) == 0.0
+        assert abs(2 * logdet_l - float(torch.logdet(K))) < 1e-10 * max(n, 8)
     # row stride larger than n
     big = torch.zeros(200, 256, dtype=torch.float64, device='cuda')
     A = torch.randn(200, 200, dtype=torch.float64, device='cuda', generator=g)
@@ -546,6 +557,7 @@ def test_native_blocked_cholesky():
     hog, side = torch.cuda.Stream(), torch.cuda.Stream()
     B1 = torch.randn(4096, 4096, device='cuda')
     torch.cuda.synchronize()
+    inv = torch.linalg.inv(K)
     for _ in range(3):
         with torch.cuda.stream(hog):
             for _ in range(40):
@@ -553,8 +565,15 @@ def test_native_blocked_cholesky():
         with torch.cuda.stream(side):
             L = torch.tril(cholesky_(K.clone()))
             resid = (L - ref).abs().max() / ref.abs().max()
+            # (6 048 roles on 512 workgroups beside the other stream's
+            # grids: roles are handed out in dependency order, every tile
+            # crosses between workgroups through sc1 stores and a flag word)
+            Kinv, head, nb = factor_inverse(K)
+            resid_inv = (Kinv - inv).abs().max() / inv.abs().max()
         torch.cuda.synchronize()
         assert float(resid) < 1e-12, float(resid)
+        assert float(resid_inv) < 1e-11, float(resid_inv)
+        assert read_head(head, nb)[0]
     # not positive definite
     K = torch.eye(100, dtype=torch.float64, device='cuda')
     K[70, 70] = -1.0
