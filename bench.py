@@ -796,7 +796,7 @@ def main():
                     kernel.eps, kernel.ftol, kernel.gtol, all_jobs, starts,
                     n, n, nJ, traits, pipeline=args.pipeline,
                     shard_plan=sp_),
-                rounds=int(os.environ.get('GD_SHARD_REBALANCE', 2)))
+                rounds=2)
         plan, local_jobs, shard = step.plan, step.local_jobs, step.shard
     else:
         plan = backend.prepare(graphs, knode, kedge, kernel.p, kernel.q,
@@ -1003,6 +1003,16 @@ def main():
                 tr['hbm_bytes_per_launch_fetch_x2'] / dur / 1e9
             roofline['traffic_source'] = 'profiles/traffic.json (rocprofv3 ' \
                 '2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes)'
+            # the other duration basis: the average of the same kernel in the
+            # committed rocprofv3 --kernel-trace --stats summary of this
+            # command (`bench.py --serial`): HIP events run 5-9 % below it
+            if tr.get('rocprof_avg_launch_ms'):
+                rp = tr['rocprof_avg_launch_ms']
+                roofline['rocprof_avg_launch_ms'] = rp
+                roofline['frac_rocprof'] = D['algorithmic_bytes'] / (
+                    rp * 1e-3) / 1e9 / HBM_PEAK_GBS
+                roofline['rocprof_source'] = 'profiles/traffic.json ' \
+                    '(kernel trace of the profiled run, another box)'
     except (OSError, KeyError, ValueError):
         pass
     peak_tf, lds_peak = VALU_PEAK_TF[args.dtype], LDS_PEAK_TBS[args.dtype]

@@ -237,7 +237,12 @@ template<class K> struct packed_edge<K, std::void_t<typename K::packed_edge_t>> 
 template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB, bool NGRAD, bool MAXIMIN, class LAY, class Graph, class NodeK, class EdgeK, class PStart>
 struct oc_solver {
     constexpr static bool STATIC = LAY::is_static;
-    static_assert(!STATIC || W == 1, "static row-batch layouts are one-wave layouts");
+    // (round 6: static layouts of several waves per pair -- graphs of degree
+    // up to 8, value solves: the layout is one compile-time fact for the whole
+    // workgroup and must dominate the trip profile of every one of its waves,
+    // HIPBackend.oc_trips with W > 1)
+    static_assert(!STATIC || W == 1 || (C == 1 && !NGRAD && !MAXIMIN),
+                  "static row-batch layouts of several waves: value solves");
     // FLY (S = 0): no register slots.  The product-graph operator is NOT
     // materialised; the owner of a row walks adj(i1) x adj(i2) in every CG
     // iteration and evaluates the edge microkernel per term, as the reference
@@ -250,10 +255,7 @@ struct oc_solver {
     static_assert(!FLY || (!STATIC && (C == 1 || !NODAL)),
                   "the on-the-fly solver: values (graph-level, nodal with their finite-difference Jacobian, maximin) and graph-level value + gradient");
     constexpr static int SA = S > 0 ? S : 1;    // slot array extent
-#ifndef GD_FLY_U
-#define GD_FLY_U 4
-#endif
-    constexpr static int FLY_U = GD_FLY_U;      // terms per trip of the inner loop
+    constexpr static int FLY_U = 4;             // terms per trip of the inner loop (2 / 4 / 8 measured: 5.06 / 4.95 / 4.33 M pairs/s before the dense product, which walks blocks of four)
     static_assert(!MAXIMIN || (NODAL && C == 1), "the maximin epilogue works on the nodal solution of a value solve");
     using P = params_t<real, Graph, NodeK, EdgeK, PStart>;
     using PF = std::conditional_t<NGRAD, params_fd_t<real, Graph, NodeK, EdgeK, PStart>, P>;
@@ -263,9 +265,6 @@ struct oc_solver {
     using node_t = typename Graph::node_t;
     using edge_t = typename Graph::edge_t;
     constexpr static int T = 64 * W;            // threads per pair (= per workgroup)
-#ifndef GD_FLY_DENSE
-#define GD_FLY_DENSE 1
-#endif
     // DENSE (on-the-fly variants, weighted graphs, direct microkernel
     // evaluation): from_ase-like molecular graphs are 88 % dense, and a pair
     // whose adjacency matrices are more than ~60 % full is cheaper as a DENSE
@@ -292,34 +291,24 @@ struct oc_solver {
     // 3.4 M pairs/s).  In double the software exponential dominates either
     // way and the dense form has 1.3 x as many: 1.81 against 2.26 M pairs/s,
     // off.  Nodal solves (they feed finite differences, whose two sides
-    // should sum in one order) keep the CSR walk.  GD_FLY_DENSE=2: all.
+    // should sum in one order) keep the CSR walk.
     constexpr static unsigned EW = sizeof(edge_t) / 4u;      // words per edge record
     constexpr static unsigned DSTRIDE = 32u;                 // words per row of the dense planes
     constexpr static bool DENSE = FLY && !TAB && GD_WEIGHTED && edge_weight<edge_t>::value && sizeof(edge_t) % 4 == 0 &&
-                                  (GD_FLY_DENSE == 2 || (GD_FLY_DENSE == 1 && sizeof(real) == 4 && !NODAL && !NGRAD && !MAXIMIN));
+                                  sizeof(real) == 4 && !NODAL && !NGRAD && !MAXIMIN;
     // PK2 (dense product, float): the edge microkernel on the records of two
     // columns at once -- difference, square, scale, the weights' product and
     // the products with p as packed instructions (v_pk_add_f32, v_pk_mul_f32,
     // v_pk_fma_f32), 19 vector instructions per trip of four terms against 24
-#ifndef GD_FLY_PK2
-#define GD_FLY_PK2 1
-#endif
-    constexpr static bool PK2 = DENSE && GD_FLY_PK2 != 0 && packed_edge<EdgeK>::value && sizeof(real) == 4;
+    constexpr static bool PK2 = DENSE && packed_edge<EdgeK>::value && sizeof(real) == 4;
     constexpr static int NR = R * T;            // row capacity
     constexpr static int NC = DMAX + 1;         // degree classes 0..DMAX
     constexpr static int NCP = NC * NC;         // degree-pair rectangles
     constexpr static int NTAB = ((NCP + 63) / 64) * 64;
     constexpr static int NM = S > 0 ? (S + 31) / 32 : 1;    // 32-bit flush-mask words
-#ifndef GD_OC_CHUNK
-#define GD_OC_CHUNK 4
-#endif
-#ifndef GD_OC_RCP
-#define GD_OC_RCP 1
-#endif
-#ifndef GD_OC_PIN
-#define GD_OC_PIN 0   // 1: pin every slot's registers (serialises the slots' loads)
-#endif
-    constexpr static int SETUP_CHUNK = GD_OC_CHUNK;
+    // slots whose loads the setup keeps in flight together (the register pins
+    // that keep the scheduler from hoisting all S loads sit at chunk ends)
+    constexpr static int SETUP_CHUNK = 4;
     // slot setup in one pass over running element indices (15 VALU per slot
     // instead of 29 in two passes); the two-pass form keeps fewer registers
     // live and stays where the register file is the limit
@@ -328,18 +317,8 @@ struct oc_solver {
     // the registers for it -- double values (130.6 -> 136.9 M pairs/s) and
     // float value + gradient (89.8 -> 93.3 M); 16 costs the dynamic double
     // gradient kernels and configuration 2's multi-wave ones 10-25 % (spills)
-#ifndef GD_OC_SEQ
-#define GD_OC_SEQ 1   // sequential value + gradient solves (below): 0 off, 1 double, 2 double and float
-#endif
-#ifdef GD_OC_GCH
-    constexpr static int GCH = GD_OC_GCH;
-#else
-    constexpr static int GCH = (STATIC && W == 1 && !NODAL && (sizeof(real) == 8 ? (C == 1 || GD_OC_SEQ != 0) : C == 2)) ? 16 : 8;
-#endif
+    constexpr static int GCH = (STATIC && W == 1 && !NODAL && (sizeof(real) == 8 || C == 2)) ? 16 : 8;
     constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4 && !STATIC && !FLY;
-#ifndef GD_OC_PACK
-#define GD_OC_PACK 1
-#endif
     // Two 16-bit LDS addresses per register (PACK): the 64-slot variants of
     // the 8- and 16-wave workgroups hold S values + S addresses = 128
     // registers per lane in float, the whole budget of a 1024-thread
@@ -351,10 +330,9 @@ struct oc_solver {
     // capped at 128 registers -- a slot is 2 + 1/2 registers instead of 3:
     // configuration 2's (16,40,2) 1.85 -> 1.18 ms, (16,64,3) 1.02 -> 0.88;
     // the 4- and 8-wave variants have the registers and only pay the unpack
-    // (+6 ... 9 %, profiles/sessions.md r4_session8).  GD_OC_PACK=3: double out.
-    constexpr static bool PACK = GD_OC_PACK != 0 && C == 1 && !NODAL && !STATIC && !FLY &&
-                                 ((sizeof(real) == 4 ? (S >= 64 && W >= 8)
-                                                     : (GD_OC_PACK != 3 && W >= 16)) || GD_OC_PACK == 2);
+    // (+6 ... 9 %, profiles/sessions.md r4_session8).
+    constexpr static bool PACK = C == 1 && !NODAL && !FLY &&
+                                 (sizeof(real) == 4 ? ((S >= 64 || (STATIC && S >= 40)) && W >= 8) : W >= 16);
     constexpr static int NADR = PACK ? (S + 1) / 2 : SA;
     // SL: the values of the LAST SL slots of a lane live in a lane-private
     // LDS column instead of registers (round 4; dynamic multi-wave value
@@ -366,21 +344,18 @@ struct oc_solver {
     // one register (two in double); the workgroup's 160 KB of LDS has ~100 KB
     // to spare beside p, the row sums, the row map and the images.  The table
     // is mirrored by HIPBackend.lds_slot_bytes (LDS sizing and the LDS limit
-    // of the classification); -DGD_OC_SL=0 turns it off, =n sets n slots.
+    // of the classification).
     // Configuration 2 in double (profiles/sessions.md r4_session17), 10 slots
     // (80 KB of a 1024-lane workgroup; 12 overflow the 160 KB with (16,64,3)):
     // (16,40,2) 1.19 -> 0.97 ms, (16,64,3) 0.87 -> 0.74 ms, the step 4.95 ->
     // 4.64 ms; 4 / 6 / 8 slots: 4.76 / 4.72 / 4.67 ms.
-#ifndef GD_OC_SL
-#define GD_OC_SL 1
-#endif
     constexpr static int lds_slot_count() {
-        if (GD_OC_SL == 0 || C != 1 || NODAL || NGRAD || STATIC || FLY || W == 1) return 0;
+        if (C != 1 || NODAL || NGRAD || STATIC || FLY || W == 1) return 0;
         // (only where the registers are short by construction: in the 4- and
         // 8-wave variants and in float the allocator answered LDS slots with
         // MORE scratch operations inside the loop, 4 -> 37 in the double
         // (8,64,4), 9 -> 26 in the float (4,64,5))
-        if (sizeof(real) == 8 && W == 16 && (S == 40 || S == 64)) return GD_OC_SL == 1 ? 10 : GD_OC_SL;
+        if (sizeof(real) == 8 && W == 16 && (S == 40 || S == 64)) return 10;
         return 0;
     }
     constexpr static int SL = lds_slot_count();
@@ -403,22 +378,15 @@ struct oc_solver {
     // the sequential form keeps those of one system and the finished solution
     // of the other.  Each system stops at sqrt(rTr) < 1e-10 * 2N / sqrt(2), so
     // that the stacked residual is under the reference's 1e-10 * 2N.
-    constexpr static bool SEQ = C == 2 && STATIC && !NODAL && W == 1 &&
-                                (GD_OC_SEQ == 2 || (GD_OC_SEQ == 1 && sizeof(real) == 8));
+    // (Double only: the float gradient solvers keep the stacked LEAN form,
+    // 52.7 against 52.8 M pairs/s with sequential solves.)
+    constexpr static bool SEQ = C == 2 && STATIC && !NODAL && W == 1 && sizeof(real) == 8;
     constexpr static int CW = SEQ ? 1 : C;      // right-hand sides per CG iteration
-#ifndef GD_OC_SEQ_XLDS
-#define GD_OC_SEQ_XLDS 0
-#endif
-    // SEQ_XLDS (off; measured): the solution being accumulated lives in a
-    // lane-private LDS cell (x += alpha p is a read-modify-write of R cells
-    // per iteration, no bank conflicts) instead of 2 R registers -- what the
-    // four-batch kernel lacks to run three waves per SIMD without reloading
-    // gather addresses from scratch inside the iteration.  It then runs no
-    // faster at three waves (3.08 ms) than with x in registers at two (2.98):
-    // the extra LDS operations cost what the third wave hides; at two waves
-    // the LDS form loses 9 % (profiles/sessions.md r4_session4).
-    constexpr static bool SEQ_XLDS = SEQ && GD_OC_SEQ_XLDS != 0;
-    constexpr static bool LEAN = STATIC && C == 2 && !NODAL && !SEQ;
+    // (Measured and dropped, round 4: the running solution in a lane-private
+    // LDS cell instead of 2 R registers lets the four-batch kernel run three
+    // waves per SIMD without scratch reloads in the loop -- and is no faster
+    // there, 3.08 against 2.98 ms; at two waves it loses 9 %.)
+    constexpr static bool LEAN = STATIC && C == 2 && !NODAL && !SEQ && W == 1;
 #ifndef GD_OC_FSCAL
 #define GD_OC_FSCAL 1
 #endif
@@ -436,35 +404,13 @@ struct oc_solver {
     // were 52 of its 134 vector instructions.
     constexpr static bool FSCAL = GD_OC_FSCAL != 0 && sizeof(real) == 8 && !NGRAD;
     using sreal = std::conditional_t<FSCAL, float, real>;
-#ifndef GD_OC_MIXED
-#define GD_OC_MIXED 0
-#endif
-    // MIXED (double builds, static one-wave value solvers; -DGD_OC_MIXED=1):
-    // iterative refinement.  The system is assembled in double -- slot values
-    // as a float and the float remainder, diagonal and right-hand side in
-    // double -- and solved by the FLOAT iteration of the float build (float
-    // slots, float p in LDS, ds_read_b32 gathers) in rounds: every round
-    // solves A d = r for the current double residual r as far as float goes
-    // (|r'| <= 1e-6 |r|), adds d to the solution in double and recomputes
-    // r -= A d with the double matrix (one pass over the slots); the last
-    // round stops at the caller's sqrt(rTr) < ftol N.  The reference's rule
-    // (marginalized_kernel.h:449) then holds for the TRUE residual.
-    // MEASURED AND LEFT OFF (profiles/sessions.md r4_session14, 1000 QM7-like
-    // graphs, ftol 1e-8): 18.1 float iterations per pair in two rounds, K
-    // within 5.7e-8 of the converged oracle -- and 147 M pairs/s against the
-    // 153 M of the double iteration with float scalars (FSCAL): the float
-    // remainders of the slots and the double diagonal / residual rows make it
-    // a 206-register kernel (the float build's: ~140), i.e. two waves per
-    // SIMD, or three with gather addresses reloaded from scratch inside the
-    // iteration.  Kept compilable (tests/test_parity_gpu.py builds it).
-    constexpr static bool MIXED = GD_OC_MIXED != 0 && sizeof(real) == 8 && STATIC && W == 1 && C == 1 &&
-                                  !NODAL && !NGRAD && !MAXIMIN;
-    constexpr static int MAXR = 4;               // refinement rounds at most
-    using creal = std::conditional_t<MIXED, float, real>;   // arithmetic of the CG iteration
-    constexpr static int NSYS = MIXED ? MAXR : C / CW;   // solves per pair (MIXED: refinement rounds at most)
-#ifndef GD_OC_DLDS
-#define GD_OC_DLDS 1
-#endif
+    // (Measured and dropped, round 4: iterative refinement -- the system in
+    // double, solved by the float iteration in rounds with the residual
+    // recomputed in double between them: correct, 18.1 float iterations in two
+    // rounds, and 147 against 153 M pairs/s of the double iteration with
+    // float scalars: the float remainders of the slots and the double rows
+    // make it a 206-register kernel.  DESIGN.md "tried and dropped".)
+    constexpr static int NSYS = C / CW;          // solves per pair
     // DLDS (the double one-wave static value solver of SIX row batches): the
     // Jacobi diagonal and its inverse -- 2 R reals, 4 R registers, read once
     // per iteration each -- live in lane-private LDS cells ([2 R][T] in the
@@ -477,14 +423,11 @@ struct oc_solver {
     // they did on the five-batch kernel, DESIGN.md "tried and dropped") -- but
     // beside the other launches of a step it overlaps better: 168.5 / 168.0
     // -> 170.4 / 169.9 M pairs/s on the headline, alternating on one box
-    // (profiles/sessions.md r5_session33).  -DGD_OC_DLDS=0: off.
-    constexpr static bool DLDS = GD_OC_DLDS != 0 && sizeof(real) == 8 && STATIC && W == 1 && C == 1 && !NODAL &&
-                                 !NGRAD && !MAXIMIN && !MIXED && !FLY && R == 6;
+    // (profiles/sessions.md r5_session33).
+    constexpr static bool DLDS = sizeof(real) == 8 && STATIC && W == 1 && C == 1 && !NODAL &&
+                                 !NGRAD && !MAXIMIN && !FLY && R == 6;
     constexpr static bool HAS_Y = (!STATIC && !FLY) || LEAN || SEQ || DLDS;   // the [Y] region exists (SEQ: the first system's solution waits there)
     constexpr static int Y_REALS = DLDS ? 2 * R * 64 * W : R * 64 * W * C;    // its size
-#ifndef GD_OC_GRID
-#define GD_OC_GRID 1
-#endif
     // GRID (static layouts whose first batch has DMAX^2 slots): slot
     // s = u DMAX + v of the first batch is the term (u-th nonzero of row i1,
     // v-th nonzero of row i2) of the batch's row, valid if u < d1 and v < d2 --
@@ -495,7 +438,7 @@ struct oc_solver {
     // running-index walk costs 20 VALU per slot, and the setup is a third of
     // a pair's instructions.
     template<class L> constexpr static int grid_slots() {
-        if constexpr (L::is_static && GD_OC_GRID != 0 && !NGRAD) return L::T.end[0] == DMAX * DMAX ? DMAX * DMAX : 0;
+        if constexpr (L::is_static && !NGRAD && ONE_PASS) return L::T.end[0] == DMAX * DMAX ? DMAX * DMAX : 0;
         else return 0;
     }
     constexpr static int G0 = grid_slots<LAY>();
@@ -538,23 +481,16 @@ struct oc_solver {
     // global pointer inside a loop that also stores results, and falls back to
     // vector loads plus v_readfirstlane, with every number derived from the
     // header computed per lane.
-#ifndef GD_OC_SLOAD
-#define GD_OC_SLOAD 1
-#endif
     template<class V> __device__ static __forceinline__ V scalar_load(V const *ptr) {
-        if constexpr (GD_OC_SLOAD != 0) {
-            static_assert(sizeof(V) % 4 == 0, "whole dwords");
-            typedef const unsigned __attribute__((address_space(4))) *const_words;
-            const_words w = (const_words)(std::uintptr_t)ptr;
-            unsigned buf[sizeof(V) / 4];
+        static_assert(sizeof(V) % 4 == 0, "whole dwords");
+        typedef const unsigned __attribute__((address_space(4))) *const_words;
+        const_words w = (const_words)(std::uintptr_t)ptr;
+        unsigned buf[sizeof(V) / 4];
 #pragma unroll
-            for (unsigned k = 0; k < sizeof(V) / 4; ++k) buf[k] = w[k];
-            V out;
-            __builtin_memcpy(&out, buf, sizeof(V));
-            return out;
-        } else {
-            return *ptr;
-        }
+        for (unsigned k = 0; k < sizeof(V) / 4; ++k) buf[k] = w[k];
+        V out;
+        __builtin_memcpy(&out, buf, sizeof(V));
+        return out;
     }
 
     // alpha and beta of the CG recurrence, a / b of two wave-uniform numbers.
@@ -564,14 +500,10 @@ struct oc_solver {
     // correction that the 1e-8 N stopping rule cannot see).
     __device__ static __forceinline__ float cg_ratio(float a, float b) { return a / b; }
     __device__ static __forceinline__ double cg_ratio(double a, double b) {
-#if GD_OC_RCP
         double y = __builtin_amdgcn_rcp(b);
         y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
         y = __builtin_fma(__builtin_fma(-b, y, 1.0), y, y);
         return a * y;
-#else
-        return a / b;
-#endif
     }
 
     // Sorted position of the row that thread `tid` (lane `lane` of wave `wv`)
@@ -606,13 +538,12 @@ struct oc_solver {
         // (static layouts keep the row sums in registers: no Y region, except
         // LEAN, which keeps the solution x there)
         real *const lp = dyn;
-        creal *const lpc = reinterpret_cast<creal *>(dyn);      // p in the arithmetic of the iteration
         real *const lY = lp + (size_t)prm.u_capacity * C;
         unsigned *const rowmap = reinterpret_cast<unsigned *>(lY + (HAS_Y ? (size_t)Y_REALS : (size_t)0));
         char *const lG1 = reinterpret_cast<char *>(rowmap + NR);
         char *const lG2 = lG1 + prm.g_capacity;
         // SL: [SL][T] slot values behind the second image
-        [[maybe_unused]] creal *const lV = reinterpret_cast<creal *>(lG2 + prm.g_capacity);
+        [[maybe_unused]] real *const lV = reinterpret_cast<real *>(lG2 + prm.g_capacity);
         real *const red0 = lds.red[0], *const red1 = lds.red[1];
         using reduce = alternating_reduce<real, W>;
         using sreduce = alternating_reduce<sreal, W>;
@@ -888,11 +819,10 @@ struct oc_solver {
 
             GD_MARK(slots);
             // ---- nonzero slots owned by this thread ---------------------------
-            creal val[SA];
-            [[maybe_unused]] float vlo[MIXED ? SA : 1];   // MIXED: value - float(value)
+            real val[SA];
             unsigned adr[NADR];   // LDS byte address of the gathered element of p (two-pass setup: first (a << 16) | b, or ~0u; PACK: two per register)
             const unsigned lp_off = lds_offset(lp);
-            constexpr unsigned ELEM = CW * sizeof(creal);
+            constexpr unsigned ELEM = CW * sizeof(real);
             unsigned fm[NM];
 #pragma unroll
             for (int w = 0; w < NM; ++w) fm[w] = 0;
@@ -982,18 +912,11 @@ struct oc_solver {
                         col = ok ? __umul24((unsigned)z1.j, (unsigned)ldp) + (unsigned)z2.j : 0u;
                         col = lp_off + col * ELEM;
                         }
-                        if constexpr (MIXED) {
-                            const real ev = ok ? e : real(0);
-                            val[s] = (creal)ev;
-                            vlo[s] = (float)(ev - (real)val[s]);
-                        } else if (SL > 0 && s >= SREG) {
+                        if (SL > 0 && s >= SREG) {
                             lV[(s - SREG) * T + tid] = ok ? e : real(0);
                         } else {
                             val[s] = ok ? e : real(0);
                         }
-#if GD_OC_PIN
-                        asm volatile("" : "+v"(val[s]), "+v"(col));
-#endif
                         if constexpr (PACK) {
                             // (byte addresses below 64 KB: host-checked)
                             if (s % 2 == 0) adr[s / 2] = col;
@@ -1001,7 +924,6 @@ struct oc_solver {
                         } else {
                             adr[s] = col;
                         }
-#if !GD_OC_PIN
                         if (s % SETUP_CHUNK == SETUP_CHUNK - 1 || s == S - 1) {
 #pragma unroll
                             for (int u = s - s % SETUP_CHUNK; u <= s; ++u) {
@@ -1012,7 +934,6 @@ struct oc_solver {
                                 else asm volatile("" : "+v"(val[u]), "+v"(adr[u]));
                             }
                         }
-#endif
                         if (s >= G0) cur.next();
                         if (flush_at(s, fm) && s != S - 1) {   // wave-uniform: next row batch
                             ++kb;
@@ -1040,7 +961,7 @@ struct oc_solver {
                             jb = 0;
                             ++ja;
                         }
-                        if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
+                        if (flush_at(s, fm)) {   // wave-uniform (static layouts: a constant)
                             ++kb;
                             j = ja = jb = 0;
                             cur = open_row(kb);
@@ -1085,11 +1006,9 @@ struct oc_solver {
 
             GD_MARK(rows);
             // ---- rows owned by this thread (sorted order) ----------------------
-            creal dg[R], mi[R], r[CW][R], p[CW][R];
+            real dg[R], mi[R], r[CW][R], p[CW][R];
             real x[C][KEEP_X ? R : 1];
-            [[maybe_unused]] creal xq[(SEQ || MIXED) ? R : 1];   // SEQ / MIXED: the solution of the system being solved
-            // MIXED: the diagonal and the residual b - A x in double
-            [[maybe_unused]] real dgd[MIXED ? R : 1], rd[MIXED ? R : 1];
+            [[maybe_unused]] real xq[SEQ ? R : 1];   // SEQ: the solution of the system being solved
             real pp[KEEP_X ? 1 : R];   // p1(i1) p2(i2) of the rows
             real xs = 0;               // this lane's share of sum_i pp_i x_i
             int paddr[R];
@@ -1097,7 +1016,7 @@ struct oc_solver {
             real rTz = 0;
             unsigned it = 0;
             [[maybe_unused]] sreal rTr_first = 0;   // SEQ: |r|^2 the first solve ended with
-            [[maybe_unused]] const unsigned lv_lane0 = lds_offset(lV) + (unsigned)tid * (unsigned)sizeof(creal);
+            [[maybe_unused]] const unsigned lv_lane0 = lds_offset(lV) + (unsigned)tid * (unsigned)sizeof(real);
 
             // FLY: the owner of row (i1, i2) walks adj(i1) x adj(i2) and
             // evaluates the edge microkernel `ek` per term (per-lane trip
@@ -1287,13 +1206,13 @@ struct oc_solver {
                 }
             };
 
-            auto publish = [&](creal const (&v)[CW][R]) {
+            auto publish = [&](real const (&v)[CW][R]) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    creal e[CW];
+                    real e[CW];
 #pragma unroll
                     for (int c = 0; c < CW; ++c) e[c] = v[c][k];
-                    store_elem<CW>(lpc, (unsigned)paddr[k], e);
+                    store_elem<CW>(lp, (unsigned)paddr[k], e);
                 }
             };
             rTz = 0;
@@ -1311,28 +1230,22 @@ struct oc_solver {
                 // (double: two reciprocals of 6 instructions instead of the two
                 // divisions of 11 the compiler expands -- cg_ratio above)
                 const real dgk = ok ? cg_ratio(dx, vx) : real(0);
-                dg[k] = (creal)dgk;
-                mi[k] = (creal)(ok ? cg_ratio(vx, dx) : real(0));
+                dg[k] = (real)dgk;
+                mi[k] = (real)(ok ? cg_ratio(vx, dx) : real(0));
                 if constexpr (DLDS) {
                     lY[k * T + tid] = dg[k];
                     lY[(R + k) * T + tid] = mi[k];
                 }
                 paddr[k] = ok ? (int)__umul24((unsigned)i1, (unsigned)ldp) + i2 : dump;
                 const real b = ok ? dx * bscale : real(0);
-                if constexpr (MIXED) {
-                    dgd[k] = dgk;
-                    rd[k] = b;
-                    xq[k] = 0;
-                }
-                if constexpr (SEQ_XLDS) lY[NR + k * T + tid] = 0;
-                else if constexpr (SEQ) xq[k] = 0;
+                if constexpr (SEQ) xq[k] = 0;
                 else if constexpr (KEEP_X) x[0][k] = 0;
                 else pp[k] = real(prm.p_start(v1)) * real(prm.p_start(v2));
                 if constexpr (LEAN) {
                     const real zero[C] = {};
                     store_elem<C>(lY, k * T + tid, zero);
                 }
-                r[0][k] = (creal)b;
+                r[0][k] = (real)b;
                 p[0][k] = r[0][k] * mi[k];
                 rTz += real(r[0][k] * p[0][k]);
                 if constexpr (C == 2 && !SEQ) {
@@ -1359,8 +1272,7 @@ struct oc_solver {
                             const unsigned rm = rowmap[ok ? pos : 0];
                             const node_t v1 = at32(g1.node, rm >> 16), v2 = at32(g2.node, rm & 0xFFFFu);
                             const real b = ok ? real(prm.p_start(v1)) * real(prm.p_start(v2)) : real(0);
-                            if constexpr (SEQ_XLDS) lY[NR + k * T + tid] = 0;
-                            else xq[k] = 0;
+                            xq[k] = 0;
                             r[0][k] = b;
                             p[0][k] = b * mi[k];
                             rTz += r[0][k] * p[0][k];
@@ -1377,29 +1289,6 @@ struct oc_solver {
                 // the iteration cap)
                 if constexpr (FSCAL) tol2 = tol2 < sreal(1.17549435e-38f) ? sreal(1.17549435e-38f) : tol2;
                 if constexpr (SEQ) tol2 = sys == 0 ? tol2 * sreal(0.5) : tol2 - rTr_first;
-                [[maybe_unused]] bool last_round = false;
-                if constexpr (MIXED) {
-                    // this round solves A d = rd (round 0: rd = b) in float, as
-                    // far as float goes: |r'| <= 1e-6 |rd|, or the caller's
-                    // tolerance if that comes first -- the last round then
-                    real rr = 0;
-                    rTz = 0;
-#pragma unroll
-                    for (int k = 0; k < R; ++k) {
-                        if (sys > 0) {
-                            r[0][k] = (creal)rd[k];
-                            p[0][k] = r[0][k] * mi[k];
-                            xq[k] = 0;
-                        }
-                        rr += rd[k] * rd[k];
-                        rTz += real(r[0][k] * p[0][k]);
-                    }
-                    const sreal rr_s = sreduce::sum((sreal)rr, sred0);
-                    if (sys > 0 && rr_s < tol2) break;   // the TRUE residual is under the tolerance
-                    const sreal reach = sreal(1e-12) * rr_s;
-                    last_round = tol2 >= reach;
-                    tol2 = last_round ? tol2 : reach;
-                }
                 publish(p);
                 job_sync<W>();   // the previous pair's last reduction is read
                 sreal rTz_s = sreduce::sum((sreal)rTz, sred1);
@@ -1427,7 +1316,7 @@ struct oc_solver {
                     job_sync<W>();   // p published
                     // row sums: sum over the slots of a batch, flushed to the
                     // lane-private cell Y[batch][lane] at wave-uniform positions
-                    [[maybe_unused]] creal ys[CW][(STATIC || FLY) ? R : 1];   // static layouts / FLY: the row sums
+                    [[maybe_unused]] real ys[CW][(STATIC || FLY) ? R : 1];   // static layouts / FLY: the row sums
                     // (static layouts of up to seven batches: every batch is
                     // flushed below, or zeroed where the walk ends early --
                     // zeroing all of them up here was 4 to 7 register moves in
@@ -1448,7 +1337,7 @@ struct oc_solver {
                     if constexpr (FLY) {
                         fly_matvec(prm.edge_kernel, ys);
                     } else {
-                        creal acc[CW];
+                        real acc[CW];
 #pragma unroll
                         for (int c = 0; c < CW; ++c) acc[c] = 0;
                         int kb = 0;
@@ -1483,8 +1372,8 @@ struct oc_solver {
                             // without the fence the scheduler merges their gathers
                             // -- 16 instead of 8 vectors in flight, and spills)
                             if constexpr (STATIC) __builtin_amdgcn_sched_barrier(0);
-                            creal g[CW][GCH];
-                            [[maybe_unused]] creal vl[SL > 0 ? GCH : 1];   // SL: this chunk's LDS-resident values
+                            real g[CW][GCH];
+                            [[maybe_unused]] real vl[SL > 0 ? GCH : 1];   // SL: this chunk's LDS-resident values
                             // (the lane's column address is re-defined here: a
                             // loop-invariant LDS load would be hoisted out of the
                             // iteration -- back into the registers it was to free)
@@ -1493,8 +1382,8 @@ struct oc_solver {
 #pragma unroll
                             for (int jj = 0; jj < GCH; ++jj) {
                                 if (SL > 0 && s0 + jj >= SREG && s0 + jj < S)
-                                    vl[jj] = load_real_at<creal>(lv_lane + (unsigned)((s0 + jj - SREG) * T * (int)sizeof(creal)));
-                                creal e[CW];
+                                    vl[jj] = load_real_at<real>(lv_lane + (unsigned)((s0 + jj - SREG) * T * (int)sizeof(real)));
+                                real e[CW];
 #pragma unroll
                                 for (int c = 0; c < CW; ++c) e[c] = 0;
                                 if (s0 + jj < S) {
@@ -1597,20 +1486,20 @@ struct oc_solver {
                     }
                     // (no barrier: a lane reads back what it wrote itself, and the
                     // LDS operations of one wave execute in order)
-                    creal Ap[CW][R];
-                    creal pAp = 0;
+                    real Ap[CW][R];
+                    real pAp = 0;
                     if constexpr (DLDS) {
-                        unsigned ly_lane = lY_off + (unsigned)tid * (unsigned)sizeof(creal);
+                        unsigned ly_lane = lY_off + (unsigned)tid * (unsigned)sizeof(real);
                         asm volatile("" : "+v"(ly_lane));
 #pragma unroll
                         for (int k = 0; k < R; ++k) {
-                            dg[k] = load_real_at<creal>(ly_lane + (unsigned)(k * T * (int)sizeof(creal)));
-                            mi[k] = load_real_at<creal>(ly_lane + (unsigned)((R + k) * T * (int)sizeof(creal)));
+                            dg[k] = load_real_at<real>(ly_lane + (unsigned)(k * T * (int)sizeof(real)));
+                            mi[k] = load_real_at<real>(ly_lane + (unsigned)((R + k) * T * (int)sizeof(real)));
                         }
                     }
 #pragma unroll
                     for (int k = 0; k < R; ++k) {
-                        creal y[CW];
+                        real y[CW];
                         if constexpr (STATIC || FLY) {
 #pragma unroll
                             for (int c = 0; c < CW; ++c) y[c] = ys[c][k];
@@ -1625,10 +1514,10 @@ struct oc_solver {
                     }
                     const sreal pAp_s = sreduce::sum((sreal)pAp, sred0);
                     if (pAp_s == sreal(0)) break;
-                    const creal alpha = (creal)cg_ratio(rTz_s, pAp_s);
-                    creal rTr = 0, rTz_next = 0;
-                    creal z[CW][R];
-                    if constexpr (!KEEP_X && !MIXED) {
+                    const real alpha = (real)cg_ratio(rTz_s, pAp_s);
+                    real rTr = 0, rTz_next = 0;
+                    real z[CW][R];
+                    if constexpr (!KEEP_X) {
                         real pdot = 0;   // (dead rows carry p = 0)
 #pragma unroll
                         for (int k = 0; k < R; ++k) pdot += pp[k] * p[0][k];
@@ -1641,15 +1530,14 @@ struct oc_solver {
                     for (int k = 0; k < R; ++k)
 #pragma unroll
                         for (int c = 0; c < CW; ++c) {
-                            if constexpr (SEQ_XLDS) lY[NR + k * T + tid] += alpha * p[c][k];
-                            else if constexpr (SEQ || MIXED) xq[k] += alpha * p[c][k];
+                            if constexpr (SEQ) xq[k] += alpha * p[c][k];
                             else if constexpr (KEEP_X) x[c][k] += alpha * p[c][k];
                             r[c][k] -= alpha * Ap[c][k];
                             z[c][k] = mi[k] * r[c][k];
                             rTr += r[c][k] * r[c][k];
                             rTz_next += r[c][k] * z[c][k];
                         }
-                    if constexpr (SEQ && !SEQ_XLDS) {
+                    if constexpr (SEQ) {
                         // (x += alpha p is done HERE: moved behind the update of
                         // p by the scheduler it keeps the old p alive, a copy
                         // per row -- as for xs above)
@@ -1663,7 +1551,7 @@ struct oc_solver {
                         ++its;
                         break;
                     }
-                    creal beta = (creal)cg_ratio(rTz_next_s, rTz_s);
+                    real beta = (real)cg_ratio(rTz_next_s, rTz_s);
                     // (one scalar: without the pin fast-math turns z + beta p into
                     // (p rTz') (1 / rTz) + z, a multiplication more per element)
                     asm volatile("" : "+v"(beta));
@@ -1679,7 +1567,7 @@ struct oc_solver {
                             // (not the sequential value + gradient solves: there
                             // the allocator splits p around the instruction, 2 R
                             // moves instead of none)
-                            if constexpr (sizeof(creal) == 8 && STATIC && W == 1)
+                            if constexpr (sizeof(real) == 8 && STATIC && W == 1)
                                 asm("v_fma_f64 %0, %1, %0, %2" : "+v"(p[c][k]) : "v"(beta), "v"(z[c][k]));
                             else
                                 p[c][k] = z[c][k] + beta * p[c][k];
@@ -1690,37 +1578,13 @@ struct oc_solver {
                     rTz_s = rTz_next_s;
                 }
                 it += its;
-                if constexpr (MIXED) {
-                    // x += d in double: K accumulates pp . d
-                    real pd = 0;
-#pragma unroll
-                    for (int k = 0; k < R; ++k) pd += pp[k] * real(xq[k]);
-                    xs += pd;
-                    if (last_round || sys == NSYS - 1) break;
-                    // rd -= A d with the double matrix: d published as float
-                    // (one wave: its LDS operations execute in order), the slot
-                    // values as float + float remainder, sums and diagonal in
-                    // double
-#pragma unroll
-                    for (int k = 0; k < R; ++k) lpc[paddr[k]] = xq[k];
-                    int s_ = 0;
-#pragma unroll
-                    for (int kb = 0; kb < R; ++kb) {
-                        real acc = 0;
-#pragma unroll
-                        for (; s_ < LAY::T.end[kb]; ++s_)
-                            acc += (real(val[s_]) + real(vlo[s_])) * real(load_real_at<creal>(adr[s_]));
-                        rd[kb] -= dgd[kb] * real(xq[kb]) - acc;
-                    }
-                }
                 if constexpr (SEQ) {
                     // the first solution waits in a lane-private LDS cell (its
                     // R reals would be live across the whole second solve)
                     if (sys == 0) {
 #pragma unroll
                         for (int k = 0; k < R; ++k) {
-                            if constexpr (SEQ_XLDS) lY[k * T + tid] = lY[NR + k * T + tid];
-                            else lY[k * T + tid] = xq[k];
+                            lY[k * T + tid] = xq[k];
                         }
                     }
                 }
@@ -1728,8 +1592,7 @@ struct oc_solver {
             if constexpr (SEQ) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) {
-                    if constexpr (SEQ_XLDS) x[1][k] = lY[NR + k * T + tid];
-                    else x[1][k] = xq[k];
+                    x[1][k] = xq[k];
                     x[0][k] = lY[k * T + tid];
                 }
             }

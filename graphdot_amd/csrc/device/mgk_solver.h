@@ -333,23 +333,14 @@ struct pair_solver {
     using edge_t = typename Graph::edge_t;
     constexpr static int T = 64 * W;   // threads per pair
     constexpr static int NV = R * T;   // capacity of p (rows)
-#ifndef GD_WPB
-#define GD_WPB 1
-#endif
-    constexpr static int WPB = (W == 1) ? GD_WPB : 1;  // independent pairs per workgroup
+    constexpr static int WPB = 1;                 // independent pairs per workgroup (four one-wave pairs per 256-thread workgroup: 4-5 % slower, round 1)
     constexpr static int threads = 64 * W * WPB;
     constexpr static int NM = (S + 31) / 32;      // 32-bit flush-mask words
     constexpr static int SETUP_CHUNK = 4;
-#ifndef GD_GCH
-#define GD_GCH 8
-#endif
-    constexpr static int GCH = GD_GCH;            // stage-1 gathers in flight
+    constexpr static int GCH = 8;                 // stage-1 gathers in flight
     constexpr static int ZPAD = 64;               // zero entries at the end of U
     constexpr static int DU = 4;                  // stage-2 degree bound of the unrolled path
-#ifndef GD_RCH
-#define GD_RCH 2
-#endif
-    constexpr static int RCH = GD_RCH;            // rows whose stage-2 reads are in flight together
+    constexpr static int RCH = 2;                 // rows whose stage-2 reads are in flight together
     // one wave per pair, one float per entry: stores of U and p go through M0
     constexpr static bool ADDTID = W == 1 && C == 1 && sizeof(real) == 4;
     constexpr static int n_jac = PStart::jac_dims + 1 + NodeK::jac_dims + EdgeK::jac_dims;

@@ -80,21 +80,11 @@ struct stream_solver {
     // -- 122 -> 100.6 ms, 136 pairs 63.7 -> 43.7 ms, one pair 1.13 -> 0.87 ms,
     // value + gradient of 36 pairs 60.5 -> 40.6 ms.  Double: 8 rows too (316
     // -> 303 ms on the 528 pairs, although more of B's images then stay in L2).
-#ifdef GD_STREAM_ROWS
-    constexpr static int A_ROWS = GD_STREAM_ROWS;
-#else
-    constexpr static int A_ROWS = 8;
-#endif
+    constexpr static int A_ROWS = 8;                  // (HIPBackend STREAM_ROWS)
 
-#ifndef GD_STREAM_CAP
-#define GD_STREAM_CAP 16
-#endif
-    constexpr static int SEG_CAP = GD_STREAM_CAP;     // neighbours of B per lane segment (doubled until the segments fit)
+    constexpr static int SEG_CAP = 16;                    // neighbours of B per lane segment (doubled until the segments fit)
     constexpr static int MAX_LAYERS = 64;             // nB <= TPB = 1024 = 64 * 16
-#ifndef GD_STREAM_LDS_BUDGET
-#define GD_STREAM_LDS_BUDGET (159 * 1024)
-#endif
-    constexpr static unsigned LDS_BUDGET = GD_STREAM_LDS_BUDGET;   // dynamic LDS a pair may ask for (HIPBackend.stream_lds_bytes)
+    constexpr static unsigned LDS_BUDGET = 159 * 1024;   // dynamic LDS a pair may ask for (HIPBackend.stream_lds_bytes)
 
     struct lds_t {
         real red[2 * W];

@@ -279,8 +279,6 @@ def _build_collector():
     import importlib.machinery
     import importlib.util
     import sysconfig
-    if os.environ.get('GD_NATIVE_COLLECT', '1') == '0':
-        return False
     src = os.path.join(CSRC, 'gdcollect.cpp')
     suffix = sysconfig.get_config_var('EXT_SUFFIX') or '.so'
     out = os.path.join(CSRC, '_gdcollect' + suffix)

@@ -83,9 +83,12 @@ def stream_parts(costs, count, resident, queued):
     return best
 
 
-def OCStatic(*L, D=4):
-    """One-wave owner-computes variant with the static layout L."""
-    return OCVariant(1, int(sum(L)), len(L), D, tuple(int(x) for x in L))
+def OCStatic(*L, D=4, W=1):
+    """Owner-computes variant with the static layout L: batch k of every wave
+    owns exactly L[k] slots (one wave per pair unless W says otherwise --
+    round 6: multi-wave layouts for graphs of degree up to 8, value solves;
+    the layout must dominate the trip profile of EVERY wave of the pair)."""
+    return OCVariant(int(W), int(sum(L)), len(L), D, tuple(int(x) for x in L))
 
 
 #: register-resident solver menu, cheapest first.  A pair fits a variant if
@@ -136,7 +139,7 @@ OC_VARIANTS = OC_STATIC_VARIANTS + [
 ] + OC_FLY_VARIANTS
 #: pairs with a node of more than this many neighbours are what the
 #: on-the-fly variants are for (the slot variants stop at degree 8)
-FLY_MIN_DEGREE = int(os.environ.get('GD_FLY_MIN_DEGREE', 8))
+FLY_MIN_DEGREE = 8
 #: sentinel: the global-memory general solver (any pair size)
 GENERAL = Variant(0, 0, 0)
 #: sentinel: the kernel that fills the global microkernel tables
@@ -149,11 +152,10 @@ GENERAL_THREADS = 1024
 #: molecular set (scripts/mfma_experiment.py).  GD_MFMA=0: off.
 MFMA = Variant(-3, 0, 0)
 MFMA_MAX_NODES = 32
-DLDS_DEFAULT = True       # mgk_oc.h GD_OC_DLDS
 #: sentinel: the streamed solver for large pairs (csrc/device/mgk_stream.h):
 #: value solves of pairs beyond every register- and LDS-resident variant; one
 #: graph of the pair staged in LDS, the other streamed row by row, CG vectors
-#: in a global scratch.  GD_STREAM=0: those pairs take the general solver.
+#: in a global scratch.
 STREAM = Variant(-2, 0, 0)
 STREAM_THREADS = 1024
 #: rows of p staged per pass and row group (mgk_stream.h A_ROWS)
@@ -165,11 +167,11 @@ STREAM_MAX_PARTS = 256
 #: dynamic LDS a pair of the streamed solver may ask for (mgk_stream.h LDS_BUDGET)
 STREAM_LDS_BUDGET = 159 * 1024
 LDS_LIMIT = 160 * 1024
-_LARGE_PAIR_SOLVERS = [MFMA] + (
-    [STREAM] if os.environ.get('GD_STREAM', '1') != '0' else []) + [GENERAL]
-#: independent pairs (waves) per workgroup of the one-wave variants;
-#: mgk_solver.h reads the same number from GD_WPB
-WPB1 = int(os.environ.get('GD_WPB', 1))
+_LARGE_PAIR_SOLVERS = [MFMA, STREAM, GENERAL]
+#: independent pairs (waves) per workgroup of the one-wave variants (mgk_solver.h
+#: WPB; four pairs per 256-thread workgroup were 4-5 % slower: a workgroup's
+#: LDS and wave slots are only released when its slowest pair is done)
+WPB1 = 1
 #: microkernel value tables (label classes) are used when they fit this much
 #: LDS per workgroup: (n_node_classes^2 + n_edge_classes^2) reals
 TABLE_LDS_LIMIT = 8 * 1024
@@ -410,7 +412,7 @@ class LaunchSet:
         # lowest priority: what overlaps them on the null stream -- a chain of
         # small dependent launches, the Cholesky factorisation -- gets compute
         # units as soon as it has a workgroup to dispatch instead of queueing
-        # behind the solver grids (GD_DETACHED_PRIORITY=0: normal streams)
+        # behind the solver grids
         self.low_streams, self.low_done = [], []
         self._last_done = self.done
         self.start = runtime.Event()
@@ -464,7 +466,7 @@ class LaunchSet:
         hint = getattr(plan, 'stream_hint', None)
         if hint and not self.streams_forced:
             ns = max(1, min(ns, hint))
-        low = detached and os.environ.get('GD_DETACHED_PRIORITY', '1') != '0'
+        low = detached
         streams, done, spool, epool = (
             (self.low_streams, self.low_done, _LOW_STREAM_POOL,
              _LOW_EVENT_POOL) if low else
@@ -562,17 +564,11 @@ class HIPBackend(Backend):
         self.device = kwargs.pop('device', None)
         self.real = np.dtype(kwargs.pop('real', np.float32)).type
         self.jobs_per_unit = int(kwargs.pop(
-            'jobs_per_unit', os.environ.get('GD_JOBS_PER_UNIT', 1)))
+            'jobs_per_unit', 1))
         self.hipcc_extra = list(kwargs.pop('hipcc_extra', [])) + \
             os.environ.get('GD_HIPCC_EXTRA', '').split()
         self.variants = list(kwargs.pop(
             'variants', OC_VARIANTS + VARIANTS + _LARGE_PAIR_SOLVERS))
-        if os.environ.get('GD_OC') == '0':        # experiments: two-stage only
-            self.variants = [v for v in self.variants
-                             if not isinstance(v, OCVariant)]
-        if os.environ.get('GD_OC_STATIC') == '0':  # experiments: dynamic only
-            self.variants = [v for v in self.variants
-                             if not (isinstance(v, OCVariant) and v.L)]
         if os.environ.get('GD_VARIANTS'):  # experiments: "W:S:R[:D],L16x4x1,..."
             def parse(item):
                 if item.startswith('L'):
@@ -595,9 +591,6 @@ class HIPBackend(Backend):
         #       expensive than a Gaussian); the owner-computes menu is off;
         #   False: every microkernel value is evaluated where it is used.
         tables = kwargs.pop('tables', 'global')
-        if os.environ.get('GD_TABLES'):           # experiments
-            tables = {'0': False, '1': 'lds'}.get(os.environ['GD_TABLES'],
-                                                  os.environ['GD_TABLES'])
         if tables is True:
             tables = 'lds'
         if tables not in (False, 'lds', 'global'):
@@ -612,7 +605,11 @@ class HIPBackend(Backend):
         # launch order): libgdhost.so (csrc/gdhost.cpp), or -- native=False --
         # the numpy restatements it is tested against
         self.native = bool(kwargs.pop(
-            'native', os.environ.get('GD_NATIVE_HOST', '1') != '0'))
+            'native', True))
+        #: static row-batch layouts of several waves per pair, made to measure
+        #: per job list (`_refine_static`): True, False or a list of layouts
+        self.multiwave_static = kwargs.pop('multiwave_static', True)
+        self._static_parent = {}
         if self.native:
             from ...hip import hostlib
             hostlib.lib()                  # fail loudly if it cannot be built
@@ -1008,15 +1005,14 @@ struct ${name}_t : ${name}_theta_t {
     #: faster than the dynamic one (14.3 / 18.4 / 22.7 ns per pair for the
     #: three- / four- / five-batch pairs against 14.5 / 17.2 / 21.7).  The
     #: static double kernels now solve the two systems one after the other
-    #: (mgk_oc.h SEQ) and are back in the menu; GD_OC_SEQ=0 restores round 3.
-    _STATIC_OFF = {(True, 2): {v.L for v in OC_STATIC_VARIANTS}} \
-        if os.environ.get('GD_OC_SEQ') == '0' else {}
+    #: (mgk_oc.h SEQ) and are back in the menu.
+    _STATIC_OFF = {}
 
     def _static_enabled(self, v, C):
         f64 = np.dtype(self.real) == np.float64
         return v.L not in self._STATIC_OFF.get((f64, C), ())
 
-    _FLY_WAVES = int(os.environ.get('GD_FLY_WAVES', 3))
+    _FLY_WAVES = 3     # (occupancy 3-6 waves per SIMD: 4.95-4.86 M pairs/s, round 3)
 
     def _oc_waves(self, v, C, ngrad=False):
         """Occupancy target of an owner-computes variant: per lane S values +
@@ -1024,6 +1020,8 @@ struct ${name}_t : ${name}_theta_t {
         the publish address), the gathers in flight and ~24 others; a double
         takes two registers."""
         f64 = np.dtype(self.real) == np.float64
+        if v in self._static_parent:
+            return self._oc_waves(self._static_parent[v], C, ngrad)
         if v.S == 0:
             # on-the-fly kernels: no slot arrays, but the unrolled term loops
             # keep ~140 registers busy (spill-free at three waves per SIMD)
@@ -1141,7 +1139,6 @@ void ${name}(params_t prm) {
         # float builds: the edge microkernel on two records at once where the
         # record and the expression allow it (mgk_oc.h, dense product)
         if (np.dtype(self.real) == np.float32 and packable(edge_t)
-                and os.environ.get('GD_PACKED_EDGES', '1') != '0'
                 and packed_expression(to_real_expr(
                     edge_kernel.gen_expr('x1', 'x2')[0], 'float32'))):
             edge2_t = '\n' + declstruct2(edge_t, 'edge2_t')
@@ -1152,7 +1149,6 @@ void ${name}(params_t prm) {
         return Template(_TEMPLATE).render(
             real=_real_name(self.real),
             weighted='1' if weighted else '0',
-            wpb=WPB1,
             node_t=declstruct(node_t, 'node_t'),
             edge_t=declstruct(edge_t, 'edge_t') + edge2_t,
             node_kernel=self.gencode_kernel(node_kernel, 'node_kernel',
@@ -1243,12 +1239,7 @@ void ${name}(params_t prm) {
         if (isinstance(v, OCVariant) and not v.L and C == 1 and v.W == 16
                 and not nodal
                 and v.S in (40, 64) and np.dtype(self.real) == np.float64):
-            n = 10
-            for f in self.hipcc_extra:           # (-DGD_OC_SL=n: experiments)
-                if f.startswith('-DGD_OC_SL='):
-                    n = int(f.split('=')[1])
-                    n = 10 if n == 1 else n
-            return n * 64 * v.W * 8
+            return 10 * 64 * v.W * 8
         return 0
 
     def _waves_without_lds_diagonals(self, v, C, nodal):
@@ -1268,13 +1259,7 @@ void ${name}(params_t prm) {
         """mgk_oc.h DLDS: the double one-wave static value solver of six row
         batches keeps the Jacobi diagonal and its inverse in lane-private LDS
         cells (2 R reals per lane in the [Y] region)."""
-        on = DLDS_DEFAULT
-        for f in self.hipcc_extra:               # (-DGD_OC_DLDS=n: experiments)
-            if f.startswith('-DGD_OC_DLDS='):
-                on = int(f.split('=')[1]) != 0
-            if f.startswith('-DGD_OC_MIXED=') and int(f.split('=')[1]) != 0:
-                on = False                       # (the refinement build keeps them)
-        return bool(on and isinstance(v, OCVariant) and v.L and v.W == 1
+        return bool(isinstance(v, OCVariant) and v.L and v.W == 1
                     and v.R == 6 and C == 1 and not nodal
                     and np.dtype(self.real) == np.float64)
 
@@ -1327,12 +1312,32 @@ void ${name}(params_t prm) {
         return worst
 
     @staticmethod
-    def oc_trips(hist1, hist2, D, nb):
-        """Per-batch trip counts of the one-wave owner-computes walk: entry
-        [t, k] is the degree product of the first row of batch k (rows
-        64 k ...) of job t in the sorted row order, 0 for batches without
-        rows.  A static layout L fits job t iff trips[t, k] <= L[k] for all
-        k < len(L) and the job has no rows beyond 64 len(L)."""
+    def oc_trips(hist1, hist2, D, nb, W=1):
+        """Per-batch trip counts of the owner-computes walk: entry [t, k] is
+        the degree product of the first row of batch k (rows 64 k ...) of job
+        t in the sorted row order, 0 for batches without rows.  A static
+        layout L fits job t iff trips[t, k] <= L[k] for all k < len(L) and the
+        job has no rows beyond 64 W len(L).  W > 1: batches of 64 W rows whose
+        64-row chunks go to the waves in snake order (mgk_oc.h row_pos); the
+        entry is the LARGEST trip count among the W waves of batch k -- a
+        static layout is compile-time code, one for the whole workgroup."""
+        if W > 1:
+            order = sorted(((a, b) for a in range(D + 1) for b in range(D + 1)),
+                           key=lambda t: -t[0] * t[1])
+            prods = np.array([a * b for a, b in order] + [0], dtype=np.int64)
+            sizes = hist1[:, [a for a, _ in order]] * hist2[:, [b for _, b in order]]
+            cum = np.cumsum(sizes, axis=1)
+            if len(cum) == 0:
+                return np.zeros((0, nb), dtype=np.int64)
+            out = np.zeros((len(cum), nb), dtype=np.int64)
+            kk = np.arange(nb, dtype=np.int64)
+            for w in range(W):
+                first = kk * 64 * W + 64 * np.where(kk % 2 == 1, W - 1 - w, w)
+                c = (cum[:, None, :] <= first[None, :, None]).sum(axis=2)
+                live = first[None, :] < cum[:, -1:]
+                out = np.maximum(out, np.where(
+                    live, prods[np.minimum(c, len(order))], 0))
+            return out
         order = sorted(((a, b) for a in range(D + 1) for b in range(D + 1)),
                        key=lambda t: -t[0] * t[1])
         prods = np.array([a * b for a, b in order] + [0], dtype=np.int64)
@@ -1453,7 +1458,8 @@ void ${name}(params_t prm) {
             count = np.bincount(pk, minlength=nc * nc)
         upk = np.flatnonzero(count)
         out = self._classify_pairs(rep[upk // nc], rep[upk % nc], dgraphs, C,
-                                   tab_bytes, gtab, oc_only, nodal, mfma)
+                                   tab_bytes, gtab, oc_only, nodal, mfma,
+                                   weights=count[upk])
         return ClassPairs(pk, upk, count, nc), out
 
     #: row batches the trip tables cover (static layouts have at most this many)
@@ -1471,9 +1477,11 @@ void ${name}(params_t prm) {
             hists[D] = (H, hid.reshape(-1))
         return hists[D]
 
-    def _trip_table(self, ji, jj, dgraphs, maxdeg, pair_maxdeg, D, hists):
+    def _trip_table(self, ji, jj, dgraphs, maxdeg, pair_maxdeg, D, hists,
+                    W=1):
         """(trips per distinct histogram pair in use, row of every job in
-        that table or -1 if a graph of the job exceeds degree D)."""
+        that table or -1 if a graph of the job exceeds degree D).  W > 1: the
+        batch-wise maximum over the W waves of a pair (`oc_trips`)."""
         H, hid = self._degree_hists(dgraphs, maxdeg, D, hists)
         nH = len(H)
         row = np.full(len(ji), -1, dtype=np.int64)
@@ -1481,11 +1489,90 @@ void ${name}(params_t prm) {
         pk = hid[ji[idx]] * nH + hid[jj[idx]]
         upk, inv = np.unique(pk, return_inverse=True)
         row[idx] = inv.reshape(-1)
-        tr = self.oc_trips(H[upk // nH], H[upk % nH], D, self.TRIP_BATCHES)
+        tr = self.oc_trips(H[upk // nH], H[upk % nH], D, self.TRIP_BATCHES,
+                           W)
         return tr, row
 
+    #: a profile-guided static layout must serve at least this many waves
+    #: (pairs x waves per pair: the launch-merging threshold), and a pair may
+    #: walk at most this share of slots more than its own profile has
+    STATIC_MIN_WAVES = 8192
+    STATIC_MAX_PADDING = 0.12
+    STATIC_MAX_LAYOUTS = 4        # per dynamic variant they are taken from
+
+    def _refine_static(self, choice, ji, jj, dgraphs, C, N, maxdeg,
+                       pair_maxdeg, hists, weights, nodal):
+        """Round 6: static row-batch layouts of SEVERAL waves per pair, made
+        to measure.  The molecular menu (OC_STATIC_VARIANTS) is a fixed list
+        because molecular degree products fall into eleven profiles; graphs of
+        degree 5-8 (configuration 2: reference
+        benchmark/kernel/marginalized/time_kernel.py:14-29) have other
+        profiles -- but few of them per set (scripts/config2_trip_profiles.py:
+        20-30 per dynamic launch, the six most common ones under one
+        layout).  After the regular classification, for every dynamic D > 4
+        multi-wave value launch: the workgroup trip profiles of its pairs
+        (batch-wise maximum over the waves, `oc_trips`), most common first; a
+        layout takes the profiles it dominates at <= 12 % more slots than the
+        pair needs; layouts that collect fewer than STATIC_MIN_WAVES waves
+        are dropped.  The layouts become variants of this backend (appended
+        to `self.variants`; their code is compiled on first use and cached
+        like any other).  `self.multiwave_static`: True (default), False, or
+        an explicit list of `OCStatic(..., W=)` to choose from."""
+        mode = self.multiwave_static
+        if not mode or C != 1 or nodal or len(choice) == 0:
+            return choice
+        f64 = np.dtype(self.real) == np.float64
+        if weights is None:
+            weights = np.ones(len(choice), dtype=np.int64)
+        choice = choice.copy()
+        for k in sorted(set(choice.tolist())):
+            v = self.variants[k] if k >= 0 else None
+            if not (isinstance(v, OCVariant) and not v.L and v.S > 0
+                    and v.W > 1 and v.D > 4):
+                continue
+            # (double, 16 waves: the dynamic kernels keep slot values in LDS
+            # to stay under the 128-register cap -- SL; static ones do not)
+            if f64 and v.W >= 16:
+                continue
+            idx = np.flatnonzero(choice == k)
+            tr, row = self._trip_table(ji[idx], jj[idx], dgraphs, maxdeg,
+                                       pair_maxdeg[idx], v.D, hists, v.W)
+            prof = tr[row]                              # (len(idx), nb)
+            need = prof.sum(axis=1)
+            w = weights[idx]
+            uniq, inv = np.unique(prof, axis=0, return_inverse=True)
+            inv = inv.reshape(-1)
+            pop = np.bincount(inv, weights=w, minlength=len(uniq))
+            if isinstance(mode, (list, tuple)):
+                cands = [np.array(list(x.L) + [0] * (prof.shape[1] - len(x.L)))
+                         for x in mode if x.W == v.W and x.D == v.D]
+            else:
+                cands = [uniq[u] for u in np.argsort(-pop)]
+            free = np.ones(len(idx), dtype=bool)
+            made = 0
+            for cand in cands:
+                if made >= self.STATIC_MAX_LAYOUTS or not free.any():
+                    break
+                L = tuple(int(x) for x in cand if x > 0)
+                if not L or sum(L) > 64:      # (larger slot arrays stay in scratch)
+                    continue
+                ok = free & (prof <= cand[None, :]).all(axis=1) & \
+                    (N[idx] <= 64 * v.W * len(L)) & \
+                    (sum(L) <= (1 + self.STATIC_MAX_PADDING) * need)
+                if w[ok].sum() * v.W < self.STATIC_MIN_WAVES:
+                    continue
+                sv = OCStatic(*L, D=v.D, W=v.W)
+                if sv not in self.variants:
+                    self.variants.append(sv)
+                # (occupancy target: that of the dynamic variant it relieves)
+                self._static_parent[sv] = v
+                choice[idx[ok]] = self.variants.index(sv)
+                free &= ~ok
+                made += 1
+        return choice
+
     def _classify_pairs(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
-                        oc_only=False, nodal=False, mfma=False):
+                        oc_only=False, nodal=False, mfma=False, weights=None):
         f = graph_features(dgraphs)
         n_node, n_nz = f['n_node'], f['n_nz']
         deg_sorted = None      # (the two-stage variants' walk: made on demand)
@@ -1511,7 +1598,7 @@ void ${name}(params_t prm) {
         oc_slots, hists, trips = {}, {}, {}
         # (the on-the-fly kernels have every flavour of the slot kernels but
         # the static layouts)
-        fly_off = os.environ.get('GD_OC_FLY') == '0'
+        fly_off = False
         # `rem`: the jobs without a variant yet -- every test below runs on
         # that shrinking subset only (most jobs leave in the first variants)
         rem = np.arange(len(ji))
@@ -1571,10 +1658,11 @@ void ${name}(params_t prm) {
                 if v.L:
                     # static layout: the trip count of every batch under its
                     # segment (looked up per pair of distinct histograms)
-                    if v.D not in trips:
-                        trips[v.D] = self._trip_table(
-                            ji, jj, dgraphs, maxdeg, pair_maxdeg, v.D, hists)
-                    tr, row = trips[v.D]
+                    if (v.D, v.W) not in trips:
+                        trips[v.D, v.W] = self._trip_table(
+                            ji, jj, dgraphs, maxdeg, pair_maxdeg, v.D, hists,
+                            v.W)
+                    tr, row = trips[v.D, v.W]
                     idx = rem[fits]
                     ok = row[idx] >= 0
                     L = np.zeros(tr.shape[1], dtype=np.int64)
@@ -1633,6 +1721,9 @@ void ${name}(params_t prm) {
             choice[dense] = self.variants.index(MFMA)
             gbytes = np.where(dense, np.maximum(f['image_bytes'][ji],
                                                 f['image_bytes'][jj]), gbytes)
+        if not tab_bytes and not oc_only:
+            choice = self._refine_static(choice, ji, jj, dgraphs, C, N, maxdeg,
+                                         pair_maxdeg, hists, weights, nodal)
         if np.any(choice < 0) and oc_only:
             raise NotOwnerComputes
         if np.any(choice < 0):

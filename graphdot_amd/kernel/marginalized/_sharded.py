@@ -171,7 +171,7 @@ def partition(cost, world_size, mode=None):
     a rank gets pairs of similar size, i.e. of one or two solver variants
     (fewer, larger launches per rank), and is as well balanced as the cost
     model is accurate."""
-    mode = mode or os.environ.get('GD_SHARD_MODE', 'snake')
+    mode = mode or 'snake'
     order = np.argsort(-cost, kind='stable')
     if mode == 'blocks':
         c = np.cumsum(cost[order], dtype=np.float64)
@@ -206,7 +206,6 @@ class ShardPlan:
         self.merge_map = merge_map
         cost = predict_cost(np.asarray(n_node), np.asarray(n_nz),
                             self.ji, self.jj)
-        mode = mode or os.environ.get('GD_SHARD_MODE')
         self.mode = 'snake'
         if launch_order is not None and mode in (None, 'measured'):
             lo = np.asarray(launch_order, dtype=np.int64)
@@ -333,13 +332,20 @@ def measured_shard_plan(backend, graphs, node_kernel, edge_kernel, jobs, nX,
     (`cost_table`), and the ranks take contiguous blocks of that order with
     equal predicted time.  Host only and deterministic: every rank computes
     the same plan."""
+    edge_kernel_in = edge_kernel
     dgraphs, edge_kernel, C, fields = backend._graphs_and_kernels(
         graphs, node_kernel, edge_kernel, traits)
     arena = backend._host_arena(dgraphs, fields)     # (host only: no upload)
     tab_bytes = backend._table_bytes(arena)
     gtab = backend._global_tables(arena)
     jobs = np.ascontiguousarray(jobs)
-    part = backend._partition(dgraphs, jobs, C, tab_bytes, gtab)
+    # (the classification `prepare` itself makes: nodal traits size the LDS
+    # regions differently, a label-blind edge kernel adds the MFMA variant --
+    # without them the merge map, and with it which solver a pair runs on,
+    # differed from a plain HIPBackend's for such calls)
+    part = backend._partition(dgraphs, jobs, C, tab_bytes, gtab,
+                              nodal=traits.nodal is not False,
+                              mfma=backend._label_blind(edge_kernel_in))
     _, used, order_all, launches = part
     merge_map = dict(part.merge_map)
     ji, jj = jobs['i'].astype(np.int64), jobs['j'].astype(np.int64)
@@ -731,24 +737,22 @@ def distributed_backend(**kwargs):
             #: rounds of measured re-balancing when a sharded step is first
             #: built (every rank times its shard, the times are all-gathered,
             #: the cuts are taken again: ShardPlan.rebalanced)
-            self.rebalance = int(os.environ.get('GD_SHARD_REBALANCE',
-                                                rebalance))
+            self.rebalance = int(rebalance)
             #: job lists shorter than this per rank are not re-balanced
-            self.rebalance_min_jobs = int(os.environ.get(
-                'GD_SHARD_REBALANCE_MIN_JOBS', 4096))
+            self.rebalance_min_jobs = 4096
             #: consumers that factor the kernel matrix (model.gaussian_process)
             #: may overlap the factorisation with the gradient solves: values
             #: first (their own sharded step), then the value + gradient
             #: solvers detached beside the dense algebra.  OFF by default
             #: (None): measured on one GPU with the shards of a world of
-            #: eight (scripts/gpr_step_sim.py, profiles/r05_gpr_step_sim_*),
-            #: the overlapped step takes 2.96 ms against 2.51 ms one after
-            #: the other -- the factorisation's chain of ~50 small dependent
-            #: launches does not run beside the solver grids, it queues
-            #: behind them (low-priority solver streams: no difference), and
-            #: the value step is paid on top.  GD_GPR_OVERLAP=1 or
-            #: `overlap_min_ranks = n` turn it on for a measurement on real
-            #: ranks.
+            #: eight (scripts/gpr_step_sim.py), the overlapped step takes
+            #: 2.44 ms against 1.63 ms one after the other with round 6's
+            #: one-launch factorisation (profiles/r06_gpr_step_sim_f64.log;
+            #: round 5, with its chain of ~50 launches: 2.96 against 2.51) --
+            #: the value step is paid on top, and a factorisation that is one
+            #: latency-bound chain gains nothing from compute units it shares
+            #: with the solver grids.  `overlap_min_ranks = n` turns it on for
+            #: a measurement on real ranks.
             self.overlap_min_ranks = None
             self._shard_plans = {}
             self._steps = {}      # (shard plan, nJ, traits) -> ShardedStep
@@ -769,9 +773,6 @@ def distributed_backend(**kwargs):
 
         def overlaps_dense_algebra(self):
             import torch.distributed as dist
-            flag = os.environ.get('GD_GPR_OVERLAP')
-            if flag is not None:
-                return flag != '0' and self.shards_over_ranks()
             return (self.overlap_min_ranks is not None
                     and self.shards_over_ranks()
                     and dist.get_world_size() >= self.overlap_min_ranks)
@@ -789,7 +790,9 @@ def distributed_backend(**kwargs):
             key = (tuple(map(id, dgraphs)), id(jobs) if not
                    jobs.flags.writeable else hash(jobs.tobytes()),
                    nX, nY, bool(traits.symmetric),
-                   traits.eval_gradient is True, rank, world)
+                   traits.eval_gradient is True, rank, world,
+                   traits.nodal is not False,
+                   self._label_blind(edge_kernel))
             hit = self._shard_plans.get(key)
             if hit is None:
                 if len(self._shard_plans) > 8:

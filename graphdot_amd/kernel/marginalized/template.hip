@@ -5,7 +5,6 @@
 // reference's graphdot/kernel/marginalized/template.cu.)
 #define GD_REAL ${real}
 #define GD_WEIGHTED ${weighted}
-#define GD_WPB ${wpb}
 #include <hip/hip_runtime.h>
 #include <numpy_type.h>
 #include <fmath.h>

@@ -6,13 +6,13 @@ whole-step PREDICTION of DESIGN.md section 8, not a measurement of N GPUs:
   shard        value + gradient solvers of the rank's 1 / N of the pairs
   values       value solvers of the same pairs (the first step of the
                overlapped form)
-  dense        the replicated part: Cholesky (potrf.hip), L^-1, K^-1 = X^T X,
-               K^-1 y, log-determinant -- on the FULL matrix of a previous
-               full evaluation
+  dense        the replicated part: factor and inverse (potrf.hip, one launch
+               since round 6), K^-1 y, log-determinant -- on the FULL matrix
+               of a previous full evaluation
   contraction  sum_p m_p W[i_p, j_p] dK[p, :] over the rank's pairs
   serial       shard, then dense, then contraction
   overlapped   values, then dense BESIDE the detached value + gradient
-               solvers, then contraction (gpr.py with GD_GPR_OVERLAP)
+               solvers, then contraction (gpr.py with `overlap_min_ranks` set)
 
 The collectives are not in it (one GPU): add the all-gather of the value
 slabs, the reassembly and the all-reduce of n_theta numbers from

@@ -41,6 +41,14 @@ for d in ('pmc_a', 'pmc_b', 'pmc_fetch', 'pmc_write'):
             traffic.setdefault(r.Kernel_Name, {})[r.Counter_Name + '_KiB'] = \
                 float(r.value_per_dispatch)
 pd.concat(rows).to_csv(f'profiles/{tag}_pmc.csv', index=False)
+# the kernel trace's average duration per kernel (`bench.py --serial`: every
+# launch alone on one stream) travels with the counters: bench.py prints it
+# beside its own HIP-event duration (roofline.rocprof_avg_launch_ms)
+stats = pd.read_csv(f'profiles/{tag}_kernel_stats.csv')
+for _, r in stats.iterrows():
+    if str(r['Name']).startswith('mgk') and r['Name'] in traffic:
+        traffic[r['Name']]['rocprof_avg_launch_ms'] = float(r['AverageNs']) / 1e6
+        traffic[r['Name']]['rocprof_calls'] = int(r['Calls'])
 for k, v in traffic.items():
     v['hbm_bytes_per_launch'] = 1024 * (v.get('FETCH_SIZE_KiB', 0)
                                         + v.get('WRITE_SIZE_KiB', 0))
@@ -57,6 +65,8 @@ except (OSError, ValueError):
 # key of this profile in traffic.json: the arithmetic, or argv[2] for the
 # profiles of other workloads (gradient, configuration 2)
 key = sys.argv[2] if len(sys.argv) > 2 else bench['dtype']
-everything[key] = {'source': f'profiles/{tag}_pmc.csv', 'kernels': traffic}
+everything[key] = {'source': f'profiles/{tag}_pmc.csv',
+                   'kernel_trace': f'profiles/{tag}_kernel_stats.csv',
+                   'kernels': traffic}
 json.dump(everything, open('profiles/traffic.json', 'w'), indent=1)
 print(json.dumps(traffic, indent=1))

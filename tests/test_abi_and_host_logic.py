@@ -651,7 +651,7 @@ def test_packed_edge_records_are_offered_only_where_they_are_exact():
     assert not packed_expression('sqrtf(x1.a * x2.a)')
     # the rendered translation units: the weighted SquareExponential edge
     # kernel of the dense molecular set gets the packed record in float, not
-    # in double, and GD_PACKED_EDGES=0 switches it off
+    # in double
     kn, ke, q = cases.tang2019_kernels()
     G = cases.tang2019_graphs(3)
     from graphdot_amd.kernel.marginalized import MarginalizedGraphKernel
@@ -741,8 +741,8 @@ def test_lds_diagonals_of_the_six_batch_layout_on_the_host():
     """mgk_oc.h DLDS, host half: the double graph-level value kernel of the
     six-batch static layout keeps its Jacobi diagonals in LDS -- 2 R reals
     per lane more in the [Y] region, three waves per SIMD --, its nodal
-    flavours, the value + gradient solver, the float build and a build with
-    -DGD_OC_DLDS=0 do not (two waves for the double ones).  (That host and
+    flavours, the value + gradient solver and the float build do not (two
+    waves for the double ones).  (That host and
     device agree is a static_assert in every rendered kernel: the compile
     matrix checks it.)"""
     from graphdot_amd.kernel.marginalized._backend_hip import (
@@ -755,9 +755,4 @@ def test_lds_diagonals_of_the_six_batch_layout_on_the_host():
     assert extra == 2 * 6 * 64 * 8
     assert b._waves_without_lds_diagonals(v6, 1, False) == 3
     assert b._waves_without_lds_diagonals(v6, 1, True) == 2
-    off = HIPBackend(real=np.float64, hipcc_extra=['-DGD_OC_DLDS=0'])
-    assert not off.diagonals_in_lds(v6, 1)
-    assert off._waves_without_lds_diagonals(v6, 1, False) == 2
     assert not HIPBackend(real=np.float32).diagonals_in_lds(v6, 1)
-    mixed = HIPBackend(real=np.float64, hipcc_extra=['-DGD_OC_MIXED=1'])
-    assert not mixed.diagonals_in_lds(v6, 1)

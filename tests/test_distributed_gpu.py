@@ -54,9 +54,10 @@ def _worker(rank, world, port, tmp):
     # the overlapped form (off by default): the matrix from a value step of
     # its own, the value + gradient solvers detached on low-priority streams
     # while the factorisation is enqueued, joined before the contraction
-    os.environ['GD_GPR_OVERLAP'] = '1'
+    k.backend.overlap_min_ranks = 1
+    assert k.backend.overlaps_dense_algebra() is True
     lml3, glml3 = gpr.log_marginal_likelihood(eval_gradient=True)
-    del os.environ['GD_GPR_OVERLAP']
+    k.backend.overlap_min_ranks = None
     assert k.backend.overlaps_dense_algebra() is False
     pending = k.backend.last_step
     assert not pending.gather_gradient and pending.n_grad == k.n_dims

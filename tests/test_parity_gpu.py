@@ -2154,29 +2154,3 @@ def test_double_scalars_build_follows_the_restatement():
     kd = MarginalizedGraphKernel(knode, kedge, q=q,
                                  backend=HIPBackend(real=np.float64))
     assert np.allclose(kd(G)[ii, jj], val, rtol=2e-7)
-
-
-def test_mixed_precision_refinement_build():
-    """-DGD_OC_MIXED=1 (mgk_oc.h MIXED: float iteration, double residual,
-    iterative refinement; measured slower than the float-scalar double
-    iteration and off by default): the build still meets the fp64 parity bar
-    -- rel 1e-9 against the converged oracle at ftol = 1e-13, and the
-    reference's stopping rule on the TRUE residual at the default ftol."""
-    from graphdot_amd.kernel.marginalized._backend_hip import HIPBackend
-    G = cases.config3_graphs(40, seed=13)
-    knode, kedge, q = cases.config3_kernels()
-    backend = HIPBackend(real=np.float64, hipcc_extra=['-DGD_OC_MIXED=1'],
-                         record_iterations=True)
-    ii, jj = np.triu_indices(len(G))
-    batch = oracle.TensorProductBatch(G, knode, kedge)
-    ref, _ = batch.run(ii, jj, q=q, real='f64', tol=1e-13)
-    k = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend,
-                                ftol=1e-13)
-    K = k(G)
-    assert all(L['variant'].L for L in backend.last_plan.launches)
-    assert np.allclose(K[ii, jj], ref, rtol=1e-9)
-    k8 = MarginalizedGraphKernel(knode, kedge, q=q, backend=backend)
-    assert np.allclose(k8(G)[ii, jj], ref, rtol=2e-7)
-    plain = MarginalizedGraphKernel(knode, kedge, q=q, ftol=1e-13,
-                                    backend=HIPBackend(real=np.float64))
-    assert np.allclose(plain(G)[ii, jj], ref, rtol=1e-9)
