@@ -237,12 +237,19 @@ template<class K> struct packed_edge<K, std::void_t<typename K::packed_edge_t>> 
 template<class real, int S, int R, int W, int C, bool NODAL, int DMAX, bool TAB, bool NGRAD, bool MAXIMIN, class LAY, class Graph, class NodeK, class EdgeK, class PStart>
 struct oc_solver {
     constexpr static bool STATIC = LAY::is_static;
-    // (round 6: static layouts of several waves per pair -- graphs of degree
-    // up to 8, value solves: the layout is one compile-time fact for the whole
-    // workgroup and must dominate the trip profile of every one of its waves,
-    // HIPBackend.oc_trips with W > 1)
-    static_assert(!STATIC || W == 1 || (C == 1 && !NGRAD && !MAXIMIN),
-                  "static row-batch layouts of several waves: value solves");
+    // (Round 6, measured and dropped: static layouts of SEVERAL waves per pair
+    // for graphs of degree 5-8 -- one compile-time layout per workgroup that
+    // dominates the trip profile of each of its waves.  Configuration 2's
+    // dynamic multi-wave launches need only 20-30 such profiles each
+    // (scripts/config2_trip_profiles.py), but the static kernels are slower:
+    // 84-146 ns per pair against 67 for the two-batch 8-wave launches, 123
+    // against 115 for the three-batch one at two waves per SIMD, 316 with
+    // packed addresses at four (272 bytes of scratch against the dynamic
+    // kernel's 112) -- without the branches between the slots the scheduler
+    // keeps more gathers and addresses live than the 128 registers of a
+    // multi-wave workgroup hold; step 3.54 against 2.42 ms.
+    // profiles/r06_static_multiwave_f32.log, commit fc7ac01.)
+    static_assert(!STATIC || W == 1, "static row-batch layouts are one-wave layouts");
     // FLY (S = 0): no register slots.  The product-graph operator is NOT
     // materialised; the owner of a row walks adj(i1) x adj(i2) in every CG
     // iteration and evaluates the edge microkernel per term, as the reference
@@ -331,8 +338,8 @@ struct oc_solver {
     // configuration 2's (16,40,2) 1.85 -> 1.18 ms, (16,64,3) 1.02 -> 0.88;
     // the 4- and 8-wave variants have the registers and only pay the unpack
     // (+6 ... 9 %, profiles/sessions.md r4_session8).
-    constexpr static bool PACK = C == 1 && !NODAL && !FLY &&
-                                 (sizeof(real) == 4 ? ((S >= 64 || (STATIC && S >= 40)) && W >= 8) : W >= 16);
+    constexpr static bool PACK = C == 1 && !NODAL && !STATIC && !FLY &&
+                                 (sizeof(real) == 4 ? (S >= 64 && W >= 8) : W >= 16);
     constexpr static int NADR = PACK ? (S + 1) / 2 : SA;
     // SL: the values of the LAST SL slots of a lane live in a lane-private
     // LDS column instead of registers (round 4; dynamic multi-wave value
@@ -386,7 +393,7 @@ struct oc_solver {
     // LDS cell instead of 2 R registers lets the four-batch kernel run three
     // waves per SIMD without scratch reloads in the loop -- and is no faster
     // there, 3.08 against 2.98 ms; at two waves it loses 9 %.)
-    constexpr static bool LEAN = STATIC && C == 2 && !NODAL && !SEQ && W == 1;
+    constexpr static bool LEAN = STATIC && C == 2 && !NODAL && !SEQ;
 #ifndef GD_OC_FSCAL
 #define GD_OC_FSCAL 1
 #endif
@@ -438,7 +445,7 @@ struct oc_solver {
     // running-index walk costs 20 VALU per slot, and the setup is a third of
     // a pair's instructions.
     template<class L> constexpr static int grid_slots() {
-        if constexpr (L::is_static && !NGRAD && ONE_PASS) return L::T.end[0] == DMAX * DMAX ? DMAX * DMAX : 0;
+        if constexpr (L::is_static && !NGRAD) return L::T.end[0] == DMAX * DMAX ? DMAX * DMAX : 0;
         else return 0;
     }
     constexpr static int G0 = grid_slots<LAY>();
@@ -961,7 +968,7 @@ struct oc_solver {
                             jb = 0;
                             ++ja;
                         }
-                        if (flush_at(s, fm)) {   // wave-uniform (static layouts: a constant)
+                        if ((fm[s / 32] >> (s % 32)) & 1u) {   // wave-uniform
                             ++kb;
                             j = ja = jb = 0;
                             cur = open_row(kb);

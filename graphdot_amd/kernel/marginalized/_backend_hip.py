@@ -83,12 +83,9 @@ def stream_parts(costs, count, resident, queued):
     return best
 
 
-def OCStatic(*L, D=4, W=1):
-    """Owner-computes variant with the static layout L: batch k of every wave
-    owns exactly L[k] slots (one wave per pair unless W says otherwise --
-    round 6: multi-wave layouts for graphs of degree up to 8, value solves;
-    the layout must dominate the trip profile of EVERY wave of the pair)."""
-    return OCVariant(int(W), int(sum(L)), len(L), D, tuple(int(x) for x in L))
+def OCStatic(*L, D=4):
+    """One-wave owner-computes variant with the static layout L."""
+    return OCVariant(1, int(sum(L)), len(L), D, tuple(int(x) for x in L))
 
 
 #: register-resident solver menu, cheapest first.  A pair fits a variant if
@@ -606,10 +603,6 @@ class HIPBackend(Backend):
         # the numpy restatements it is tested against
         self.native = bool(kwargs.pop(
             'native', True))
-        #: static row-batch layouts of several waves per pair, made to measure
-        #: per job list (`_refine_static`): True, False or a list of layouts
-        self.multiwave_static = kwargs.pop('multiwave_static', True)
-        self._static_parent = {}
         if self.native:
             from ...hip import hostlib
             hostlib.lib()                  # fail loudly if it cannot be built
@@ -1020,8 +1013,6 @@ struct ${name}_t : ${name}_theta_t {
         the publish address), the gathers in flight and ~24 others; a double
         takes two registers."""
         f64 = np.dtype(self.real) == np.float64
-        if v in self._static_parent:
-            return self._oc_waves(self._static_parent[v], C, ngrad)
         if v.S == 0:
             # on-the-fly kernels: no slot arrays, but the unrolled term loops
             # keep ~140 registers busy (spill-free at three waves per SIMD)
@@ -1312,32 +1303,12 @@ void ${name}(params_t prm) {
         return worst
 
     @staticmethod
-    def oc_trips(hist1, hist2, D, nb, W=1):
-        """Per-batch trip counts of the owner-computes walk: entry [t, k] is
-        the degree product of the first row of batch k (rows 64 k ...) of job
-        t in the sorted row order, 0 for batches without rows.  A static
-        layout L fits job t iff trips[t, k] <= L[k] for all k < len(L) and the
-        job has no rows beyond 64 W len(L).  W > 1: batches of 64 W rows whose
-        64-row chunks go to the waves in snake order (mgk_oc.h row_pos); the
-        entry is the LARGEST trip count among the W waves of batch k -- a
-        static layout is compile-time code, one for the whole workgroup."""
-        if W > 1:
-            order = sorted(((a, b) for a in range(D + 1) for b in range(D + 1)),
-                           key=lambda t: -t[0] * t[1])
-            prods = np.array([a * b for a, b in order] + [0], dtype=np.int64)
-            sizes = hist1[:, [a for a, _ in order]] * hist2[:, [b for _, b in order]]
-            cum = np.cumsum(sizes, axis=1)
-            if len(cum) == 0:
-                return np.zeros((0, nb), dtype=np.int64)
-            out = np.zeros((len(cum), nb), dtype=np.int64)
-            kk = np.arange(nb, dtype=np.int64)
-            for w in range(W):
-                first = kk * 64 * W + 64 * np.where(kk % 2 == 1, W - 1 - w, w)
-                c = (cum[:, None, :] <= first[None, :, None]).sum(axis=2)
-                live = first[None, :] < cum[:, -1:]
-                out = np.maximum(out, np.where(
-                    live, prods[np.minimum(c, len(order))], 0))
-            return out
+    def oc_trips(hist1, hist2, D, nb):
+        """Per-batch trip counts of the one-wave owner-computes walk: entry
+        [t, k] is the degree product of the first row of batch k (rows
+        64 k ...) of job t in the sorted row order, 0 for batches without
+        rows.  A static layout L fits job t iff trips[t, k] <= L[k] for all
+        k < len(L) and the job has no rows beyond 64 len(L)."""
         order = sorted(((a, b) for a in range(D + 1) for b in range(D + 1)),
                        key=lambda t: -t[0] * t[1])
         prods = np.array([a * b for a, b in order] + [0], dtype=np.int64)
@@ -1458,8 +1429,7 @@ void ${name}(params_t prm) {
             count = np.bincount(pk, minlength=nc * nc)
         upk = np.flatnonzero(count)
         out = self._classify_pairs(rep[upk // nc], rep[upk % nc], dgraphs, C,
-                                   tab_bytes, gtab, oc_only, nodal, mfma,
-                                   weights=count[upk])
+                                   tab_bytes, gtab, oc_only, nodal, mfma)
         return ClassPairs(pk, upk, count, nc), out
 
     #: row batches the trip tables cover (static layouts have at most this many)
@@ -1477,11 +1447,9 @@ void ${name}(params_t prm) {
             hists[D] = (H, hid.reshape(-1))
         return hists[D]
 
-    def _trip_table(self, ji, jj, dgraphs, maxdeg, pair_maxdeg, D, hists,
-                    W=1):
+    def _trip_table(self, ji, jj, dgraphs, maxdeg, pair_maxdeg, D, hists):
         """(trips per distinct histogram pair in use, row of every job in
-        that table or -1 if a graph of the job exceeds degree D).  W > 1: the
-        batch-wise maximum over the W waves of a pair (`oc_trips`)."""
+        that table or -1 if a graph of the job exceeds degree D)."""
         H, hid = self._degree_hists(dgraphs, maxdeg, D, hists)
         nH = len(H)
         row = np.full(len(ji), -1, dtype=np.int64)
@@ -1489,90 +1457,11 @@ void ${name}(params_t prm) {
         pk = hid[ji[idx]] * nH + hid[jj[idx]]
         upk, inv = np.unique(pk, return_inverse=True)
         row[idx] = inv.reshape(-1)
-        tr = self.oc_trips(H[upk // nH], H[upk % nH], D, self.TRIP_BATCHES,
-                           W)
+        tr = self.oc_trips(H[upk // nH], H[upk % nH], D, self.TRIP_BATCHES)
         return tr, row
 
-    #: a profile-guided static layout must serve at least this many waves
-    #: (pairs x waves per pair: the launch-merging threshold), and a pair may
-    #: walk at most this share of slots more than its own profile has
-    STATIC_MIN_WAVES = 8192
-    STATIC_MAX_PADDING = 0.12
-    STATIC_MAX_LAYOUTS = 4        # per dynamic variant they are taken from
-
-    def _refine_static(self, choice, ji, jj, dgraphs, C, N, maxdeg,
-                       pair_maxdeg, hists, weights, nodal):
-        """Round 6: static row-batch layouts of SEVERAL waves per pair, made
-        to measure.  The molecular menu (OC_STATIC_VARIANTS) is a fixed list
-        because molecular degree products fall into eleven profiles; graphs of
-        degree 5-8 (configuration 2: reference
-        benchmark/kernel/marginalized/time_kernel.py:14-29) have other
-        profiles -- but few of them per set (scripts/config2_trip_profiles.py:
-        20-30 per dynamic launch, the six most common ones under one
-        layout).  After the regular classification, for every dynamic D > 4
-        multi-wave value launch: the workgroup trip profiles of its pairs
-        (batch-wise maximum over the waves, `oc_trips`), most common first; a
-        layout takes the profiles it dominates at <= 12 % more slots than the
-        pair needs; layouts that collect fewer than STATIC_MIN_WAVES waves
-        are dropped.  The layouts become variants of this backend (appended
-        to `self.variants`; their code is compiled on first use and cached
-        like any other).  `self.multiwave_static`: True (default), False, or
-        an explicit list of `OCStatic(..., W=)` to choose from."""
-        mode = self.multiwave_static
-        if not mode or C != 1 or nodal or len(choice) == 0:
-            return choice
-        f64 = np.dtype(self.real) == np.float64
-        if weights is None:
-            weights = np.ones(len(choice), dtype=np.int64)
-        choice = choice.copy()
-        for k in sorted(set(choice.tolist())):
-            v = self.variants[k] if k >= 0 else None
-            if not (isinstance(v, OCVariant) and not v.L and v.S > 0
-                    and v.W > 1 and v.D > 4):
-                continue
-            # (double, 16 waves: the dynamic kernels keep slot values in LDS
-            # to stay under the 128-register cap -- SL; static ones do not)
-            if f64 and v.W >= 16:
-                continue
-            idx = np.flatnonzero(choice == k)
-            tr, row = self._trip_table(ji[idx], jj[idx], dgraphs, maxdeg,
-                                       pair_maxdeg[idx], v.D, hists, v.W)
-            prof = tr[row]                              # (len(idx), nb)
-            need = prof.sum(axis=1)
-            w = weights[idx]
-            uniq, inv = np.unique(prof, axis=0, return_inverse=True)
-            inv = inv.reshape(-1)
-            pop = np.bincount(inv, weights=w, minlength=len(uniq))
-            if isinstance(mode, (list, tuple)):
-                cands = [np.array(list(x.L) + [0] * (prof.shape[1] - len(x.L)))
-                         for x in mode if x.W == v.W and x.D == v.D]
-            else:
-                cands = [uniq[u] for u in np.argsort(-pop)]
-            free = np.ones(len(idx), dtype=bool)
-            made = 0
-            for cand in cands:
-                if made >= self.STATIC_MAX_LAYOUTS or not free.any():
-                    break
-                L = tuple(int(x) for x in cand if x > 0)
-                if not L or sum(L) > 64:      # (larger slot arrays stay in scratch)
-                    continue
-                ok = free & (prof <= cand[None, :]).all(axis=1) & \
-                    (N[idx] <= 64 * v.W * len(L)) & \
-                    (sum(L) <= (1 + self.STATIC_MAX_PADDING) * need)
-                if w[ok].sum() * v.W < self.STATIC_MIN_WAVES:
-                    continue
-                sv = OCStatic(*L, D=v.D, W=v.W)
-                if sv not in self.variants:
-                    self.variants.append(sv)
-                # (occupancy target: that of the dynamic variant it relieves)
-                self._static_parent[sv] = v
-                choice[idx[ok]] = self.variants.index(sv)
-                free &= ~ok
-                made += 1
-        return choice
-
     def _classify_pairs(self, ji, jj, dgraphs, C, tab_bytes=0, gtab=False,
-                        oc_only=False, nodal=False, mfma=False, weights=None):
+                        oc_only=False, nodal=False, mfma=False):
         f = graph_features(dgraphs)
         n_node, n_nz = f['n_node'], f['n_nz']
         deg_sorted = None      # (the two-stage variants' walk: made on demand)
@@ -1658,11 +1547,10 @@ void ${name}(params_t prm) {
                 if v.L:
                     # static layout: the trip count of every batch under its
                     # segment (looked up per pair of distinct histograms)
-                    if (v.D, v.W) not in trips:
-                        trips[v.D, v.W] = self._trip_table(
-                            ji, jj, dgraphs, maxdeg, pair_maxdeg, v.D, hists,
-                            v.W)
-                    tr, row = trips[v.D, v.W]
+                    if v.D not in trips:
+                        trips[v.D] = self._trip_table(
+                            ji, jj, dgraphs, maxdeg, pair_maxdeg, v.D, hists)
+                    tr, row = trips[v.D]
                     idx = rem[fits]
                     ok = row[idx] >= 0
                     L = np.zeros(tr.shape[1], dtype=np.int64)
@@ -1721,9 +1609,6 @@ void ${name}(params_t prm) {
             choice[dense] = self.variants.index(MFMA)
             gbytes = np.where(dense, np.maximum(f['image_bytes'][ji],
                                                 f['image_bytes'][jj]), gbytes)
-        if not tab_bytes and not oc_only:
-            choice = self._refine_static(choice, ji, jj, dgraphs, C, N, maxdeg,
-                                         pair_maxdeg, hists, weights, nodal)
         if np.any(choice < 0) and oc_only:
             raise NotOwnerComputes
         if np.any(choice < 0):

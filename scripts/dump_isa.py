@@ -40,8 +40,8 @@ if dgs[0].weighted:      # (as HIPBackend._graphs_and_kernels wraps it)
 oc = [int(a.split('=')[1]) for a in sys.argv if a.startswith('--oc=')]
 lay = [a.split('=')[1] for a in sys.argv if a.startswith('--layout=')]
 variant = OCVariant(W, S, R, oc[0]) if oc else Variant(W, S, R)
-if lay:       # --layout=16x4x4x1 (S R are then ignored; W > 1: a multi-wave layout)
-    variant = OCStatic(*map(int, lay[0].split('x')), D=oc[0] if oc else 4, W=W)
+if lay:       # --layout=16x4x4x1 (W S R are then ignored)
+    variant = OCStatic(*map(int, lay[0].split('x')))
 src = backend.render_source(kn, ke2, k.p, node_t, edge_t, [variant], C,
                             tab=2 if '--tab=2' in sys.argv else '--tab' in sys.argv,
                             weighted=dgs[0].weighted)
