@@ -64,8 +64,14 @@ def fits(prod_sorted, L):
                for k in range(len(L)))
 
 
-def slot_addresses(rp1, nj1, rp2, nj2, L, ldp, grid=True, lane_of=None):
-    """dword index of p gathered by every lane in every slot: [S, 64]."""
+def slot_addresses(rp1, nj1, rp2, nj2, L, ldp, grid=True, lane_of=None,
+                   swz=None):
+    """dword index of p gathered by every lane in every slot: [S, 64].
+    `swz(j1, j2)`: the column of element (j1, j2) within its row of p (round
+    6: bank swizzles -- XOR of row bits into the column -- against the odd
+    stride)."""
+    if swz is None:
+        swz = lambda j1, j2: j2
     rm, d1, d2 = sorted_rows(rp1, rp2)
     N = len(rm)
     S = sum(L)
@@ -85,10 +91,11 @@ def slot_addresses(rp1, nj1, rp2, nj2, L, ldp, grid=True, lane_of=None):
                     for v in range(DMAX):
                         if u < a and v < b:
                             adr[s0 + u * DMAX + v, lane] = \
-                                n1_[u] * ldp + n2_[v]
+                                n1_[u] * ldp + swz(n1_[u], n2_[v])
             else:
                 for t in range(min(Lk, a * b)):
-                    adr[s0 + t, lane] = n1_[t // b] * ldp + n2_[t % b]
+                    adr[s0 + t, lane] = n1_[t // b] * ldp + \
+                        swz(n1_[t // b], n2_[t % b])
         s0 += Lk
     return adr
 
@@ -133,6 +140,18 @@ def main():
             'stride n2, grid': dict(ldp=n2, grid=True),
             'stride 32, grid': dict(ldp=32, grid=True),
             'stride 33, grid': dict(ldp=33, grid=True),
+            # swizzles on rows of 32 cells (n2 <= 23 on this set): the row
+            # index XORed into the column bits
+            'stride 32, col ^ row': dict(
+                ldp=32, grid=True, swz=lambda j1, j2: j2 ^ (j1 & 31)),
+            'stride 32, col ^ 3 row': dict(
+                ldp=32, grid=True, swz=lambda j1, j2: j2 ^ ((3 * j1) & 31)),
+            'stride 32, col ^ 5 row': dict(
+                ldp=32, grid=True, swz=lambda j1, j2: j2 ^ ((5 * j1) & 31)),
+            'stride 32, col ^ 7 row': dict(
+                ldp=32, grid=True, swz=lambda j1, j2: j2 ^ ((7 * j1) & 31)),
+            'stride 32, col + 11 row (rotate)': dict(
+                ldp=32, grid=True, swz=lambda j1, j2: (j2 + 11 * j1) & 31),
         }
         for name, kw in cases_.items():
             c = gather_cycles(slot_addresses(rp1, nj1, rp2, nj2, L, **kw))

@@ -45,6 +45,42 @@ __global__ __launch_bounds__(256) void probe(double *out, unsigned long long *t,
 #pragma unroll 16
         for (int i = 0; i < N; ++i) xf = __builtin_fmaf(xf, yf, yf);
         x = xf;
+    } else if (MODE == 8) {     // independent v_fma_f64, THREE distinct register sources (acc += b * c)
+        double a[8], b[8], c[8];
+        for (int k = 0; k < 8; ++k) { a[k] = x + k; b[k] = y + k * 1e-3; c[k] = y - k * 1e-3; }
+#pragma unroll 2
+        for (int i = 0; i < N / 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a[k] = __builtin_fma(b[k], c[k], a[k]);
+                asm volatile("" : "+v"(a[k]), "+v"(b[k]), "+v"(c[k]));
+            }
+        x = 0;
+        for (int k = 0; k < 8; ++k) x += a[k];
+    } else if (MODE == 9) {     // the same with ONE shared multiplier register (acc += b * y)
+        double a[8], b[8];
+        for (int k = 0; k < 8; ++k) { a[k] = x + k; b[k] = y + k * 1e-3; }
+#pragma unroll 2
+        for (int i = 0; i < N / 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a[k] = __builtin_fma(b[k], y, a[k]);
+                asm volatile("" : "+v"(a[k]), "+v"(b[k]));
+            }
+        x = 0;
+        for (int k = 0; k < 8; ++k) x += a[k];
+    } else if (MODE == 10) {    // independent v_mul_f64, two distinct sources
+        double a[8], b[8], c[8];
+        for (int k = 0; k < 8; ++k) { a[k] = x + k; b[k] = y + k * 1e-3; c[k] = y - k * 1e-3; }
+#pragma unroll 2
+        for (int i = 0; i < N / 8; ++i)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                a[k] = b[k] * c[k];
+                asm volatile("" : "+v"(a[k]), "+v"(b[k]), "+v"(c[k]));
+            }
+        x = 0;
+        for (int k = 0; k < 8; ++k) x += a[k];
     } else if (MODE == 7) {     // barrier alone
         for (int i = 0; i < N; ++i) { __syncthreads(); x += y; }
     }
@@ -72,6 +108,9 @@ int main() {
         run<3>("8 independent v_fma_f64 chains (per fma)", threads);
         run<5>("dependent compare + add + select (f64)", threads);
         run<6>("dependent v_fma_f32", threads);
+        run<8>("independent fma, 3 distinct sources (per fma)", threads);
+        run<9>("independent fma, shared multiplier (per fma)", threads);
+        run<10>("independent mul, 2 distinct sources (per mul)", threads);
     }
     run<4>("LDS write -> barrier -> read + add", 256);
     run<7>("barrier + add", 256);
