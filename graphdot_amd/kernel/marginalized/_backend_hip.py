@@ -2220,8 +2220,12 @@ void ${name}(params_t prm) {
         # gradient: three, 64.5 against 63.7 M; the same plans run to
         # convergence, ftol 1e-13 and 26 iterations instead of 17: three, 126.6
         # against 125.7 M, r5_session36 -- hence the tolerance in the rule).
+        # Round 6: the float value plans too -- equal on the full matrix, and on
+        # a rank's share of it (354 graphs, five launches) 0.342 against 0.373 ms
+        # per step (double: 0.447 against 0.455; one stream: 0.513 / 0.392;
+        # scripts/fixed_cost_experiment.sh, profiles/r06_fixed_cost.log).
         plan.stream_hint = 2 if (
-            np.dtype(self.real) == np.float64 and C == 1 and not nodal
+            C == 1 and not nodal
             and not ngrad and len(launches) > 2 and ftol >= 1e-10
             and all(isinstance(L['variant'], OCVariant) and L['variant'].L
                     for L in launches)) else None
