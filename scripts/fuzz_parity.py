@@ -235,7 +235,7 @@ def main():
                                          'bulk', 'bulkgrad', 'huge', 'maximin',
                                          'gradmodes', 'ringlist', 'nodalgrad',
                                          'startprob', 'pairlist', 'features',
-                                         'spatial', 'sharded'])
+                                         'spatial', 'sharded', 'mfma'])
         stats[(family, mode, 'f64' if f64 else 'f32')] = \
             stats.get((family, mode, 'f64' if f64 else 'f32'), 0) + 1
         tag = f'round {it} seed {seed}: {family} {mode} {real.__name__} q={q} ' \
@@ -322,6 +322,52 @@ def main():
                 dev = (np.abs(g_ - want).max(axis=0) / scale).max() if len(ij) else 0.0
                 assert np.isfinite(g_).all() and dev < (1e-6 if f64 else 4e-3), \
                     (tag, float(dev))
+            elif mode == 'mfma':
+                # the dense-tile solver on the matrix cores (mgk_mfma.h: float
+                # value solves of DENSE pairs of graphs of at most 32 nodes
+                # under an edge kernel that ignores the labels): dense graphs
+                # of 2-32 nodes mixed with sparse ones and with graphs just
+                # beyond the tile (33-40 nodes: they must take another solver),
+                # weighted or not, every output mode of a value solve, against
+                # the dense oracle; the launches must include the MFMA kernel
+                def dense_graph(n):
+                    g = nx.gnp_random_graph(n, float(rng.uniform(0.7, 1.0)),
+                                            seed=int(rng.integers(1 << 30)))
+                    for u in range(n - 1):
+                        g.add_edge(u, u + 1)
+                    for v in g.nodes:
+                        g.nodes[v]['category'] = int(rng.integers(1, 4))
+                        g.nodes[v]['radius'] = float(rng.choice([1.0, 1.5, 2.0]))
+                    for e in g.edges:
+                        g.edges[e]['w'] = float(rng.choice([0.5, 1.0, 2.0])) \
+                            if weighted else 1.0
+                        g.edges[e]['length'] = float(rng.uniform(0.5, 2.5))
+                        g.edges[e]['order'] = int(rng.integers(1, 3))
+                    return Graph.from_networkx(g, weight='w' if weighted else None)
+                sizes = [int(rng.integers(2, 33)) for _ in range(int(rng.integers(3, 9)))] \
+                    + [32, int(rng.integers(33, 41))]
+                Gm = [dense_graph(n_) for n_ in sizes] + \
+                    [random_graph('tree', weighted), random_graph('ring', weighted)]
+                Gm = Graph.unify_datatype([Gm[i_] for i_ in rng.permutation(len(Gm))])
+                bm = HIPBackend(real=np.float32)
+                km = MarginalizedGraphKernel(kn, Constant(float(rng.choice([1.0, 0.7]))),
+                                             q=q, backend=bm)
+                tagm = tag + f' mfma: sizes {[len(g.nodes) for g in Gm]}'
+                rt = 2e-5 * max(1.0, 0.05 / q)
+                want = oracle.gram(Gm, kn, km.edge_kernel, q=q)
+                check(tagm, km(Gm), want, rt)
+                names = [bm.kernel_name(L['variant'], 1, False, L.get('tab', False))
+                         for L in bm.last_plan.launches]
+                assert any('mfma' in n_ for n_ in names), (tagm, names)
+                h = len(Gm) // 2
+                check(tagm + ' (X x Y)', km(Gm[:h], Gm[h:]),
+                      oracle.gram(Gm[:h], kn, km.edge_kernel, Y=Gm[h:], q=q), rt)
+                check(tagm + ' (diag)', km.diag(Gm), np.diag(want), rt)
+                check(tagm + ' (lmin)', km(Gm, lmin=1),
+                      oracle.gram(Gm, kn, km.edge_kernel, q=q, lmin=1), 10 * rt)
+                refn = oracle.gram(Gm[:3], kn, km.edge_kernel, q=q, nodal=True)
+                check(tagm + ' (nodal)', km(Gm[:3], nodal=True), refn, rt,
+                      atol=rt * np.abs(refn).max())
             elif mode == 'features':
                 # Normalize(DotProduct()) over a vector attribute and Convolution
                 # over a variable-length one, on nodes and edges (reference:

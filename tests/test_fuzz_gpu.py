@@ -28,6 +28,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     (12, 'features', 6),
     (13, 'spatial', 2),
     (14, 'sharded', 2),
+    # round 6: the dense-tile solver on the matrix cores (mgk_mfma.h)
+    (15, 'mfma', 5),
 ])
 def test_fuzzer_rounds(seed, modes, rounds):
     cmd = [sys.executable, os.path.join(ROOT, 'scripts', 'fuzz_parity.py'),
