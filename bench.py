@@ -513,6 +513,16 @@ def gpr_fit_line(args, world, rank, backend, graphs, real, dist,
     start = None
     for _ in range(max(args.warmup, 1)):
         start = gpr.log_marginal_likelihood(theta0, eval_gradient=True)[0]
+    # (the line search of this fit overshoots once into hyperparameters whose
+    # kernel matrix is not positive definite: that evaluation takes the
+    # pseudo-inverse like the reference's, base.py:108-127 -- 22 ms of
+    # torch.linalg.eigh at n = 1000, but 205 ms the first time a process
+    # calls it (library initialisation, scripts/fit_probe.py): warmed here
+    # like the code objects above)
+    if torch.cuda.is_available():
+        w_ = torch.randn(256, 256, dtype=torch.float64, device='cuda')
+        torch.linalg.eigh(w_ + w_.T)
+        del w_
     evals, parts = [0], {'kernel': 0.0, 'linalg': 0.0}
     objective = gpr.log_marginal_likelihood
 
