@@ -1,45 +1,51 @@
 #!/usr/bin/env python3
 """The dense algebra of one GPR likelihood + gradient step, piece by piece
-(n = 1000, n_theta gradient planes, float64, MI355X)."""
+(n = 1000, n_theta gradient planes, float64, MI355X): the round-6 path --
+one-launch factor-and-invert (potrf.hip), K^-1 y, W, the contraction with the
+gradient planes, ONE download."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import torch
 import numpy as np
-from graphdot_amd.model.gaussian_process.gpr import _Dense
-from graphdot_amd.model.gaussian_process._potrf import cholesky_
-n, nt = 1000, 6
+from graphdot_amd.model.gaussian_process.gpr import _contract_planes
+from graphdot_amd.model.gaussian_process._potrf import factor_inverse, parse_head
+n, nt = 1000, 7
 dev = torch.device('cuda')
 g = torch.Generator(device='cpu').manual_seed(0)
 A = torch.randn(n, n, generator=g, dtype=torch.float64)
 K = (A @ A.T / n + torch.eye(n, dtype=torch.float64)).to(dev)
-dK = torch.randn(nt, n, n, generator=g, dtype=torch.float64).to(dev).permute(1, 2, 0)   # planes contiguous
+dK = torch.randn(nt, n, n, generator=g, dtype=torch.float64).to(dev).permute(2, 1, 0)   # planes contiguous
 y = torch.randn(n, generator=g, dtype=torch.float64).to(dev)
-la = _Dense('cuda')
-def timed(name, f, reps=20):
+
+
+def timed(name, f, reps=50):
     f(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         r = f()
     torch.cuda.synchronize()
-    print(f'{name:44s} {1e3 * (time.perf_counter() - t0) / reps:7.3f} ms')
+    print(f'{name:52s} {1e3 * (time.perf_counter() - t0) / reps:7.3f} ms')
     return r
-timed('clone + potrf.hip + tril', lambda: torch.tril(cholesky_(K.clone())))
-L = torch.tril(cholesky_(K.clone()))
-timed('finite / positive check (host sync)', lambda: bool((torch.isfinite(torch.diagonal(L)) & (torch.diagonal(L) > 0)).all()))
-I = torch.eye(n, dtype=torch.float64, device=dev)
-X = timed('solve_triangular(L, I)', lambda: torch.linalg.solve_triangular(L, I, upper=False))
-Kinv = timed('X^T X', lambda: X.T @ X)
-timed('eye(n)', lambda: torch.eye(n, dtype=torch.float64, device=dev))
-timed('logdet (host sync)', lambda: float(2.0 * torch.log(torch.diagonal(L)).sum()))
+
+
+timed('K.clone()', lambda: K.clone())
+Kinv, head, nb = timed('factor_inverse(K) (clone + workspaces + launch)', lambda: factor_inverse(K))
 Ky = timed('Kinv @ y', lambda: Kinv @ y)
-timed('y @ Ky (host sync)', lambda: float(y @ Ky))
-timed('(Kinv[..., None] * dK).sum((0, 1))', lambda: (Kinv.unsqueeze(-1) * dK).sum((0, 1)))
-timed('Ky @ tensordot(Ky, dK)', lambda: Ky @ torch.tensordot(Ky, dK, dims=([0], [0])))
-W = Kinv - torch.outer(Ky, Ky)
-timed('W = Kinv - Ky Ky^T', lambda: Kinv - torch.outer(Ky, Ky))
-timed('(W[..., None] * dK).sum((0, 1))', lambda: (W.unsqueeze(-1) * dK).sum((0, 1)))
-dKp = dK.permute(2, 0, 1)
-timed('(dKp * W).sum((1, 2))  [plane-major]', lambda: (dKp * W).sum((1, 2)))
-timed('dKp.reshape(nt, -1) @ W.reshape(-1)', lambda: dKp.reshape(nt, -1) @ W.reshape(-1))
-timed('factor() as a whole', lambda: la.factor(K, 1e-10))
-timed('.cpu() of the gradient', lambda: (dKp.reshape(nt, -1) @ W.reshape(-1)).cpu())
+timed('y @ Ky', lambda: y @ Ky)
+W = timed('W = Kinv - outer(Ky, Ky)', lambda: Kinv - torch.outer(Ky, Ky))
+d = timed('contraction with the planes', lambda: _contract_planes(W, dK))
+timed('cat + .cpu()', lambda: torch.cat((head[:16 + 2 * nb].view(torch.float64), (y @ Ky).reshape(1), d)).cpu())
+
+
+def whole():
+    Kinv, head, nb = factor_inverse(K)
+    Ky = Kinv @ y
+    W = Kinv - torch.outer(Ky, Ky)
+    return torch.cat((head[:16 + 2 * nb].view(torch.float64), (y @ Ky).reshape(1),
+                      _contract_planes(W, dK))).cpu()
+
+
+t0 = time.perf_counter()
+for _ in range(50):
+    whole()
+print(f'{"the whole dense part, one download per step":52s} {1e3 * (time.perf_counter() - t0) / 50:7.3f} ms')
